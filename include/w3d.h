@@ -1,0 +1,123 @@
+/*
+ * w3d.h — C-ABI of the MI355X-native Gaussian rasterizer (libw3d_hip.so).
+ *
+ * This is the drop-in boundary underneath Wheat-3DGS's Python rasterizer modules.  Each entry
+ * point replaces one native call of the (un-vendored) CUDA submodules the reference binds:
+ *
+ *   w3d_forward_stage1 + w3d_forward_stage2
+ *        <- diff_gaussian_rasterization._C.rasterize_gaussians, reached from
+ *           GaussianRasterizer(...)(means3D, means2D, shs, colors_precomp, opacities, scales,
+ *           rotations, cov3D_precomp)          reference gaussian_renderer/__init__.py:55,89-97
+ *        <- flashsplat_rasterization's forward (8 outputs; gt_mask / num_obj)
+ *                                              reference gaussian_renderer/__init__.py:149,194-204
+ *   w3d_backward
+ *        <- diff_gaussian_rasterization._C.rasterize_gaussians_backward, reached from
+ *           loss.backward()                    reference train_vanilla_3dgs.py:80
+ *   w3d_knn_dist2
+ *        <- simple_knn._C.distCUDA2            reference scene/gaussian_model.py:20,148
+ *   w3d_l1_ssim_fwd_bwd (next-row N1)
+ *        <- utils/loss_utils.py:17-63 as used at train_vanilla_3dgs.py:77-80
+ *   w3d_adam_step (next-row N2)
+ *        <- torch.optim.Adam over the 6 parameter groups, scene/gaussian_model.py:172-182
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  Every pointer named in a
+ * signature is a DEVICE pointer unless its name ends in _host.  All arrays are fp32, dense,
+ * row-major with the shapes the reference's Python passes (means3D (P,3), shs (P,M,3),
+ * opacities (P,1), scales (P,3), rotations (P,4), cov3D_precomp (P,6), images (C,H,W)).
+ * viewmatrix / projmatrix are the TRANSPOSED matrices exactly as scene/cameras.py:56-58 builds
+ * them.  The caller owns every buffer (outputs, state, scratch, lists) and allocates them with
+ * its own allocator (torch's, in the Python host); the library never allocates device memory
+ * and keeps no global mutable state besides the last-error string (thread-local).
+ * All work is enqueued on `stream`; nothing synchronises unless stated.
+ *
+ * Return value: 0 on success, a W3D_ERR_* code otherwise (w3d_last_error() has the text).
+ */
+#ifndef W3D_H_
+#define W3D_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *w3d_stream_t; /* hipStream_t */
+
+enum {
+    W3D_OK = 0,
+    W3D_ERR_INVALID = 1,  /* bad argument (null pointer, non-positive size, unsupported degree...) */
+    W3D_ERR_CAPACITY = 2, /* a caller-provided buffer is too small */
+    W3D_ERR_HIP = 3,      /* a HIP runtime call or kernel launch failed */
+    W3D_ERR_UNSUPPORTED = 4
+};
+
+/* GaussianRasterizationSettings of the reference (gaussian_renderer/__init__.py:40-53), flattened. */
+typedef struct w3d_view {
+    int32_t image_height, image_width;
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;       /* ACTIVE degree 0..3 */
+    int32_t sh_coeffs;       /* coefficients stored per Gaussian in `shs` (16 for max degree 3) */
+    int32_t prefiltered;     /* accepted, unused (always False in the reference) */
+    int32_t debug;           /* 1: synchronise + check after every kernel */
+    const float *bg;         /* device (3,) */
+    const float *viewmatrix; /* device (4,4) transposed world->view */
+    const float *projmatrix; /* device (4,4) transposed full projection */
+    const float *campos;     /* device (3,) */
+} w3d_view;
+
+int w3d_version(void);
+const char *w3d_last_error(void);
+
+/* Bytes of the per-call `state` buffer (kept alive until backward has run) and of the
+ * temporary `scratch` buffer (may be released after stage 2).  Both must be 256-B aligned. */
+int w3d_forward_sizes(int32_t P, int32_t H, int32_t W, uint64_t *state_bytes, uint64_t *scratch_bytes);
+
+/* Stage 1: preprocess (cull, project, covariance, SH->RGB), global depth sort of the Gaussians,
+ * per-tile counting and scan.  Writes radii (P,) int32.  If counts_host is non-NULL the two
+ * counters {num_visible, num_rendered} are copied there and the stream is synchronised (the one
+ * host sync of a forward pass: the per-tile list length R = num_rendered sizes stage 2's list). */
+int w3d_forward_stage1(const w3d_view *view, int32_t P, const float *means3D, const float *shs,
+                       const float *colors_precomp, const float *opacities, const float *scales,
+                       const float *rotations, const float *cov3D_precomp, int32_t *radii, void *state,
+                       void *scratch, uint32_t *counts_host, w3d_stream_t stream);
+
+/* Stage 2: fill the per-tile depth-ordered lists (point_list, capacity in entries, must be
+ * >= num_rendered) and blend front-to-back.  out_color (3,H,W), out_depth (1,H,W), out_alpha
+ * (1,H,W).  FlashSplat extras are all nullable: gt_mask (H,W) fp32 labels in [0,num_obj],
+ * used_count (num_obj+1,P) is ACCUMULATED into (caller zero-fills), contrib_num (H,W) int32,
+ * proj_xy (P,2), gs_depth (P,). */
+int w3d_forward_stage2(const w3d_view *view, int32_t P, void *state, void *scratch, uint32_t *point_list,
+                       uint64_t list_capacity, float *out_color, float *out_depth, float *out_alpha,
+                       const float *gt_mask, int32_t num_obj, float *used_count, int32_t *contrib_num,
+                       float *proj_xy, float *gs_depth, w3d_stream_t stream);
+
+int w3d_backward_sizes(int32_t P, uint64_t *scratch_bytes);
+
+/* Backward of stage1+stage2.  dL_dcolor (3,H,W) required; dL_ddepth / dL_dalpha (H,W) nullable
+ * (Wheat-3DGS's loss never feeds them).  Outputs are OVERWRITTEN (zero rows for culled
+ * Gaussians): dL_dmeans3D (P,3), dL_dmeans2D (P,3) [x,y scaled by W/2,H/2; z = 0 — the
+ * densification statistic of scene/gaussian_model.py:462], dL_dopacity (P,1), and per input
+ * variant dL_dshs (P,M,3) | dL_dcolors (P,3), dL_dscales (P,3) + dL_drots (P,4) | dL_dcov3D (P,6).
+ * Unused variant outputs may be NULL. */
+int w3d_backward(const w3d_view *view, int32_t P, const float *means3D, const float *shs,
+                 const float *colors_precomp, const float *opacities, const float *scales,
+                 const float *rotations, const float *cov3D_precomp, const void *state,
+                 const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth,
+                 const float *dL_dalpha, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors,
+                 float *dL_dshs, float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
+                 void *scratch, w3d_stream_t stream);
+
+/* mean squared distance to the 3 nearest other points; points (N,3) -> out (N,) */
+int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream);
+
+/* Debug/inspection: copies of internal per-tile ranges (T,2) uint32 laid out as [start,end). */
+int w3d_debug_tile_ranges(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *ranges_out, w3d_stream_t stream);
+/* Debug/inspection of the per-pixel state kept for backward: final_T (H,W) f32, n_contrib (H,W) u32. */
+int w3d_debug_pixel_state(int32_t H, int32_t W, int32_t P, const void *state, float *final_T_out,
+                          uint32_t *n_contrib_out, w3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* W3D_H_ */

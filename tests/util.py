@@ -1,0 +1,58 @@
+"""Shared helpers of the test-suite (inputs for one view of a synthetic scene)."""
+import math
+
+import numpy as np
+import torch
+
+from w3d_amd.synth import small_test_scene, make_scene, make_cameras
+
+
+def view_inputs(sc, cam, sh_degree=3, precomp_color=False, precomp_cov=False, scale_modifier=1.0):
+    """Activated rasterizer inputs exactly as reference render() marshals them
+    (gaussian_renderer/__init__.py:57-84)."""
+    from oracle.oracle import torch_cov3d, torch_sh_to_rgb
+    means = sc.xyz.float().contiguous()
+    opac = torch.sigmoid(sc.opacity).float().contiguous()
+    scales = torch.exp(sc.scaling).float().contiguous()
+    rots = torch.nn.functional.normalize(sc.rotation).float().contiguous()
+    shs = torch.cat([sc.features_dc, sc.features_rest], 1).float().contiguous()
+    d = dict(means3D=means, opacities=opac, shs=shs, colors_precomp=None, scales=scales, rotations=rots,
+             cov3D_precomp=None)
+    if precomp_color:
+        d["colors_precomp"] = torch_sh_to_rgb(sh_degree, shs, means, cam.camera_center.float()).contiguous()
+        d["shs"] = None
+    if precomp_cov:
+        d["cov3D_precomp"] = torch_cov3d(scales, rots, scale_modifier).contiguous()
+        d["scales"] = d["rotations"] = None
+    return d
+
+
+def cam_settings(cam, bg, sh_degree=3, scale_modifier=1.0):
+    return dict(H=cam.image_height, W=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
+                tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, viewmatrix=cam.world_view_transform,
+                projmatrix=cam.full_proj_transform, campos=cam.camera_center, sh_degree=sh_degree,
+                scale_modifier=scale_modifier)
+
+
+def make_oracle(cam, bg, sh_degree=3, scale_modifier=1.0, nthreads=1):
+    from oracle.oracle import COracle
+    s = cam_settings(cam, bg, sh_degree, scale_modifier)
+    return COracle(s["H"], s["W"], s["tanfovx"], s["tanfovy"], np.asarray(bg, np.float32),
+                   cam.world_view_transform.cpu().numpy(), cam.full_proj_transform.cpu().numpy(),
+                   cam.camera_center.cpu().numpy(), sh_degree=sh_degree, scale_modifier=scale_modifier,
+                   nthreads=nthreads)
+
+
+def np_inputs(d):
+    return {k: (None if v is None else v.detach().cpu().numpy()) for k, v in d.items()}
+
+
+def psnr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    mse = ((a - b) ** 2).mean()
+    return 20 * math.log10(1.0 / math.sqrt(mse)) if mse > 0 else float("inf")
+
+
+def rel_err(x, ref):
+    x, ref = np.asarray(x, np.float64), np.asarray(ref, np.float64)
+    return float(np.abs(x - ref).max() / (np.abs(ref).max() + 1e-30))

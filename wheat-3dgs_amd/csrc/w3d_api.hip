@@ -1,0 +1,179 @@
+// w3d_api.hip — the extern "C" boundary declared in include/w3d.h: argument checks, buffer
+// layout, kernel sequencing.  No device allocation, no global mutable state except the
+// thread-local last-error text.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "w3d_common.h"
+
+static thread_local char g_err[512] = "";
+
+void w3d_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int w3d_debug_tile_ranges_impl(const W3DLayout &L, const char *state, uint32_t *ranges_out, hipStream_t stream);
+int w3d_debug_pixel_state_impl(const W3DLayout &L, const char *state, float *final_T_out, uint32_t *n_contrib_out,
+                               hipStream_t stream);
+
+static int check_view(const w3d_view *v) {
+    if (!v) { w3d_set_error("view is NULL"); return W3D_ERR_INVALID; }
+    if (v->image_height <= 0 || v->image_width <= 0) { w3d_set_error("image size must be positive"); return W3D_ERR_INVALID; }
+    if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos) { w3d_set_error("view holds a NULL device pointer"); return W3D_ERR_INVALID; }
+    if (v->sh_degree < 0 || v->sh_degree > 3) { w3d_set_error("sh_degree %d unsupported (0..3)", v->sh_degree); return W3D_ERR_UNSUPPORTED; }
+    return W3D_OK;
+}
+
+static int check_variants(const w3d_view *v, const float *shs, const float *colors_precomp, const float *scales,
+                          const float *rotations, const float *cov3D_precomp) {
+    if ((shs == nullptr) == (colors_precomp == nullptr)) {
+        w3d_set_error("provide exactly one of shs / colors_precomp");
+        return W3D_ERR_INVALID;
+    }
+    const bool sr = scales && rotations;
+    if ((scales == nullptr) != (rotations == nullptr) || sr == (cov3D_precomp != nullptr)) {
+        w3d_set_error("provide exactly one of (scales, rotations) / cov3D_precomp");
+        return W3D_ERR_INVALID;
+    }
+    if (shs && v->sh_coeffs < (v->sh_degree + 1) * (v->sh_degree + 1)) {
+        w3d_set_error("shs holds %d coefficients, degree %d needs %d", v->sh_coeffs, v->sh_degree, (v->sh_degree + 1) * (v->sh_degree + 1));
+        return W3D_ERR_INVALID;
+    }
+    return W3D_OK;
+}
+
+extern "C" {
+
+int w3d_version(void) { return 100; }
+
+const char *w3d_last_error(void) { return g_err; }
+
+int w3d_forward_sizes(int32_t P, int32_t H, int32_t W, uint64_t *state_bytes, uint64_t *scratch_bytes) {
+    W3DLayout L;
+    int rc = w3d_make_layout(P, H, W, &L);
+    if (rc) { w3d_set_error("bad sizes P=%d H=%d W=%d", P, H, W); return rc; }
+    if (state_bytes) *state_bytes = L.state_bytes;
+    if (scratch_bytes) *scratch_bytes = L.scratch_bytes;
+    return W3D_OK;
+}
+
+int w3d_forward_stage1(const w3d_view *view, int32_t P, const float *means3D, const float *shs,
+                       const float *colors_precomp, const float *opacities, const float *scales,
+                       const float *rotations, const float *cov3D_precomp, int32_t *radii, void *state,
+                       void *scratch, uint32_t *counts_host, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    int rc = check_view(view);
+    if (rc) return rc;
+    W3DLayout L;
+    rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
+    if (rc) { w3d_set_error("bad sizes"); return rc; }
+    if (!state || !scratch) { w3d_set_error("state/scratch is NULL"); return W3D_ERR_INVALID; }
+    if (P > 0) {
+        if (!means3D || !opacities || !radii) { w3d_set_error("means3D/opacities/radii is NULL"); return W3D_ERR_INVALID; }
+        rc = check_variants(view, shs, colors_precomp, scales, rotations, cov3D_precomp);
+        if (rc) return rc;
+    }
+    char *st = static_cast<char *>(state), *sc = static_cast<char *>(scratch);
+    rc = w3d_launch_preprocess(L, *view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii,
+                               st, sc, nullptr, stream);
+    if (rc) return rc;
+    rc = w3d_launch_sort_and_count(L, *view, st, sc, stream);
+    if (rc) return rc;
+    if (counts_host) {
+        W3D_HIP_CHECK(hipMemcpyAsync(counts_host, st + L.o_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        W3D_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    return W3D_OK;
+}
+
+int w3d_forward_stage2(const w3d_view *view, int32_t P, void *state, void *scratch, uint32_t *point_list,
+                       uint64_t list_capacity, float *out_color, float *out_depth, float *out_alpha,
+                       const float *gt_mask, int32_t num_obj, float *used_count, int32_t *contrib_num,
+                       float *proj_xy, float *gs_depth, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    int rc = check_view(view);
+    if (rc) return rc;
+    W3DLayout L;
+    rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
+    if (rc) { w3d_set_error("bad sizes"); return rc; }
+    if (!state || !scratch || !out_color || !out_depth || !out_alpha) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
+    if (list_capacity > 0 && !point_list) { w3d_set_error("point_list is NULL"); return W3D_ERR_INVALID; }
+    if (gt_mask && used_count && num_obj < 0) { w3d_set_error("num_obj must be >= 0"); return W3D_ERR_INVALID; }
+    char *st = static_cast<char *>(state), *sc = static_cast<char *>(scratch);
+    rc = w3d_launch_fill_lists(L, *view, st, sc, point_list, list_capacity, stream);
+    if (rc) return rc;
+    rc = w3d_launch_render(L, *view, st, point_list, out_color, out_depth, out_alpha, gt_mask, num_obj, used_count,
+                           contrib_num, stream);
+    if (rc) return rc;
+    if (proj_xy || gs_depth) {
+        // radii are not kept in the state; visibility is re-derived from the tile rectangle
+        rc = w3d_launch_flash_extras(L, *view, nullptr, st, proj_xy, gs_depth, stream);
+        if (rc) return rc;
+    }
+    return W3D_OK;
+}
+
+int w3d_backward_sizes(int32_t P, uint64_t *scratch_bytes) {
+    if (P < 0) { w3d_set_error("P < 0"); return W3D_ERR_INVALID; }
+    if (scratch_bytes) *scratch_bytes = w3d_align_up((uint64_t)(P > 0 ? P : 1) * W3D_G2D_STRIDE * sizeof(float));
+    return W3D_OK;
+}
+
+int w3d_backward(const w3d_view *view, int32_t P, const float *means3D, const float *shs,
+                 const float *colors_precomp, const float *opacities, const float *scales,
+                 const float *rotations, const float *cov3D_precomp, const void *state,
+                 const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth,
+                 const float *dL_dalpha, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors,
+                 float *dL_dshs, float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
+                 void *scratch, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    (void)opacities;
+    int rc = check_view(view);
+    if (rc) return rc;
+    W3DLayout L;
+    rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
+    if (rc) { w3d_set_error("bad sizes"); return rc; }
+    if (P == 0) return W3D_OK;
+    if (!state || !scratch || !dL_dcolor || !means3D || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity) {
+        w3d_set_error("NULL buffer");
+        return W3D_ERR_INVALID;
+    }
+    rc = check_variants(view, shs, colors_precomp, scales, rotations, cov3D_precomp);
+    if (rc) return rc;
+    if (shs && !dL_dshs) { w3d_set_error("dL_dshs is NULL"); return W3D_ERR_INVALID; }
+    if (scales && (!dL_dscales || !dL_drots)) { w3d_set_error("dL_dscales/dL_drots is NULL"); return W3D_ERR_INVALID; }
+    if (cov3D_precomp && !dL_dcov3D) { w3d_set_error("dL_dcov3D is NULL"); return W3D_ERR_INVALID; }
+    const char *st = static_cast<const char *>(state);
+    float *grad2d = static_cast<float *>(scratch);
+    rc = w3d_launch_render_backward(L, *view, st, point_list, dL_dcolor, dL_ddepth, dL_dalpha, grad2d, stream);
+    if (rc) return rc;
+    return w3d_launch_preprocess_backward(L, *view, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, st,
+                                          grad2d, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dshs, dL_dopacity, dL_dscales,
+                                          dL_drots, dL_dcov3D, stream);
+}
+
+int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream_) {
+    if (N < 0 || (N > 0 && (!points || !out))) { w3d_set_error("bad knn arguments"); return W3D_ERR_INVALID; }
+    return w3d_launch_knn(N, points, out, reinterpret_cast<hipStream_t>(stream_));
+}
+
+int w3d_debug_tile_ranges(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *ranges_out, w3d_stream_t stream_) {
+    W3DLayout L;
+    int rc = w3d_make_layout(P, H, W, &L);
+    if (rc || !state || !ranges_out) { w3d_set_error("bad arguments"); return W3D_ERR_INVALID; }
+    return w3d_debug_tile_ranges_impl(L, static_cast<const char *>(state), ranges_out, reinterpret_cast<hipStream_t>(stream_));
+}
+
+int w3d_debug_pixel_state(int32_t H, int32_t W, int32_t P, const void *state, float *final_T_out,
+                          uint32_t *n_contrib_out, w3d_stream_t stream_) {
+    W3DLayout L;
+    int rc = w3d_make_layout(P, H, W, &L);
+    if (rc || !state) { w3d_set_error("bad arguments"); return W3D_ERR_INVALID; }
+    return w3d_debug_pixel_state_impl(L, static_cast<const char *>(state), final_T_out, n_contrib_out,
+                                      reinterpret_cast<hipStream_t>(stream_));
+}
+
+}  // extern "C"

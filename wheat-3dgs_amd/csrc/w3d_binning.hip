@@ -1,0 +1,329 @@
+// w3d_binning.hip — depth sort of the Gaussians and construction of the per-tile lists
+// (replaces the scan / duplicate-with-keys / 64-bit radix sort /
+// identify-ranges stage of the reference's CUDA submodule).
+//
+// MI355X-first formulation.  Instead of materialising R = sum(tiles touched) 64-bit
+// (tile|depth) keys and radix-sorting all of them through HBM, the order contract
+// "within a tile ascending depth bits, ties by ascending Gaussian index" is met in two steps:
+//   1. ONE stable LSD radix sort of the P (depth bits, index) pairs  — P << R, 16 B per Gaussian;
+//   2. a single-pass stable counting sort of the tile instances by tile id: the Gaussians are
+//      cut into C depth-contiguous chunks, one wave per chunk; a wave keeps a counter for EVERY
+//      tile of the image in LDS (2 B x T in the count pass, 4 B x T in the fill pass — 7500
+//      tiles at 1600x1200 = 15/30 KB per wave, which is what the 160 KB LDS of a CDNA4 CU buys)
+//      and walks its Gaussians in depth order, lanes <-> tiles of the current Gaussian's
+//      rectangle, so every list slot is written exactly once, already in its final position.
+// HBM traffic: 4 B per tile instance (the list itself) + the C x T counter matrices, instead
+// of >= 6 passes x 24 B per instance.  No atomics on the instance path.
+//
+// Everything here is wave-synchronous (wave64): the LDS counters of a wave are private to it,
+// so there is no __syncthreads() in the hot loops.
+#include "w3d_common.h"
+
+namespace {
+
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+
+// ------------------------------------------------------------------------------ radix sort
+// One pass = histogram, row scan, scatter.  A "run" is the contiguous slice of keys one wave owns.
+__global__ void __launch_bounds__(256)
+radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items, uint32_t n_runs, int shift,
+                  uint32_t *__restrict__ hist /* [256][n_runs] */) {
+    __shared__ uint32_t h_all[4][256];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t run = blockIdx.x * 4 + wv;
+    volatile uint32_t *h = h_all[wv];
+    for (int i = lane; i < 256; i += 64) h[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (run < n_runs) {
+        const uint32_t beg = run * items, end = min(n, beg + items);
+        for (uint32_t i = beg + lane; i < end; i += 64) {
+            const uint32_t d = (keys[i] >> shift) & 255u;
+            atomicAdd(const_cast<uint32_t *>(&h_all[wv][d]), 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < 256; i += 64) hist[(size_t)i * n_runs + run] = h[i];
+    }
+}
+
+// exclusive scan of the whole [256][n_runs] matrix in row-major (digit-major) order; one block.
+__global__ void __launch_bounds__(1024)
+radix_scan_kernel(uint32_t *__restrict__ hist, uint32_t total) {
+    __shared__ uint32_t partial[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (total + 1023) / 1024;
+    const uint32_t beg = min(total, tid * per), end = min(total, beg + per);
+    uint32_t sum = 0;
+    for (uint32_t i = beg; i < end; i++) sum += hist[i];
+    partial[tid] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (tid >= off) ? partial[tid - off] : 0;
+        __syncthreads();
+        partial[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = (tid == 0) ? 0 : partial[tid - 1];
+    for (uint32_t i = beg; i < end; i++) {
+        const uint32_t c = hist[i];
+        hist[i] = run;
+        run += c;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t items,
+                     uint32_t n_runs, int shift, const uint32_t *__restrict__ offs /* scanned [256][n_runs] */) {
+    __shared__ uint32_t cur_all[4][256];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t run = blockIdx.x * 4 + wv;
+    if (run >= n_runs) return;
+    volatile uint32_t *cur = cur_all[wv];
+    for (int i = lane; i < 256; i += 64) cur[i] = offs[(size_t)i * n_runs + run];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t beg = run * items, end = min(n, beg + items);
+    const uint64_t lt = lanemask_lt();
+    for (uint32_t base = beg; base < end; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < end;
+        const uint32_t key = valid ? keys_in[i] : 0u;
+        const uint32_t val = valid ? vals_in[i] : 0u;
+        const uint32_t d = (key >> shift) & 255u;
+        // lanes holding the same digit (stable rank = number of such lanes below me)
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t rank = __popcll(peers & lt);
+        uint32_t pos = 0;
+        if (valid) pos = cur[d] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) cur[d] = pos + (uint32_t)__popcll(peers);   // group leader advances the cursor
+        __builtin_amdgcn_wave_barrier();
+        if (valid) { keys_out[pos] = key; vals_out[pos] = val; }
+    }
+}
+
+// ------------------------------------------------------------------------------ tile counting
+__device__ __forceinline__ void divmod_small(uint32_t k, uint32_t w, float inv_w, uint32_t &q, uint32_t &r) {
+    q = (uint32_t)((float)k * inv_w);
+    if (q * w > k) q--;
+    if ((q + 1) * w <= k) q++;
+    r = k - q * w;
+}
+
+// One wave per depth-contiguous chunk.  MODE 0: count (u16 LDS counters, dumps the row of the
+// count matrix).  MODE 1: fill (u32 LDS cursors initialised from the offset matrix; writes list).
+template <int MODE>
+__global__ void __launch_bounds__(256)
+chunk_walk_kernel(const uint32_t *__restrict__ sorted_ids, const uint2 *__restrict__ rect, const uint32_t *__restrict__ counters,
+                  uint32_t chunk, uint32_t C, uint32_t T, uint32_t gx, uint32_t waves_per_block,
+                  uint16_t *__restrict__ cnt, const uint32_t *__restrict__ off, uint32_t *__restrict__ point_list,
+                  uint64_t capacity) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wv >= waves_per_block) return;
+    const uint32_t c = blockIdx.x * waves_per_block + wv;
+    if (c >= C) return;
+    const uint32_t V = counters[0];
+    const uint32_t Tpad = (T + 63u) & ~63u;
+    volatile uint16_t *h16 = reinterpret_cast<volatile uint16_t *>(smem) + (size_t)wv * Tpad;
+    volatile uint32_t *h32 = reinterpret_cast<volatile uint32_t *>(smem) + (size_t)wv * Tpad;
+    if (MODE == 0) {
+        for (uint32_t t = lane; t < Tpad; t += 64) h16[t] = 0;
+    } else {
+        const uint32_t *row = off + (size_t)c * T;
+        for (uint32_t t = lane; t < T; t += 64) h32[t] = row[t];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t s_beg = min(V, c * chunk), s_end = min(V, s_beg + chunk);
+    for (uint32_t base = s_beg; base < s_end; base += 64) {
+        const uint32_t nb = min(64u, s_end - base);
+        uint32_t my_g = 0;
+        uint2 my_rc = make_uint2(0u, 0u);
+        if (lane < nb) {
+            my_g = sorted_ids[base + lane];
+            my_rc = rect[my_g];
+        }
+        for (uint32_t j = 0; j < nb; j++) {
+            const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)j);
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)my_rc.x, (int)j);
+            const uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)my_rc.y, (int)j);
+            const uint32_t minx = r0 & 0xFFFFu, miny = r0 >> 16, maxx = r1 & 0xFFFFu, maxy = r1 >> 16;
+            const uint32_t w = maxx - minx, n = w * (maxy - miny);
+            const float inv_w = 1.0f / (float)w;
+            for (uint32_t kb = 0; kb < n; kb += 64) {
+                const uint32_t k = kb + lane;
+                if (k < n) {
+                    uint32_t ty, tx;
+                    divmod_small(k, w, inv_w, ty, tx);
+                    const uint32_t t = (miny + ty) * gx + minx + tx;
+                    if (MODE == 0) {
+                        h16[t] = (uint16_t)(h16[t] + 1);
+                    } else {
+                        const uint32_t pos = h32[t];
+                        h32[t] = pos + 1;
+                        if (pos < capacity) point_list[pos] = g;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (MODE == 0) {
+        __builtin_amdgcn_wave_barrier();
+        uint16_t *row = cnt + (size_t)c * T;
+        for (uint32_t t = lane; t < T; t += 64) row[t] = h16[t];
+    }
+}
+
+// ------------------------------------------------------------------------------ offset scan
+// part[sg][t] = sum over the chunks of segment sg of cnt[c][t]
+__global__ void __launch_bounds__(256)
+seg_sum_kernel(const uint16_t *__restrict__ cnt, uint32_t C, uint32_t T, uint32_t seg, uint32_t *__restrict__ part) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, sg = blockIdx.y;
+    if (t >= T) return;
+    const uint32_t c0 = sg * seg, c1 = min(C, c0 + seg);
+    uint32_t s = 0;
+    for (uint32_t c = c0; c < c1; c++) s += cnt[(size_t)c * T + t];
+    part[(size_t)sg * T + t] = s;
+}
+
+// one block: totals per tile -> exclusive scan -> tile_start[T+1]; part[][] becomes the
+// absolute list offset at which each segment starts inside its tile; counters[1] = R.
+__global__ void __launch_bounds__(1024)
+tile_scan_kernel(uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, uint32_t *__restrict__ tile_start,
+                 uint32_t *__restrict__ counters) {
+    __shared__ uint32_t partial[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (T + 1023) / 1024;
+    const uint32_t beg = min(T, tid * per), end = min(T, beg + per);
+    uint32_t sum = 0;
+    for (uint32_t t = beg; t < end; t++)
+        for (uint32_t s = 0; s < nseg; s++) sum += part[(size_t)s * T + t];
+    partial[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (tid >= off) ? partial[tid - off] : 0;
+        __syncthreads();
+        partial[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = (tid == 0) ? 0 : partial[tid - 1];
+    for (uint32_t t = beg; t < end; t++) {
+        tile_start[t] = run;
+        for (uint32_t s = 0; s < nseg; s++) {
+            const uint32_t c = part[(size_t)s * T + t];
+            part[(size_t)s * T + t] = run;
+            run += c;
+        }
+    }
+    if (tid == 1023) {
+        tile_start[T] = partial[1023];
+        counters[1] = partial[1023];
+    }
+}
+
+// off[c][t] = start of chunk c's entries inside tile t's list
+__global__ void __launch_bounds__(256)
+chunk_off_kernel(const uint16_t *__restrict__ cnt, const uint32_t *__restrict__ part, uint32_t C, uint32_t T, uint32_t seg,
+                 uint32_t *__restrict__ off) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, sg = blockIdx.y;
+    if (t >= T) return;
+    const uint32_t c0 = sg * seg, c1 = min(C, c0 + seg);
+    uint32_t run = part[(size_t)sg * T + t];
+    for (uint32_t c = c0; c < c1; c++) {
+        off[(size_t)c * T + t] = run;
+        run += cnt[(size_t)c * T + t];
+    }
+}
+
+__global__ void copy_ranges_kernel(const uint32_t *__restrict__ tile_start, uint32_t T, uint32_t *__restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) { out[2 * t] = tile_start[t]; out[2 * t + 1] = tile_start[t + 1]; }
+}
+
+uint32_t pick_waves_per_block(uint64_t bytes_per_wave) {
+    uint64_t w = (160u * 1024u) / (bytes_per_wave ? bytes_per_wave : 1);
+    if (w > 4) w = 4;
+    return (uint32_t)w;
+}
+
+}  // namespace
+
+int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream) {
+    uint32_t *counters = reinterpret_cast<uint32_t *>(state + L.o_counters);
+    uint32_t *tile_start = reinterpret_cast<uint32_t *>(state + L.o_tile_start);
+    uint32_t *keys[2] = {reinterpret_cast<uint32_t *>(scratch + L.s_keys0), reinterpret_cast<uint32_t *>(scratch + L.s_keys1)};
+    uint32_t *vals[2] = {reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(scratch + L.s_vals1)};
+    uint32_t *hist = reinterpret_cast<uint32_t *>(scratch + L.s_hist);
+    uint16_t *cnt = reinterpret_cast<uint16_t *>(scratch + L.s_cnt);
+    uint32_t *part = reinterpret_cast<uint32_t *>(scratch + L.s_part);
+    uint32_t *off = reinterpret_cast<uint32_t *>(scratch + L.s_off);
+    const uint32_t T = (uint32_t)L.T;
+    if (L.P > 0) {
+        // ---- stable LSD radix sort of (depth bits, id), 4 x 8 bits; culled Gaussians carry key 0xFFFFFFFF
+        const uint32_t n = (uint32_t)L.P, runs = L.sort_waves, blocks = (runs + 3) / 4;
+        int src = 0;
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 8 * pass;
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], n, L.sort_items, runs, shift, hist);
+            W3D_LAUNCH_CHECK(v.debug, stream);
+            hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, 256u * runs);
+            W3D_LAUNCH_CHECK(v.debug, stream);
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], vals[src], keys[src ^ 1],
+                               vals[src ^ 1], n, L.sort_items, runs, shift, hist);
+            W3D_LAUNCH_CHECK(v.debug, stream);
+            src ^= 1;
+        }
+        // after 4 passes the sorted ids are back in vals[0]
+    }
+    // ---- per-chunk per-tile counts
+    const uint64_t bpw16 = (uint64_t)((T + 63u) & ~63u) * 2;
+    const uint32_t wpb = pick_waves_per_block(bpw16);
+    if (wpb == 0) { w3d_set_error("image has too many tiles (%u) for the LDS-resident binning", T); return W3D_ERR_UNSUPPORTED; }
+    const size_t lds16 = (size_t)bpw16 * wpb;
+    if (lds16 > 64 * 1024)
+        W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+    hipLaunchKernelGGL(chunk_walk_kernel<0>, dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds16, stream, vals[0],
+                       reinterpret_cast<const uint2 *>(state + L.o_rect), counters, L.chunk, L.C, T, (uint32_t)L.gx, wpb, cnt,
+                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0);
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    // ---- offsets
+    const uint32_t tb = (T + 255) / 256;
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, L.C, T, L.seg, part);
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, part, T, (uint32_t)W3D_SCAN_SEGS, tile_start, counters);
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    hipLaunchKernelGGL(chunk_off_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, part, L.C, T, L.seg, off);
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    return W3D_OK;
+}
+
+int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
+                          uint64_t list_capacity, hipStream_t stream) {
+    const uint32_t T = (uint32_t)L.T;
+    const uint64_t bpw32 = (uint64_t)((T + 63u) & ~63u) * 4;
+    const uint32_t wpb = pick_waves_per_block(bpw32);
+    if (wpb == 0) { w3d_set_error("image has too many tiles (%u) for the LDS-resident binning", T); return W3D_ERR_UNSUPPORTED; }
+    const size_t lds32 = (size_t)bpw32 * wpb;
+    if (lds32 > 64 * 1024)
+        W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+    hipLaunchKernelGGL(chunk_walk_kernel<1>, dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds32, stream,
+                       reinterpret_cast<const uint32_t *>(scratch + L.s_vals0), reinterpret_cast<const uint2 *>(state + L.o_rect),
+                       reinterpret_cast<const uint32_t *>(state + L.o_counters), L.chunk, L.C, T, (uint32_t)L.gx, wpb,
+                       (uint16_t *)nullptr, reinterpret_cast<const uint32_t *>(scratch + L.s_off), point_list, list_capacity);
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    return W3D_OK;
+}
+
+int w3d_debug_tile_ranges_impl(const W3DLayout &L, const char *state, uint32_t *ranges_out, hipStream_t stream) {
+    const uint32_t T = (uint32_t)L.T;
+    hipLaunchKernelGGL(copy_ranges_kernel, dim3((T + 255) / 256), dim3(256), 0, stream,
+                       reinterpret_cast<const uint32_t *>(state + L.o_tile_start), T, ranges_out);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}

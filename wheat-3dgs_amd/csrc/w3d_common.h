@@ -1,0 +1,138 @@
+// w3d_common.h — shared declarations of the gfx950 rasterizer kernels (internal; the public
+// boundary is include/w3d.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/w3d.h"
+
+#define W3D_TILE 16
+#define W3D_WAVE 64
+#define W3D_NEAR 0.2f
+#define W3D_INVALID_KEY 0xFFFFFFFFu
+
+// Upper bounds of the binning geometry (see w3d_binning.hip).
+#define W3D_MAX_CHUNKS 2048       // depth-contiguous chunks of Gaussians, one wave each
+#define W3D_CHUNK_MAX 65472       // per-chunk Gaussian count must fit a u16 counter (multiple of 64)
+#define W3D_SCAN_SEGS 16          // segments of the chunk axis in the offset scan
+
+static inline uint64_t w3d_align_up(uint64_t x, uint64_t a = 256) { return (x + a - 1) / a * a; }
+
+// Everything derived from (P, H, W) that host and kernels agree on.
+struct W3DLayout {
+    int32_t P, H, W, gx, gy, T;
+    uint32_t chunk;   // Gaussians per binning chunk (multiple of 64)
+    uint32_t C;       // number of chunks
+    uint32_t seg;     // chunks per scan segment
+    // ---- state buffer (kept until backward)
+    uint64_t o_counters;   // u32[16]: [0]=num_visible [1]=num_rendered [2]=error flags
+    uint64_t o_xy;         // float2[P]
+    uint64_t o_conic_op;   // float4[P]
+    uint64_t o_rgbd;       // float4[P]  (r,g,b,depth)
+    uint64_t o_rect;       // ushort4[P] (minx,miny,maxx,maxy) tile units
+    uint64_t o_clamped;    // u8[P] bit c set: SH colour channel c clamped at 0
+    uint64_t o_tile_start; // u32[T+1]
+    uint64_t o_final_T;    // float[HW]
+    uint64_t o_n_contrib;  // u32[HW]
+    uint64_t state_bytes;
+    // ---- scratch buffer (forward temporaries)
+    uint64_t s_keys0, s_keys1, s_vals0, s_vals1; // u32[P] each (depth keys, Gaussian ids)
+    uint64_t s_hist;       // u32[256 * sort_waves] radix digit histograms
+    uint64_t s_cnt;        // u16[C*T] per-chunk per-tile counts
+    uint64_t s_off;        // u32[C*T] per-chunk per-tile list offsets
+    uint64_t s_part;       // u32[SEGS*T]
+    uint64_t scratch_bytes;
+    uint32_t sort_waves;   // waves used by the radix passes
+    uint32_t sort_items;   // keys per wave per pass (multiple of 64)
+};
+
+static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L) {
+    if (P < 0 || H <= 0 || W <= 0) return W3D_ERR_INVALID;
+    L->P = P; L->H = H; L->W = W;
+    L->gx = (W + W3D_TILE - 1) / W3D_TILE;
+    L->gy = (H + W3D_TILE - 1) / W3D_TILE;
+    L->T = L->gx * L->gy;
+    if (L->gx > 65535 || L->gy > 65535) return W3D_ERR_UNSUPPORTED;
+    uint64_t Pp = P > 0 ? (uint64_t)P : 1;
+    uint64_t chunk = (Pp + W3D_MAX_CHUNKS - 1) / W3D_MAX_CHUNKS;
+    chunk = (chunk + 63) / 64 * 64;
+    if (chunk < 64) chunk = 64;
+    if (chunk > W3D_CHUNK_MAX) chunk = W3D_CHUNK_MAX;
+    L->chunk = (uint32_t)chunk;
+    L->C = (uint32_t)((Pp + chunk - 1) / chunk);
+    L->seg = (L->C + W3D_SCAN_SEGS - 1) / W3D_SCAN_SEGS;
+    uint64_t HW = (uint64_t)H * W, T = (uint64_t)L->T;
+    uint64_t o = 0;
+    L->o_counters = o;   o += w3d_align_up(16 * 4);
+    L->o_xy = o;         o += w3d_align_up(Pp * 8);
+    L->o_conic_op = o;   o += w3d_align_up(Pp * 16);
+    L->o_rgbd = o;       o += w3d_align_up(Pp * 16);
+    L->o_rect = o;       o += w3d_align_up(Pp * 8);
+    L->o_clamped = o;    o += w3d_align_up(Pp);
+    L->o_tile_start = o; o += w3d_align_up((T + 1) * 4);
+    L->o_final_T = o;    o += w3d_align_up(HW * 4);
+    L->o_n_contrib = o;  o += w3d_align_up(HW * 4);
+    L->state_bytes = o;
+    // radix sort geometry: one wave per contiguous run of sort_items keys
+    uint64_t items = (Pp + 2047) / 2048;         // aim at <= 2048 waves
+    items = (items + 63) / 64 * 64;
+    if (items < 1024) items = 1024;
+    L->sort_items = (uint32_t)items;
+    L->sort_waves = (uint32_t)((Pp + items - 1) / items);
+    o = 0;
+    L->s_keys0 = o; o += w3d_align_up(Pp * 4);
+    L->s_keys1 = o; o += w3d_align_up(Pp * 4);
+    L->s_vals0 = o; o += w3d_align_up(Pp * 4);
+    L->s_vals1 = o; o += w3d_align_up(Pp * 4);
+    L->s_hist = o;  o += w3d_align_up((uint64_t)256 * L->sort_waves * 4);
+    L->s_cnt = o;   o += w3d_align_up((uint64_t)L->C * T * 2);
+    L->s_off = o;   o += w3d_align_up((uint64_t)L->C * T * 4);
+    L->s_part = o;  o += w3d_align_up((uint64_t)W3D_SCAN_SEGS * T * 4);
+    L->scratch_bytes = o;
+    return W3D_OK;
+}
+
+// error plumbing (w3d_api.hip)
+void w3d_set_error(const char *fmt, ...);
+#define W3D_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            w3d_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return W3D_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+#define W3D_LAUNCH_CHECK(view_debug, stream)                                                 \
+    do {                                                                                     \
+        W3D_HIP_CHECK(hipGetLastError());                                                    \
+        if (view_debug) W3D_HIP_CHECK(hipStreamSynchronize(stream));                         \
+    } while (0)
+
+// kernels' host launchers (one per .hip file)
+int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,
+                          const float *colors_precomp, const float *opacities, const float *scales,
+                          const float *rotations, const float *cov3D_precomp, int32_t *radii, char *state,
+                          char *scratch, float *proj_xy_unused, hipStream_t stream);
+int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream);
+int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
+                          uint64_t list_capacity, hipStream_t stream);
+int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const uint32_t *point_list, float *out_color,
+                      float *out_depth, float *out_alpha, const float *gt_mask, int32_t num_obj, float *used_count,
+                      int32_t *contrib_num, hipStream_t stream);
+int w3d_launch_flash_extras(const W3DLayout &L, const w3d_view &v, const int32_t *radii_unused, char *state,
+                            float *proj_xy, float *gs_depth, hipStream_t stream);
+int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char *state, const uint32_t *point_list,
+                               const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha, float *grad2d,
+                               hipStream_t stream);
+int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,
+                                   const float *colors_precomp, const float *scales, const float *rotations,
+                                   const float *cov3D_precomp, const char *state, const float *grad2d,
+                                   float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors, float *dL_dshs,
+                                   float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
+                                   hipStream_t stream);
+int w3d_launch_knn(int32_t N, const float *points, float *out, hipStream_t stream);
+
+// per-Gaussian 2-D gradient record accumulated by the blend backward (16 floats = one 64-B line)
+//  [0] dL/dmean2D.x  [1] dL/dmean2D.y  [2] dL/dconic.x  [3] dL/dconic.y(half)  [4] dL/dconic.z
+//  [5] dL/dopacity   [6..8] dL/drgb    [9] dL/ddepth_g   [10..15] unused
+#define W3D_G2D_STRIDE 16

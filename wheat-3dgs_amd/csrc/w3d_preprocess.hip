@@ -1,0 +1,543 @@
+// w3d_preprocess.hip — per-Gaussian stages of the rasterizer, forward and backward.
+//
+// Forward (replaces the preprocess stage reached through
+// reference gaussian_renderer/__init__.py:89-97): near-plane cull, projection, 3-D covariance
+// from scale/quaternion (or precomputed), EWA 2-D covariance, conic, radius, tile rectangle,
+// SH -> RGB.  One thread per Gaussian, reads coalesced across the wave; writes the packed
+// per-Gaussian records of the state buffer and the depth key / id pair the sort consumes.
+//
+// Backward (Appendix A.5): 2-D gradient record -> means3D, SH | colours, scale + quaternion | cov3D,
+// opacity, and the screen-space gradient used by densification.
+//
+// The geometric part of the forward is compiled with FP contraction OFF and written in one
+// fixed operation order so that every integer derived from it (radii, tile rectangles, depth
+// keys and therefore the per-tile order) is reproducible bit for bit against the CPU oracle.
+#include "w3d_common.h"
+
+namespace {
+
+__device__ __constant__ float SH_C0 = 0.28209479177387814f;
+__device__ __constant__ float SH_C1 = 0.4886025119029199f;
+__device__ __constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                          -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                          0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                          -0.5900435899266435f};
+
+struct Cam {
+    float V[16], M[16], campos[3];
+};
+
+__device__ __forceinline__ void load_cam(const w3d_view &v, Cam &c) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) { c.V[i] = v.viewmatrix[i]; c.M[i] = v.projmatrix[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) c.campos[i] = v.campos[i];
+}
+
+// ---- exact-order geometry (contraction off) -------------------------------------------------
+struct Geo {
+    float depth, px, py;
+    float cov3D[6];
+    float Tm[2][3];
+    float a, b, c;       // 2-D covariance incl. the 0.3 dilation
+    float txc, tyc;      // clamped view-space x,y
+    bool clx, cly;
+};
+
+__device__ __forceinline__ void quat_to_R(const float *q, float R[3][3]) {
+#pragma clang fp contract(off)
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1.f - 2.f * (y * y + z * z);
+    R[0][1] = 2.f * (x * y - r * z);
+    R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z);
+    R[1][1] = 1.f - 2.f * (x * x + z * z);
+    R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y);
+    R[2][1] = 2.f * (y * z + r * x);
+    R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float *scale, float mod, const float *q, float *c) {
+#pragma clang fp contract(off)
+    float R[3][3], L[3][3];
+    quat_to_R(q, R);
+    float s[3] = {mod * scale[0], mod * scale[1], mod * scale[2]};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) L[i][j] = R[i][j] * s[j];
+    c[0] = L[0][0] * L[0][0] + L[0][1] * L[0][1] + L[0][2] * L[0][2];
+    c[1] = L[0][0] * L[1][0] + L[0][1] * L[1][1] + L[0][2] * L[1][2];
+    c[2] = L[0][0] * L[2][0] + L[0][1] * L[2][1] + L[0][2] * L[2][2];
+    c[3] = L[1][0] * L[1][0] + L[1][1] * L[1][1] + L[1][2] * L[1][2];
+    c[4] = L[1][0] * L[2][0] + L[1][1] * L[2][1] + L[1][2] * L[2][2];
+    c[5] = L[2][0] * L[2][0] + L[2][1] * L[2][1] + L[2][2] * L[2][2];
+}
+
+// T = J W and the dilated 2-D covariance.  pv = view-space mean.
+__device__ __forceinline__ void ewa(const w3d_view &v, const Cam &cam, const float *pv, const float *cov3D, Geo &g) {
+#pragma clang fp contract(off)
+    float fx = (float)v.image_width / (2.f * v.tanfovx), fy = (float)v.image_height / (2.f * v.tanfovy);
+    float limx = 1.3f * v.tanfovx, limy = 1.3f * v.tanfovy;
+    float tz = pv[2];
+    float txtz = pv[0] / tz, tytz = pv[1] / tz;
+    g.clx = (txtz < -limx || txtz > limx);
+    g.cly = (tytz < -limy || tytz > limy);
+    float tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+    float ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    g.txc = tx; g.tyc = ty;
+    float J00 = fx / tz, J02 = -(fx * tx) / (tz * tz);
+    float J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+    const float *V = cam.V;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        g.Tm[0][c] = J00 * V[4 * c + 0] + J02 * V[4 * c + 2];
+        g.Tm[1][c] = J11 * V[4 * c + 1] + J12 * V[4 * c + 2];
+    }
+    float S[3][3] = {{cov3D[0], cov3D[1], cov3D[2]}, {cov3D[1], cov3D[3], cov3D[4]}, {cov3D[2], cov3D[4], cov3D[5]}};
+    float TS[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) TS[i][j] = g.Tm[i][0] * S[0][j] + g.Tm[i][1] * S[1][j] + g.Tm[i][2] * S[2][j];
+    g.a = TS[0][0] * g.Tm[0][0] + TS[0][1] * g.Tm[0][1] + TS[0][2] * g.Tm[0][2] + 0.3f;
+    g.b = TS[0][0] * g.Tm[1][0] + TS[0][1] * g.Tm[1][1] + TS[0][2] * g.Tm[1][2];
+    g.c = TS[1][0] * g.Tm[1][0] + TS[1][1] * g.Tm[1][1] + TS[1][2] * g.Tm[1][2] + 0.3f;
+}
+
+__device__ __forceinline__ void xform4x3(const float *m, const float *p, float *o) {
+#pragma clang fp contract(off)
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+__device__ __forceinline__ void xform4x4(const float *m, const float *p, float *o) {
+#pragma clang fp contract(off)
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+    o[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+}
+
+// SH -> RGB (+0.5, clamp at 0).  sh points at this Gaussian's (M,3) block.
+__device__ __forceinline__ void sh_to_rgb(int deg, const float *__restrict__ sh, const float *pos, const float *campos,
+                                          float *rgb, uint32_t &clamped) {
+#pragma clang fp contract(off)
+    float d0 = pos[0] - campos[0], d1 = pos[1] - campos[1], d2 = pos[2] - campos[2];
+    float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    float x = d0 / len, y = d1 / len, z = d2 / len;
+    float r[3];
+    // coefficient k, channel ch lives at sh[3k + ch]; 16-B vector loads when the block is aligned
+    const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
+    float c[48];
+    const int ncoef = (deg + 1) * (deg + 1);
+    const int nvec = (ncoef * 3 + 3) / 4;
+    if ((reinterpret_cast<uintptr_t>(sh) & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++)
+            if (i < nvec) { float4 t = sh4[i]; c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 48; i++)
+            if (i < ncoef * 3) c[i] = sh[i];
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+#define SH(k) c[(k)*3 + ch]
+        float res = SH_C0 * SH(0);
+        if (deg > 0) {
+            res = res - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                res = res + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) + SH_C2[2] * (2.f * zz - xx - yy) * SH(6) +
+                      SH_C2[3] * xz * SH(7) + SH_C2[4] * (xx - yy) * SH(8);
+                if (deg > 2) {
+                    res = res + SH_C3[0] * y * (3.f * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
+                          SH_C3[2] * y * (4.f * zz - xx - yy) * SH(11) +
+                          SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * SH(12) +
+                          SH_C3[4] * x * (4.f * zz - xx - yy) * SH(13) + SH_C3[5] * z * (xx - yy) * SH(14) +
+                          SH_C3[6] * x * (xx - 3.f * yy) * SH(15);
+                }
+            }
+        }
+#undef SH
+        res += 0.5f;
+        r[ch] = res;
+    }
+    clamped = (r[0] < 0.f ? 1u : 0u) | (r[1] < 0.f ? 2u : 0u) | (r[2] < 0.f ? 4u : 0u);
+    rgb[0] = fmaxf(r[0], 0.f); rgb[1] = fmaxf(r[1], 0.f); rgb[2] = fmaxf(r[2], 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict__ means3D,
+                      const float *__restrict__ shs, const float *__restrict__ colors_precomp,
+                      const float *__restrict__ opacities, const float *__restrict__ scales,
+                      const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
+                      int32_t *__restrict__ radii, float2 *__restrict__ xy, float4 *__restrict__ conic_op,
+                      float4 *__restrict__ rgbd, ushort4 *__restrict__ rect, uint8_t *__restrict__ clamped_out,
+                      uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ counters) {
+#pragma clang fp contract(off)
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    Cam cam;
+    load_cam(v, cam);
+    int radius = 0;
+    uint32_t key = W3D_INVALID_KEY;
+    do {
+        float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
+        float pv[3];
+        xform4x3(cam.V, p, pv);
+        if (!(pv[2] > W3D_NEAR)) break;   // near cull (also rejects NaN depth)
+        float ph[4];
+        xform4x4(cam.M, p, ph);
+        float pw = 1.0f / (ph[3] + 0.0000001f);
+        float ppx = ph[0] * pw, ppy = ph[1] * pw;
+        float c3[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * (size_t)g + i];
+        } else {
+            float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
+            const float4 q4 = reinterpret_cast<const float4 *>(rotations)[g];
+            float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            cov3d_from_scale_rot(s, v.scale_modifier, q, c3);
+        }
+        Geo geo;
+        ewa(v, cam, pv, c3, geo);
+        float det = geo.a * geo.c - geo.b * geo.b;
+        if (det == 0.0f) break;
+        float det_inv = 1.f / det;
+        float conx = geo.c * det_inv, cony = -geo.b * det_inv, conz = geo.a * det_inv;
+        float mid = 0.5f * (geo.a + geo.c);
+        float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+        float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        float px = ((ppx + 1.0f) * (float)v.image_width - 1.0f) * 0.5f;
+        float py = ((ppy + 1.0f) * (float)v.image_height - 1.0f) * 0.5f;
+        // radius can exceed int range for degenerate inputs: clamp before converting
+        int r = (int)fminf(my_radius, 1.0e9f);
+        float rf = (float)r;
+        float fminx = (px - rf) / (float)W3D_TILE, fminy = (py - rf) / (float)W3D_TILE;
+        float fmaxx = (px + rf + (float)(W3D_TILE - 1)) / (float)W3D_TILE;
+        float fmaxy = (py + rf + (float)(W3D_TILE - 1)) / (float)W3D_TILE;
+        // clamp in float first (same result as int clamp for in-range values, safe for huge ones)
+        int minx = (int)fminf(fmaxf(fminx, -1.0f), (float)gx + 1.0f), miny = (int)fminf(fmaxf(fminy, -1.0f), (float)gy + 1.0f);
+        int maxx = (int)fminf(fmaxf(fmaxx, -1.0f), (float)gx + 1.0f), maxy = (int)fminf(fmaxf(fmaxy, -1.0f), (float)gy + 1.0f);
+        minx = min(gx, max(0, minx)); miny = min(gy, max(0, miny));
+        maxx = min(gx, max(0, maxx)); maxy = min(gy, max(0, maxy));
+        if ((maxx - minx) * (maxy - miny) == 0) break;
+        float rgb[3];
+        uint32_t cl = 0;
+        if (colors_precomp) {
+            rgb[0] = colors_precomp[3 * (size_t)g]; rgb[1] = colors_precomp[3 * (size_t)g + 1]; rgb[2] = colors_precomp[3 * (size_t)g + 2];
+        } else {
+            sh_to_rgb(v.sh_degree, shs + (size_t)g * v.sh_coeffs * 3, p, cam.campos, rgb, cl);
+        }
+        radius = r;
+        key = __float_as_uint(pv[2]);
+        xy[g] = make_float2(px, py);
+        conic_op[g] = make_float4(conx, cony, conz, opacities[g]);
+        rgbd[g] = make_float4(rgb[0], rgb[1], rgb[2], pv[2]);
+        rect[g] = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
+        clamped_out[g] = (uint8_t)cl;
+    } while (0);
+    radii[g] = radius;
+    keys[g] = key;
+    vals[g] = (uint32_t)g;
+    // visible count: one atomic per wave
+    const unsigned long long vis = __ballot(radius > 0);
+    if ((threadIdx.x & 63) == 0 && vis) atomicAdd(&counters[0], (uint32_t)__popcll(vis));
+}
+
+// proj_xy / gs_depth outputs of the FlashSplat variant (zeros for culled Gaussians)
+__global__ void flash_extras_kernel(int P, const uint32_t *__restrict__ keys_unused, const float2 *__restrict__ xy,
+                                    const float4 *__restrict__ rgbd, const ushort4 *__restrict__ rect,
+                                    const int32_t *__restrict__ radii, float *__restrict__ proj_xy,
+                                    float *__restrict__ gs_depth) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    const ushort4 rc = rect[g];
+    const bool vis = ((int)rc.z - (int)rc.x) * ((int)rc.w - (int)rc.y) > 0;
+    (void)radii;
+    if (proj_xy) {
+        float2 p = vis ? xy[g] : make_float2(0.f, 0.f);
+        proj_xy[2 * (size_t)g] = p.x; proj_xy[2 * (size_t)g + 1] = p.y;
+    }
+    if (gs_depth) gs_depth[g] = vis ? rgbd[g].w : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the per-Gaussian stages (Appendix A.5).  visible <=> the forward wrote a record,
+// flagged by rect having a non-empty area (rect is zero-initialised per call for culled ones).
+template <bool HAS_SH, bool HAS_SCALE_ROT>
+__global__ void __launch_bounds__(256)
+preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
+                      const float *__restrict__ scales, const float *__restrict__ rotations,
+                      const float *__restrict__ cov3D_precomp, const int32_t *__restrict__ visible_radii_unused,
+                      const ushort4 *__restrict__ rect, const uint8_t *__restrict__ clamped,
+                      const uint32_t *__restrict__ keys_unused, const float *__restrict__ grad2d,
+                      float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dcolors,
+                      float *__restrict__ dL_dshs, float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
+                      float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    const int Mc = v.sh_coeffs;
+    const ushort4 rc = rect[g];
+    const bool vis = ((int)rc.z - (int)rc.x) * ((int)rc.w - (int)rc.y) > 0;
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dm2[2] = {0.f, 0.f};
+    float dop = 0.f;
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+    float dcol[3] = {0.f, 0.f, 0.f};
+    float *dsh = HAS_SH ? dL_dshs + (size_t)g * Mc * 3 : nullptr;
+    if (!vis) {
+        if (HAS_SH) {
+            for (int i = 0; i < Mc * 3; i++) dsh[i] = 0.f;
+        }
+    } else {
+        Cam cam;
+        load_cam(v, cam);
+        const float4 *rec = reinterpret_cast<const float4 *>(grad2d + (size_t)g * W3D_G2D_STRIDE);
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        dm2[0] = r0.x; dm2[1] = r0.y;
+        const float dconic[3] = {r0.z, r0.w, r1.x};
+        dop = r1.y;
+        dcol[0] = r1.z; dcol[1] = r1.w; dcol[2] = r2.x;
+        const float ddepth = r2.y;
+        float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
+        float pv[3];
+        xform4x3(cam.V, p, pv);
+        float c3[6];
+        float q[4] = {1.f, 0.f, 0.f, 0.f}, s[3] = {0.f, 0.f, 0.f};
+        if (HAS_SCALE_ROT) {
+            s[0] = scales[3 * (size_t)g]; s[1] = scales[3 * (size_t)g + 1]; s[2] = scales[3 * (size_t)g + 2];
+            const float4 q4 = reinterpret_cast<const float4 *>(rotations)[g];
+            q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+            cov3d_from_scale_rot(s, v.scale_modifier, q, c3);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * (size_t)g + i];
+        }
+        Geo geo;
+        ewa(v, cam, pv, c3, geo);
+        // (i) conic -> cov2D -> cov3D, view-space mean
+        const float ca = geo.a, cb = geo.b, cc = geo.c;
+        const float denom = ca * cc - cb * cb;
+        const float denom2inv = 1.0f / (denom * denom + 0.0000001f);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        const float(*Tm)[3] = geo.Tm;
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-cc * cc * dconic[0] + 2.f * cb * cc * dconic[1] + (denom - ca * cc) * dconic[2]);
+            dL_dc = denom2inv * (-ca * ca * dconic[2] + 2.f * ca * cb * dconic[1] + (denom - ca * cc) * dconic[0]);
+            dL_db = denom2inv * 2.f * (cb * cc * dconic[0] - (denom + 2.f * cb * cb) * dconic[1] + ca * cb * dconic[2]);
+            dcov[0] = Tm[0][0] * Tm[0][0] * dL_da + Tm[0][0] * Tm[1][0] * dL_db + Tm[1][0] * Tm[1][0] * dL_dc;
+            dcov[3] = Tm[0][1] * Tm[0][1] * dL_da + Tm[0][1] * Tm[1][1] * dL_db + Tm[1][1] * Tm[1][1] * dL_dc;
+            dcov[5] = Tm[0][2] * Tm[0][2] * dL_da + Tm[0][2] * Tm[1][2] * dL_db + Tm[1][2] * Tm[1][2] * dL_dc;
+            dcov[1] = 2.f * Tm[0][0] * Tm[0][1] * dL_da + (Tm[0][0] * Tm[1][1] + Tm[0][1] * Tm[1][0]) * dL_db + 2.f * Tm[1][0] * Tm[1][1] * dL_dc;
+            dcov[2] = 2.f * Tm[0][0] * Tm[0][2] * dL_da + (Tm[0][0] * Tm[1][2] + Tm[0][2] * Tm[1][0]) * dL_db + 2.f * Tm[1][0] * Tm[1][2] * dL_dc;
+            dcov[4] = 2.f * Tm[0][2] * Tm[0][1] * dL_da + (Tm[0][1] * Tm[1][2] + Tm[0][2] * Tm[1][1]) * dL_db + 2.f * Tm[1][1] * Tm[1][2] * dL_dc;
+        }
+        const float S[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+        float TS[2][3], dT[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) TS[i][j] = Tm[i][0] * S[0][j] + Tm[i][1] * S[1][j] + Tm[i][2] * S[2][j];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            dT[0][j] = 2.f * TS[0][j] * dL_da + TS[1][j] * dL_db;
+            dT[1][j] = 2.f * TS[1][j] * dL_dc + TS[0][j] * dL_db;
+        }
+        const float *V = cam.V;
+        const float dJ00 = dT[0][0] * V[0] + dT[0][1] * V[4] + dT[0][2] * V[8];
+        const float dJ02 = dT[0][0] * V[2] + dT[0][1] * V[6] + dT[0][2] * V[10];
+        const float dJ11 = dT[1][0] * V[1] + dT[1][1] * V[5] + dT[1][2] * V[9];
+        const float dJ12 = dT[1][0] * V[2] + dT[1][1] * V[6] + dT[1][2] * V[10];
+        const float fx = (float)v.image_width / (2.f * v.tanfovx), fy = (float)v.image_height / (2.f * v.tanfovy);
+        const float tz = 1.f / pv[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dtx = (geo.clx ? 0.f : 1.f) * -fx * tz2 * dJ02;
+        const float dty = (geo.cly ? 0.f : 1.f) * -fy * tz2 * dJ12;
+        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * geo.txc) * tz3 * dJ02 + (2.f * fy * geo.tyc) * tz3 * dJ12;
+        dmean[0] = V[0] * dtx + V[1] * dty + V[2] * dtz;
+        dmean[1] = V[4] * dtx + V[5] * dty + V[6] * dtz;
+        dmean[2] = V[8] * dtx + V[9] * dty + V[10] * dtz;
+        // (ii) screen-space mean -> 3-D mean through the perspective divide
+        const float *M = cam.M;
+        float mh[4];
+        xform4x4(M, p, mh);
+        const float mw = 1.0f / (mh[3] + 0.0000001f);
+        const float mul1 = mh[0] * mw * mw, mul2 = mh[1] * mw * mw;
+        dmean[0] += (M[0] * mw - M[3] * mul1) * dm2[0] + (M[1] * mw - M[3] * mul2) * dm2[1];
+        dmean[1] += (M[4] * mw - M[7] * mul1) * dm2[0] + (M[5] * mw - M[7] * mul2) * dm2[1];
+        dmean[2] += (M[8] * mw - M[11] * mul1) * dm2[0] + (M[9] * mw - M[11] * mul2) * dm2[1];
+        // (iii) depth output
+        dmean[0] += V[2] * ddepth; dmean[1] += V[6] * ddepth; dmean[2] += V[10] * ddepth;
+        // (iv) colour
+        if (HAS_SH) {
+            const int deg = v.sh_degree;
+            const float *sh = shs + (size_t)g * Mc * 3;
+            const uint32_t cl = clamped[g];
+            const float dRGB[3] = {(cl & 1u) ? 0.f : dcol[0], (cl & 2u) ? 0.f : dcol[1], (cl & 4u) ? 0.f : dcol[2]};
+            const float d0 = p[0] - cam.campos[0], d1 = p[1] - cam.campos[1], d2 = p[2] - cam.campos[2];
+            const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+            const float x = d0 / len, y = d1 / len, z = d2 / len;
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            float ddir[3] = {0.f, 0.f, 0.f};
+            // basis values (shared by the three channels)
+            float B[16];
+            B[0] = SH_C0;
+            B[1] = -SH_C1 * y; B[2] = SH_C1 * z; B[3] = -SH_C1 * x;
+            B[4] = SH_C2[0] * xy; B[5] = SH_C2[1] * yz; B[6] = SH_C2[2] * (2.f * zz - xx - yy);
+            B[7] = SH_C2[3] * xz; B[8] = SH_C2[4] * (xx - yy);
+            B[9] = SH_C3[0] * y * (3.f * xx - yy); B[10] = SH_C3[1] * xy * z; B[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+            B[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); B[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+            B[14] = SH_C3[5] * z * (xx - yy); B[15] = SH_C3[6] * x * (xx - 3.f * yy);
+            const int ncoef = (deg + 1) * (deg + 1);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {   // static indices keep B[] in registers
+                if (k < Mc) {
+                    const float b = (k < ncoef) ? B[k] : 0.f;
+                    dsh[3 * k + 0] = b * dRGB[0]; dsh[3 * k + 1] = b * dRGB[1]; dsh[3 * k + 2] = b * dRGB[2];
+                }
+            }
+            for (int k = 16; k < Mc; k++) { dsh[3 * k + 0] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+#define SH(k) sh[(k)*3 + ch]
+                float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+                if (deg > 0) {
+                    ddx = -SH_C1 * SH(3); ddy = -SH_C1 * SH(1); ddz = SH_C1 * SH(2);
+                    if (deg > 1) {
+                        ddx += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
+                        ddy += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
+                        ddz += SH_C2[1] * y * SH(5) + SH_C2[2] * 2.f * 2.f * z * SH(6) + SH_C2[3] * x * SH(7);
+                        if (deg > 2) {
+                            ddx += SH_C3[0] * SH(9) * 3.f * 2.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
+                                   SH_C3[3] * SH(12) * -3.f * 2.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                                   SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy);
+                            ddy += SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz +
+                                   SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SH(12) * -3.f * 2.f * yz +
+                                   SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz + SH_C3[6] * SH(15) * -3.f * 2.f * xy;
+                            ddz += SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 4.f * 2.f * yz +
+                                   SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SH(13) * 4.f * 2.f * xz +
+                                   SH_C3[5] * SH(14) * (xx - yy);
+                        }
+                    }
+                }
+#undef SH
+                ddir[0] += ddx * dRGB[ch]; ddir[1] += ddy * dRGB[ch]; ddir[2] += ddz * dRGB[ch];
+            }
+            const float sum2 = d0 * d0 + d1 * d1 + d2 * d2;
+            const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            dmean[0] += ((sum2 - d0 * d0) * ddir[0] - d1 * d0 * ddir[1] - d2 * d0 * ddir[2]) * inv32;
+            dmean[1] += (-d0 * d1 * ddir[0] + (sum2 - d1 * d1) * ddir[1] - d2 * d1 * ddir[2]) * inv32;
+            dmean[2] += (-d0 * d2 * ddir[0] - d1 * d2 * ddir[1] + (sum2 - d2 * d2) * ddir[2]) * inv32;
+        }
+        // (v) cov3D -> scale, quaternion (as given)
+        if (HAS_SCALE_ROT) {
+            float R[3][3], L[3][3];
+            quat_to_R(q, R);
+            const float mod = v.scale_modifier;
+            const float sc[3] = {mod * s[0], mod * s[1], mod * s[2]};
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) L[i][j] = R[i][j] * sc[j];
+            const float Gs[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                    {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                    {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+            float dLm[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) dLm[i][j] = 2.f * (Gs[i][0] * L[0][j] + Gs[i][1] * L[1][j] + Gs[i][2] * L[2][j]);
+#pragma unroll
+            for (int j = 0; j < 3; j++) dscale[j] = mod * (dLm[0][j] * R[0][j] + dLm[1][j] * R[1][j] + dLm[2][j] * R[2][j]);
+            float GR[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) GR[i][j] = dLm[i][j] * sc[j];
+            const float r = q[0], x = q[1], y = q[2], z = q[3];
+            drot[0] = 2.f * (-z * GR[0][1] + y * GR[0][2] + z * GR[1][0] - x * GR[1][2] - y * GR[2][0] + x * GR[2][1]);
+            drot[1] = 2.f * (y * GR[0][1] + z * GR[0][2] + y * GR[1][0] - 2.f * x * GR[1][1] - r * GR[1][2] + z * GR[2][0] + r * GR[2][1] - 2.f * x * GR[2][2]);
+            drot[2] = 2.f * (-2.f * y * GR[0][0] + x * GR[0][1] + r * GR[0][2] + x * GR[1][0] + z * GR[1][2] - r * GR[2][0] + z * GR[2][1] - 2.f * y * GR[2][2]);
+            drot[3] = 2.f * (-2.f * z * GR[0][0] - r * GR[0][1] + x * GR[0][2] + r * GR[1][0] - 2.f * z * GR[1][1] + y * GR[1][2] + x * GR[2][0] + y * GR[2][1]);
+        }
+    }
+    dL_dmeans3D[3 * (size_t)g] = dmean[0]; dL_dmeans3D[3 * (size_t)g + 1] = dmean[1]; dL_dmeans3D[3 * (size_t)g + 2] = dmean[2];
+    dL_dmeans2D[3 * (size_t)g] = dm2[0]; dL_dmeans2D[3 * (size_t)g + 1] = dm2[1]; dL_dmeans2D[3 * (size_t)g + 2] = 0.f;
+    dL_dopacity[g] = dop;
+    if (!HAS_SH && dL_dcolors) {
+        dL_dcolors[3 * (size_t)g] = dcol[0]; dL_dcolors[3 * (size_t)g + 1] = dcol[1]; dL_dcolors[3 * (size_t)g + 2] = dcol[2];
+    }
+    if (HAS_SCALE_ROT) {
+        dL_dscales[3 * (size_t)g] = dscale[0]; dL_dscales[3 * (size_t)g + 1] = dscale[1]; dL_dscales[3 * (size_t)g + 2] = dscale[2];
+        reinterpret_cast<float4 *>(dL_drots)[g] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    }
+    if (dL_dcov3D) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) dL_dcov3D[6 * (size_t)g + i] = dcov[i];
+    }
+}
+
+}  // namespace
+
+int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,
+                          const float *colors_precomp, const float *opacities, const float *scales,
+                          const float *rotations, const float *cov3D_precomp, int32_t *radii, char *state,
+                          char *scratch, float *, hipStream_t stream) {
+    // counters and the rect array start at zero each call (rect == 0 marks a culled Gaussian)
+    W3D_HIP_CHECK(hipMemsetAsync(state + L.o_counters, 0, 64, stream));
+    W3D_HIP_CHECK(hipMemsetAsync(state + L.o_rect, 0, (size_t)(L.P > 0 ? L.P : 1) * 8, stream));
+    if (L.P == 0) return W3D_OK;
+    const int block = 256, grid = (L.P + block - 1) / block;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(grid), dim3(block), 0, stream, v, L.P, L.gx, L.gy, means3D, shs,
+                       colors_precomp, opacities, scales, rotations, cov3D_precomp, radii,
+                       reinterpret_cast<float2 *>(state + L.o_xy), reinterpret_cast<float4 *>(state + L.o_conic_op),
+                       reinterpret_cast<float4 *>(state + L.o_rgbd), reinterpret_cast<ushort4 *>(state + L.o_rect),
+                       reinterpret_cast<uint8_t *>(state + L.o_clamped), reinterpret_cast<uint32_t *>(scratch + L.s_keys0),
+                       reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(state + L.o_counters));
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    return W3D_OK;
+}
+
+int w3d_launch_flash_extras(const W3DLayout &L, const w3d_view &v, const int32_t *radii, char *state, float *proj_xy,
+                            float *gs_depth, hipStream_t stream) {
+    if (L.P == 0 || (!proj_xy && !gs_depth)) return W3D_OK;
+    const int block = 256, grid = (L.P + block - 1) / block;
+    hipLaunchKernelGGL(flash_extras_kernel, dim3(grid), dim3(block), 0, stream, L.P, (const uint32_t *)nullptr,
+                       reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_rgbd),
+                       reinterpret_cast<const ushort4 *>(state + L.o_rect), radii, proj_xy, gs_depth);
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    return W3D_OK;
+}
+
+int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,
+                                   const float *colors_precomp, const float *scales, const float *rotations,
+                                   const float *cov3D_precomp, const char *state, const float *grad2d,
+                                   float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors, float *dL_dshs,
+                                   float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
+                                   hipStream_t stream) {
+    if (L.P == 0) return W3D_OK;
+    const int block = 256, grid = (L.P + block - 1) / block;
+    const bool has_sh = (shs != nullptr), has_sr = (scales != nullptr);
+    (void)colors_precomp;
+#define LAUNCH(A, B)                                                                                                  \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<A, B>), dim3(grid), dim3(block), 0, stream, v, L.P, means3D, shs, scales, \
+                       rotations, cov3D_precomp, (const int32_t *)nullptr,                                            \
+                       reinterpret_cast<const ushort4 *>(state + L.o_rect),                                           \
+                       reinterpret_cast<const uint8_t *>(state + L.o_clamped), (const uint32_t *)nullptr, grad2d,     \
+                       dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
+    if (has_sh && has_sr) LAUNCH(true, true);
+    else if (has_sh) LAUNCH(true, false);
+    else if (has_sr) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    return W3D_OK;
+}

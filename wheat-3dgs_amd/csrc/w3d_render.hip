@@ -1,0 +1,379 @@
+// w3d_render.hip — per-tile alpha compositing, forward and backward (SURVEY.md Appendix
+// A.3, A.4, A.6; replaces the render stage behind reference gaussian_renderer/__init__.py:89-97
+// and :194-204).
+//
+// CDNA4 mapping: ONE wave64 owns ONE 16x16 tile; each lane carries four pixels (the same
+// (lx,ly) position inside each 8x8 quadrant of the tile).  Consequences:
+//   * no __syncthreads() anywhere — staging through LDS and consuming it are wave-synchronous;
+//   * a staged Gaussian (three 16-B LDS broadcast reads) is amortised over 4 pixels per lane;
+//   * quadrant-level culling: a whole 8x8 quadrant skips exp/accumulate for a Gaussian when no
+//     lane of it can reach alpha >= 1/255 (wave-uniform branch on a ballot);
+//   * in the backward pass the per-Gaussian partial sums of the 4 pixels are added in registers
+//     first, then ONE wave reduction (DPP row ops + row_bcast, no LDS traffic) per tile instance
+//     and ONE 40-B atomic record update per tile instance — instead of 9 atomics per
+//     (pixel, Gaussian) pair.
+// Workgroups are 256 threads = 4 independent tiles; the wave -> tile map keeps the tiles of one
+// XCD contiguous so neighbouring tiles (which share Gaussians) hit the same L2.
+#include "w3d_common.h"
+
+namespace {
+
+#define LOG2E 1.4426950408889634f
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_mov(float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, ROW_MASK, 0xF, true));
+}
+// sum over the 64 lanes; the result is valid in lane 63 (and returned broadcast through readlane)
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);       // row_half_mirror
+    v += dpp_mov<0x140>(v);       // row_mirror  -> every lane holds its row's sum
+    v += dpp_mov<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_mov<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// wave index -> tile index, keeping each XCD's tiles contiguous (blocks are dealt round-robin
+// over the 8 XCDs; speed only, never correctness).
+__device__ __forceinline__ uint32_t wave_to_tile(uint32_t T, uint32_t &tile) {
+    const uint32_t nblocks = gridDim.x;
+    const uint32_t b = blockIdx.x;
+    const uint32_t per_xcd = (nblocks + 7) / 8;
+    const uint32_t logical_block = (b & 7u) * per_xcd + (b >> 3);
+    tile = logical_block * 4 + (threadIdx.x >> 6);
+    return tile < T;
+}
+
+struct StagedLDS {
+    float4 a[64];  // x, y, pmin (power below which alpha < 1/255 for sure), id bits
+    float4 b[64];  // conic.x, conic.y, conic.z, opacity
+    float4 c[64];  // r, g, b, depth
+};
+
+__device__ __forceinline__ void stage_entries(StagedLDS &s, uint32_t lane, uint32_t n, const uint32_t *__restrict__ list,
+                                              const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
+                                              const float4 *__restrict__ rgbd) {
+    if (lane < n) {
+        const uint32_t g = list[lane];
+        const float2 p = xy[g];
+        const float4 co = conic_op[g];
+        const float4 cd = rgbd[g];
+        // alpha = min(0.99, o*exp(power)) >= 1/255 needs power >= -log(255 o); 1e-4 slack covers
+        // the rounding of the fast exp, so skipping below pmin never changes a result.
+        const float pmin = (co.w > 0.f) ? (-__logf(255.0f * co.w) - 1e-4f) : 1.0f;
+        s.a[lane] = make_float4(p.x, p.y, pmin, __uint_as_float(g));
+        s.b[lane] = co;
+        s.c[lane] = cd;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------------------ forward
+template <bool FLASH>
+__global__ void __launch_bounds__(256)
+render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restrict__ tile_start,
+                  const uint32_t *__restrict__ point_list, const float2 *__restrict__ xy,
+                  const float4 *__restrict__ conic_op, const float4 *__restrict__ rgbd, const float *__restrict__ bg,
+                  float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_alpha,
+                  float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                  const float *__restrict__ gt_mask, int num_obj, int P, float *__restrict__ used_count,
+                  int32_t *__restrict__ contrib_num) {
+    __shared__ StagedLDS lds[4];
+    __shared__ int s_labels[4][FLASH ? 256 : 1];
+    uint32_t tile;
+    if (!wave_to_tile(T, tile)) return;
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    StagedLDS &s = lds[wv];
+    const uint32_t tx0 = (tile % gx) * W3D_TILE, ty0 = (tile / gx) * W3D_TILE;
+    const uint32_t lx = lane & 7, ly = lane >> 3;
+    float pxf[4], pyf[4];
+    bool inside[4], done[4];
+    float Tr[4], C0[4], C1[4], C2[4], D[4], A[4];
+    uint32_t last[4];
+    int napplied[4];
+    int label[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t px = tx0 + (k & 1) * 8 + lx, py = ty0 + (k >> 1) * 8 + ly;
+        pxf[k] = (float)px; pyf[k] = (float)py;
+        inside[k] = (px < (uint32_t)W) && (py < (uint32_t)H);
+        done[k] = !inside[k];
+        Tr[k] = 1.f; C0[k] = C1[k] = C2[k] = D[k] = A[k] = 0.f;
+        last[k] = 0; napplied[k] = 0;
+        label[k] = -1;
+        if (FLASH && gt_mask && inside[k]) {
+            const int l = (int)gt_mask[(size_t)py * W + px];
+            label[k] = (l >= 0 && l <= num_obj) ? l : -1;
+        }
+    }
+    // distinct labels present in this tile (FlashSplat scatter loops over them)
+    int nlabels = 0;
+    if (FLASH && gt_mask && used_count) {
+        int cur = -1;
+        for (;;) {
+            int m = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (label[k] > cur) m = min(m, label[k]);
+            m = wave_min_i32(m);
+            if (m == 0x7fffffff) break;
+            if (lane == 0) s_labels[wv][nlabels] = m;
+            nlabels++;
+            cur = m;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    for (uint32_t base = start; base < end; base += 64) {
+        if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
+        const uint32_t n = min(64u, end - base);
+        stage_entries(s, lane, n, point_list + base, xy, conic_op, rgbd);
+        for (uint32_t j = 0; j < n; j++) {
+            const float4 ea = s.a[j], eb = s.b[j], ec = s.c[j];
+            const uint32_t contributor = base - start + j + 1;
+            float wk[4] = {0.f, 0.f, 0.f, 0.f};
+            bool any_applied = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float dx = ea.x - pxf[k], dy = ea.y - pyf[k];
+                const float power = -0.5f * (eb.x * dx * dx + eb.z * dy * dy) - eb.y * dx * dy;
+                const bool cand = !done[k] && power <= 0.f && power >= ea.z;
+                if (__ballot(cand) == 0ull) continue;   // whole quadrant untouched by this Gaussian
+                const float alpha = fminf(0.99f, eb.w * __builtin_amdgcn_exp2f(power * LOG2E));
+                const float test_T = Tr[k] * (1.f - alpha);
+                const bool ok = cand && alpha >= (1.0f / 255.0f);
+                const bool stop = ok && test_T < 0.0001f;
+                const bool apply = ok && !stop;
+                const float w = apply ? alpha * Tr[k] : 0.f;
+                C0[k] += ec.x * w; C1[k] += ec.y * w; C2[k] += ec.z * w;
+                D[k] += ec.w * w; A[k] += w;
+                Tr[k] = apply ? test_T : Tr[k];
+                last[k] = apply ? contributor : last[k];
+                done[k] = done[k] || stop;
+                if (FLASH) { wk[k] = w; napplied[k] += apply ? 1 : 0; any_applied = any_applied || apply; }
+            }
+            if (FLASH && gt_mask && used_count) {
+                if (__ballot(any_applied) != 0ull) {
+                    const uint32_t g = __float_as_uint(ea.w);
+                    for (int li = 0; li < nlabels; li++) {
+                        const int L = s_labels[wv][li];
+                        float part = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) part += (label[k] == L) ? wk[k] : 0.f;
+                        const float tot = wave_sum(part);
+                        if (lane == 0 && tot != 0.f) atomicAdd(&used_count[(size_t)L * P + g], tot);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const size_t HW = (size_t)H * W;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (inside[k]) {
+            const size_t pix = (size_t)(uint32_t)pyf[k] * W + (uint32_t)pxf[k];
+            out_color[pix] = C0[k] + Tr[k] * bg0;
+            out_color[HW + pix] = C1[k] + Tr[k] * bg1;
+            out_color[2 * HW + pix] = C2[k] + Tr[k] * bg2;
+            out_depth[pix] = D[k];
+            out_alpha[pix] = A[k];
+            final_T[pix] = Tr[k];
+            n_contrib[pix] = last[k];
+            if (FLASH && contrib_num) contrib_num[pix] = napplied[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ backward
+// HAS_DA: gradients w.r.t. the depth and alpha images are present.
+template <bool HAS_DA>
+__global__ void __launch_bounds__(256)
+render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restrict__ tile_start,
+                  const uint32_t *__restrict__ point_list, const float2 *__restrict__ xy,
+                  const float4 *__restrict__ conic_op, const float4 *__restrict__ rgbd, const float *__restrict__ bg,
+                  const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                  const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
+                  const float *__restrict__ dL_dalpha_px, float *__restrict__ grad2d) {
+    __shared__ StagedLDS lds[4];
+    uint32_t tile;
+    if (!wave_to_tile(T, tile)) return;
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    StagedLDS &s = lds[wv];
+    const uint32_t tx0 = (tile % gx) * W3D_TILE, ty0 = (tile / gx) * W3D_TILE;
+    const uint32_t lx = lane & 7, ly = lane >> 3;
+    const size_t HW = (size_t)H * W;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    float pxf[4], pyf[4], Tr[4], Tfin[4], bgdot[4];
+    float dp0[4], dp1[4], dp2[4], dpd[4], dpa[4];
+    float ar0[4], ar1[4], ar2[4], ard[4], ara[4];
+    float lc0[4], lc1[4], lc2[4], ld[4], la[4];
+    uint32_t last[4];
+    uint32_t maxc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t px = tx0 + (k & 1) * 8 + lx, py = ty0 + (k >> 1) * 8 + ly;
+        pxf[k] = (float)px; pyf[k] = (float)py;
+        const bool in = (px < (uint32_t)W) && (py < (uint32_t)H);
+        const size_t pix = (size_t)py * W + px;
+        Tfin[k] = in ? final_T[pix] : 0.f;
+        Tr[k] = Tfin[k];
+        last[k] = in ? n_contrib[pix] : 0u;
+        dp0[k] = in ? dL_dcolor[pix] : 0.f;
+        dp1[k] = in ? dL_dcolor[HW + pix] : 0.f;
+        dp2[k] = in ? dL_dcolor[2 * HW + pix] : 0.f;
+        dpd[k] = (HAS_DA && in && dL_ddepth) ? dL_ddepth[pix] : 0.f;
+        dpa[k] = (HAS_DA && in && dL_dalpha_px) ? dL_dalpha_px[pix] : 0.f;
+        bgdot[k] = bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k];
+        ar0[k] = ar1[k] = ar2[k] = ard[k] = ara[k] = 0.f;
+        lc0[k] = lc1[k] = lc2[k] = ld[k] = la[k] = 0.f;
+        maxc = max(maxc, last[k]);
+    }
+    maxc = wave_max_u32(maxc);
+    if (maxc == 0) return;
+    const uint32_t start = tile_start[tile];
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    const int nb = (int)((maxc + 63) / 64);
+    for (int b = nb - 1; b >= 0; b--) {
+        const uint32_t n = min(64u, maxc - (uint32_t)b * 64u);
+        stage_entries(s, lane, n, point_list + start + (uint32_t)b * 64u, xy, conic_op, rgbd);
+        for (int j = (int)n - 1; j >= 0; j--) {
+            const float4 ea = s.a[j], eb = s.b[j], ec = s.c[j];
+            const uint32_t idx0 = (uint32_t)b * 64u + (uint32_t)j;   // 0-based position in the tile list
+            float gmx = 0.f, gmy = 0.f, gcx = 0.f, gcy = 0.f, gcz = 0.f, gop = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f;
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float dx = ea.x - pxf[k], dy = ea.y - pyf[k];
+                const float power = -0.5f * (eb.x * dx * dx + eb.z * dy * dy) - eb.y * dx * dy;
+                const bool cand = idx0 < last[k] && power <= 0.f && power >= ea.z;
+                if (__ballot(cand) == 0ull) continue;
+                const float G = __builtin_amdgcn_exp2f(power * LOG2E);
+                const float alpha = fminf(0.99f, eb.w * G);
+                const bool ok = cand && alpha >= (1.0f / 255.0f);
+                if (__ballot(ok) == 0ull) continue;
+                any = any || ok;
+                const float one_m_a = 1.f - alpha;
+                const float inv = __builtin_amdgcn_rcpf(one_m_a);
+                const float Tn = Tr[k] * inv;
+                const float dch = alpha * Tn;
+                // suffix colour seen behind this Gaussian
+                const float n0 = la[k] * lc0[k] + (1.f - la[k]) * ar0[k];
+                const float n1 = la[k] * lc1[k] + (1.f - la[k]) * ar1[k];
+                const float n2 = la[k] * lc2[k] + (1.f - la[k]) * ar2[k];
+                float dL_dalpha = (ec.x - n0) * dp0[k] + (ec.y - n1) * dp1[k] + (ec.z - n2) * dp2[k];
+                float nd = 0.f, na = 0.f;
+                if (HAS_DA) {
+                    nd = la[k] * ld[k] + (1.f - la[k]) * ard[k];
+                    na = la[k] + (1.f - la[k]) * ara[k];
+                    dL_dalpha += (ec.w - nd) * dpd[k] + (1.f - na) * dpa[k];
+                }
+                dL_dalpha *= Tn;
+                dL_dalpha += (-Tfin[k] * inv) * bgdot[k];
+                const float dL_dG = eb.w * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * eb.x - gdy * eb.y;
+                const float dG_ddely = -gdy * eb.z - gdx * eb.y;
+                if (ok) {
+                    Tr[k] = Tn;
+                    ar0[k] = n0; ar1[k] = n1; ar2[k] = n2;
+                    lc0[k] = ec.x; lc1[k] = ec.y; lc2[k] = ec.z;
+                    if (HAS_DA) { ard[k] = nd; ara[k] = na; ld[k] = ec.w; }
+                    la[k] = alpha;
+                    gr += dch * dp0[k]; gg += dch * dp1[k]; gb += dch * dp2[k];
+                    if (HAS_DA) gd += dch * dpd[k];
+                    gmx += dL_dG * dG_ddelx; gmy += dL_dG * dG_ddely;
+                    gcx += -0.5f * gdx * dx * dL_dG; gcy += -0.5f * gdx * dy * dL_dG; gcz += -0.5f * gdy * dy * dL_dG;
+                    gop += G * dL_dalpha;
+                }
+            }
+            if (__ballot(any) == 0ull) continue;
+            // one wave reduction per tile instance, then one 40-B record update
+            const float s0 = wave_sum(gmx) * ddelx_dx, s1 = wave_sum(gmy) * ddely_dy;
+            const float s2 = wave_sum(gcx), s3 = wave_sum(gcy), s4 = wave_sum(gcz), s5 = wave_sum(gop);
+            const float s6 = wave_sum(gr), s7 = wave_sum(gg), s8 = wave_sum(gb);
+            const float s9 = HAS_DA ? wave_sum(gd) : 0.f;
+            float val = s0;
+            val = lane == 1 ? s1 : val; val = lane == 2 ? s2 : val; val = lane == 3 ? s3 : val;
+            val = lane == 4 ? s4 : val; val = lane == 5 ? s5 : val; val = lane == 6 ? s6 : val;
+            val = lane == 7 ? s7 : val; val = lane == 8 ? s8 : val; val = lane == 9 ? s9 : val;
+            const uint32_t g = __float_as_uint(ea.w);
+            if (lane < (HAS_DA ? 10u : 9u)) atomicAdd(&grad2d[(size_t)g * W3D_G2D_STRIDE + lane], val);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void copy_pixel_state_kernel(const float *__restrict__ fT, const uint32_t *__restrict__ nc, size_t n,
+                                        float *__restrict__ fT_out, uint32_t *__restrict__ nc_out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        if (fT_out) fT_out[i] = fT[i];
+        if (nc_out) nc_out[i] = nc[i];
+    }
+}
+
+}  // namespace
+
+int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const uint32_t *point_list, float *out_color,
+                      float *out_depth, float *out_alpha, const float *gt_mask, int32_t num_obj, float *used_count,
+                      int32_t *contrib_num, hipStream_t stream) {
+    const uint32_t T = (uint32_t)L.T;
+    uint32_t blocks = (T + 3) / 4;
+    blocks = (blocks + 7) / 8 * 8;   // the XCD-contiguous map needs a multiple of 8 blocks
+    const bool flash = (gt_mask != nullptr) || (used_count != nullptr) || (contrib_num != nullptr);
+#define ARGS                                                                                                          \
+    T, (uint32_t)L.gx, L.W, L.H, reinterpret_cast<const uint32_t *>(state + L.o_tile_start), point_list,              \
+        reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_conic_op),     \
+        reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg, out_color, out_depth, out_alpha,                    \
+        reinterpret_cast<float *>(state + L.o_final_T), reinterpret_cast<uint32_t *>(state + L.o_n_contrib), gt_mask, \
+        num_obj, L.P, used_count, contrib_num
+    if (flash) hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, ARGS);
+    else hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, ARGS);
+#undef ARGS
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    return W3D_OK;
+}
+
+int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char *state, const uint32_t *point_list,
+                               const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha, float *grad2d,
+                               hipStream_t stream) {
+    const uint32_t T = (uint32_t)L.T;
+    uint32_t blocks = (T + 3) / 4;
+    blocks = (blocks + 7) / 8 * 8;
+    W3D_HIP_CHECK(hipMemsetAsync(grad2d, 0, (size_t)(L.P > 0 ? L.P : 1) * W3D_G2D_STRIDE * sizeof(float), stream));
+#define ARGS                                                                                                      \
+    T, (uint32_t)L.gx, L.W, L.H, reinterpret_cast<const uint32_t *>(state + L.o_tile_start), point_list,          \
+        reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_conic_op), \
+        reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg,                                                 \
+        reinterpret_cast<const float *>(state + L.o_final_T), reinterpret_cast<const uint32_t *>(state + L.o_n_contrib), \
+        dL_dcolor, dL_ddepth, dL_dalpha, grad2d
+    if (dL_ddepth || dL_dalpha) hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, ARGS);
+    else hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, ARGS);
+#undef ARGS
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    return W3D_OK;
+}
+
+int w3d_debug_pixel_state_impl(const W3DLayout &L, const char *state, float *final_T_out, uint32_t *n_contrib_out,
+                               hipStream_t stream) {
+    const size_t n = (size_t)L.H * L.W;
+    hipLaunchKernelGGL(copy_pixel_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float *>(state + L.o_final_T),
+                       reinterpret_cast<const uint32_t *>(state + L.o_n_contrib), n, final_T_out, n_contrib_out);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}

@@ -1,0 +1,286 @@
+"""Host side of the rasterizer: torch.autograd wrappers over the C-ABI (include/w3d.h).
+
+Mirrors the Python surface of the two rasterizer packages the reference imports
+(gaussian_renderer/__init__.py:14,18-19): ``GaussianRasterizationSettings`` +
+``GaussianRasterizer`` with the call signature used at gaussian_renderer/__init__.py:89-97
+(4 outputs) and :194-204 (FlashSplat, 8 outputs).  PyTorch is plumbing only: it owns device
+memory (outputs, state, scratch, lists all come from its caching allocator, so the host code's
+``torch.cuda.empty_cache()`` calls — run_3d_seg.py:99 — keep working) and the stream.
+"""
+import ctypes
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib
+from ._lib import W3DView, check, lib, ptr, stream_ptr
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """Fields and order of the reference call site gaussian_renderer/__init__.py:40-53."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class FlashSplatRasterizationSettings(NamedTuple):
+    """The 14-field variant of gaussian_renderer/__init__.py:132-147."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    mask_grad: bool = False
+    num_obj: int = 2
+
+
+def _f32c(t: Optional[torch.Tensor], device):
+    if t is None:
+        return None
+    if t.device != device:
+        raise ValueError(f"tensor on {t.device}, expected {device}")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _require_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("the MI355X rasterizer needs its inputs on the GPU (device='cuda'); there is no CPU path")
+
+
+class _View:
+    """Keeps the device tensors of a w3d_view alive next to the ctypes struct."""
+
+    def __init__(self, s, sh_coeffs, device):
+        self.bg = _f32c(s.bg, device)
+        self.vm = _f32c(s.viewmatrix, device)
+        self.pm = _f32c(s.projmatrix, device)
+        self.cp = _f32c(s.campos, device)
+        if self.bg.numel() != 3 or self.vm.numel() != 16 or self.pm.numel() != 16 or self.cp.numel() != 3:
+            raise ValueError("bg/viewmatrix/projmatrix/campos must have 3/16/16/3 elements")
+        v = W3DView()
+        v.image_height, v.image_width = int(s.image_height), int(s.image_width)
+        v.tanfovx, v.tanfovy = float(s.tanfovx), float(s.tanfovy)
+        v.scale_modifier = float(s.scale_modifier)
+        v.sh_degree, v.sh_coeffs = int(s.sh_degree), int(sh_coeffs)
+        v.prefiltered, v.debug = int(bool(s.prefiltered)), int(bool(s.debug))
+        v.bg, v.viewmatrix = self.bg.data_ptr(), self.vm.data_ptr()
+        v.projmatrix, v.campos = self.pm.data_ptr(), self.cp.data_ptr()
+        self.c = v
+
+
+def _check_variants(shs, colors_precomp, scales, rotations, cov3D_precomp):
+    # same messages/behaviour as the rasterizer modules the reference binds
+    if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+            ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+
+def _forward_impl(settings, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                  flash=None):
+    """Runs stage 1 + stage 2.  Returns (color, radii, depth, alpha, saved, extras)."""
+    _require_gpu(means3D)
+    dev = means3D.device
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    P = int(means3D.shape[0])
+    H, W = int(settings.image_height), int(settings.image_width)
+    means3D = _f32c(means3D, dev)
+    shs, colors_precomp = _f32c(shs, dev), _f32c(colors_precomp, dev)
+    opacities = _f32c(opacities, dev)
+    scales, rotations, cov3D_precomp = _f32c(scales, dev), _f32c(rotations, dev), _f32c(cov3D_precomp, dev)
+    sh_coeffs = int(shs.shape[1]) if shs is not None and shs.dim() == 3 else 0
+    if shs is not None and (shs.dim() != 3 or shs.shape[0] != P or shs.shape[2] != 3):
+        raise RuntimeError("shs must have dimensions (num_points, coeffs, 3)")
+    view = _View(settings, sh_coeffs, dev)
+    with torch.cuda.device(dev):
+        stream = stream_ptr(dev)
+        state_b, scratch_b = ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib.w3d_forward_sizes(P, H, W, ctypes.byref(state_b), ctypes.byref(scratch_b)))
+        state = torch.empty(state_b.value, dtype=torch.uint8, device=dev)
+        scratch = torch.empty(scratch_b.value, dtype=torch.uint8, device=dev)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        counts = (ctypes.c_uint32 * 2)()
+        check(lib.w3d_forward_stage1(ctypes.byref(view.c), P, ptr(means3D), ptr(shs), ptr(colors_precomp),
+                                     ptr(opacities), ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(radii),
+                                     ptr(state), ptr(scratch), ctypes.cast(counts, ctypes.c_void_p), stream))
+        num_rendered = int(counts[1])
+        point_list = torch.empty(max(num_rendered, 1), dtype=torch.int32, device=dev)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        extras = None
+        gt_mask = used_count = contrib_num = proj_xy = gs_depth = None
+        num_obj = 0
+        if flash is not None:
+            num_obj = int(flash["num_obj"])
+            gt_mask = flash.get("gt_mask")
+            if gt_mask is not None:
+                gt_mask = _f32c(gt_mask, dev)
+                if tuple(gt_mask.shape[-2:]) != (H, W) or gt_mask.numel() != H * W:
+                    raise RuntimeError("gt_mask must have dimensions (image_height, image_width)")
+            used_count = torch.zeros(num_obj + 1, P, dtype=torch.float32, device=dev)
+            contrib_num = torch.empty(H, W, dtype=torch.int32, device=dev)
+            proj_xy = torch.empty(P, 2, dtype=torch.float32, device=dev)
+            gs_depth = torch.empty(P, dtype=torch.float32, device=dev)
+            extras = (contrib_num, used_count, proj_xy, gs_depth)
+        check(lib.w3d_forward_stage2(ctypes.byref(view.c), P, ptr(state), ptr(scratch), ptr(point_list),
+                                     ctypes.c_uint64(num_rendered), ptr(color), ptr(depth), ptr(alpha),
+                                     ptr(gt_mask), num_obj, ptr(used_count), ptr(contrib_num), ptr(proj_xy),
+                                     ptr(gs_depth), stream))
+    saved = dict(view=view, P=P, means3D=means3D, shs=shs, colors_precomp=colors_precomp, opacities=opacities,
+                 scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, state=state,
+                 point_list=point_list, num_rendered=num_rendered, num_visible=int(counts[0]))
+    return color, radii, depth, alpha, saved, extras
+
+
+def _backward_impl(saved, grad_color, grad_depth, grad_alpha):
+    view, P = saved["view"], saved["P"]
+    dev = saved["means3D"].device
+    shs, colors_precomp = saved["shs"], saved["colors_precomp"]
+    scales, cov3D_precomp = saved["scales"], saved["cov3D_precomp"]
+    H, W = view.c.image_height, view.c.image_width
+    grad_color = _f32c(grad_color, dev) if grad_color is not None else torch.zeros(3, H, W, device=dev)
+    grad_depth, grad_alpha = _f32c(grad_depth, dev), _f32c(grad_alpha, dev)
+    e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+    g_means3D, g_means2D, g_opac = e(P, 3), e(P, 3), e(P, 1)
+    g_shs = e(*shs.shape) if shs is not None else None
+    g_colors = e(P, 3) if colors_precomp is not None else None
+    g_scales = e(P, 3) if scales is not None else None
+    g_rots = e(P, 4) if scales is not None else None
+    g_cov = e(P, 6) if cov3D_precomp is not None else None
+    if P == 0:
+        return g_means3D, g_means2D, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov
+    with torch.cuda.device(dev):
+        sb = ctypes.c_uint64()
+        check(lib.w3d_backward_sizes(P, ctypes.byref(sb)))
+        scratch = torch.empty(sb.value, dtype=torch.uint8, device=dev)
+        check(lib.w3d_backward(ctypes.byref(view.c), P, ptr(saved["means3D"]), ptr(shs), ptr(colors_precomp),
+                               ptr(saved["opacities"]), ptr(scales), ptr(saved["rotations"]), ptr(cov3D_precomp),
+                               ptr(saved["state"]), ptr(saved["point_list"]), ptr(grad_color), ptr(grad_depth),
+                               ptr(grad_alpha), ptr(g_means3D), ptr(g_means2D), ptr(g_colors), ptr(g_shs),
+                               ptr(g_opac), ptr(g_scales), ptr(g_rots), ptr(g_cov), ptr(scratch), stream_ptr(dev)))
+    return g_means3D, g_means2D, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
+        color, radii, depth, alpha, saved, _ = _forward_impl(settings, means3D, sh, colors_precomp, opacities,
+                                                             scales, rotations, cov3Ds_precomp)
+        ctx.saved = saved
+        ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
+        ctx.opac_shape = tuple(opacities.shape)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        saved = ctx.saved
+        g_means3D, g_means2D, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov = _backward_impl(
+            saved, grad_color, grad_depth, grad_alpha)
+        if ctx.means2D_shape is not None and tuple(g_means2D.shape) != ctx.means2D_shape:
+            g_means2D = None   # means2D is only a gradient carrier; mismatched proxies get nothing
+        ctx.saved = None
+        return (g_means3D, g_means2D, g_shs, g_colors, g_opac.reshape(ctx.opac_shape), g_scales, g_rots, g_cov, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, settings)
+
+
+class GaussianRasterizer(torch.nn.Module):
+    """Drop-in for diff_gaussian_rasterization.GaussianRasterizer (depth/alpha fork): returns
+    (color (3,H,W), radii (P,) int32, depth (1,H,W), alpha (1,H,W))."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean near-plane visibility (never called by Wheat-3DGS; kept for API completeness)."""
+        with torch.no_grad():
+            vm = self.raster_settings.viewmatrix
+            z = positions @ vm[:3, 2] + vm[3, 2]
+            return z > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        _check_variants(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, self.raster_settings)
+
+
+class FlashSplatRasterizer(torch.nn.Module):
+    """Drop-in for flashsplat_rasterization.GaussianRasterizer as called at
+    gaussian_renderer/__init__.py:194-204: forward-only (every call site is under no_grad and
+    mask_grad=False), returns (color, radii, depth, alpha, contrib_num, used_count, proj_xy, gs_depth)
+    with used_count of shape (num_obj+1, P)."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, gt_mask=None, unique_label=None, shs=None, colors_precomp=None,
+                scales=None, rotations=None, cov3D_precomp=None):
+        _check_variants(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        s = self.raster_settings
+        if getattr(s, "mask_grad", False):
+            raise NotImplementedError("mask_grad=True is not used by Wheat-3DGS and is not implemented")
+        with torch.no_grad():
+            color, radii, depth, alpha, _, extras = _forward_impl(
+                s, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                flash=dict(gt_mask=gt_mask, num_obj=getattr(s, "num_obj", 2)))
+        contrib_num, used_count, proj_xy, gs_depth = extras
+        return color, radii, depth, alpha, contrib_num, used_count, proj_xy, gs_depth
+
+
+def dist2_knn3(points: torch.Tensor) -> torch.Tensor:
+    """distCUDA2 (reference scene/gaussian_model.py:148): (N,3) fp32 cuda -> (N,) mean squared
+    distance to the 3 nearest other points."""
+    _require_gpu(points)
+    pts = _f32c(points, points.device)
+    if pts.dim() != 2 or pts.shape[1] != 3:
+        raise RuntimeError("points must have dimensions (num_points, 3)")
+    out = torch.empty(pts.shape[0], dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        check(lib.w3d_knn_dist2(int(pts.shape[0]), ptr(pts), ptr(out), stream_ptr(pts.device)))
+    return out
+
+
+def debug_tile_ranges(saved):
+    v = saved["view"].c
+    T = ((v.image_width + 15) // 16) * ((v.image_height + 15) // 16)
+    dev = saved["state"].device
+    out = torch.empty(T, 2, dtype=torch.int32, device=dev)
+    check(lib.w3d_debug_tile_ranges(v.image_height, v.image_width, saved["P"], ptr(saved["state"]), ptr(out), stream_ptr(dev)))
+    return out
+
+
+def debug_pixel_state(saved):
+    v = saved["view"].c
+    dev = saved["state"].device
+    ft = torch.empty(v.image_height, v.image_width, dtype=torch.float32, device=dev)
+    nc = torch.empty(v.image_height, v.image_width, dtype=torch.int32, device=dev)
+    check(lib.w3d_debug_pixel_state(v.image_height, v.image_width, saved["P"], ptr(saved["state"]), ptr(ft), ptr(nc), stream_ptr(dev)))
+    return ft, nc

@@ -1,0 +1,164 @@
+"""Seeded synthetic wheat-plot scenes and cameras.
+
+No wheat-plot data ships with the reference, so every config of BASELINE.json runs on this
+generator: a plot-shaped slab of Gaussians seen by 36 overhead cameras (3 rows x 12).
+The camera matrices follow the reference's conventions exactly:
+  * world->view from (R, T) as utils/graphics_utils.py:38-49 (getWorld2View2),
+  * projection as utils/graphics_utils.py:51-71 (getProjectionMatrix), znear 0.01 / zfar 100
+    (scene/cameras.py:50-51),
+  * both handed to the rasterizer TRANSPOSED, full_proj = view^T-form @ proj^T-form, camera
+    centre = inverse(view^T-form)[3, :3]   (scene/cameras.py:56-59).
+Everything is generated on the CPU with a fixed torch.Generator and then moved to the device.
+"""
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+
+def getWorld2View2(R, t, translate=np.array([0.0, 0.0, 0.0]), scale=1.0):
+    """Restates reference utils/graphics_utils.py:38-49."""
+    Rt = np.zeros((4, 4), dtype=np.float64)
+    Rt[:3, :3] = R.transpose()
+    Rt[:3, 3] = t
+    Rt[3, 3] = 1.0
+    C2W = np.linalg.inv(Rt)
+    cam_center = C2W[:3, 3]
+    cam_center = (cam_center + translate) * scale
+    C2W[:3, 3] = cam_center
+    Rt = np.linalg.inv(C2W)
+    return np.float64(Rt)
+
+
+def getProjectionMatrix(znear, zfar, fovX, fovY):
+    """Restates reference utils/graphics_utils.py:51-71."""
+    tanHalfFovY = math.tan(fovY / 2)
+    tanHalfFovX = math.tan(fovX / 2)
+    top = tanHalfFovY * znear
+    bottom = -top
+    right = tanHalfFovX * znear
+    left = -right
+    P = torch.zeros(4, 4)
+    z_sign = 1.0
+    P[0, 0] = 2.0 * znear / (right - left)
+    P[1, 1] = 2.0 * znear / (top - bottom)
+    P[0, 2] = (right + left) / (right - left)
+    P[1, 2] = (top + bottom) / (top - bottom)
+    P[3, 2] = z_sign
+    P[2, 2] = z_sign * zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+def focal2fov(focal, pixels):
+    return 2 * math.atan(pixels / (2 * focal))
+
+
+class SynthCamera:
+    """Duck-types the fields of reference scene/cameras.py Camera / MiniCam that render() reads."""
+
+    def __init__(self, uid, R, T, FoVx, FoVy, width, height, device="cpu"):
+        self.uid = uid
+        self.R, self.T = R, T
+        self.FoVx, self.FoVy = FoVx, FoVy
+        self.image_width, self.image_height = int(width), int(height)
+        self.znear, self.zfar = 0.01, 100.0
+        wvt = torch.tensor(getWorld2View2(R, T).astype(np.float32)).transpose(0, 1)
+        proj = getProjectionMatrix(self.znear, self.zfar, FoVx, FoVy).transpose(0, 1)
+        self.world_view_transform = wvt.to(device)
+        self.projection_matrix = proj.to(device)
+        self.full_proj_transform = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0).to(device)
+        self.camera_center = wvt.inverse()[3, :3].to(device)
+        self.original_image = None
+
+    def to(self, device):
+        for k in ("world_view_transform", "projection_matrix", "full_proj_transform", "camera_center"):
+            setattr(self, k, getattr(self, k).to(device))
+        if self.original_image is not None:
+            self.original_image = self.original_image.to(device)
+        return self
+
+
+def look_at_camera(uid, eye, target, width, height, focal_px, device="cpu"):
+    """COLMAP-style camera (x right, y down, z forward) at `eye` looking at `target`."""
+    eye = np.asarray(eye, np.float64)
+    fwd = np.asarray(target, np.float64) - eye
+    fwd /= np.linalg.norm(fwd)
+    up_hint = np.array([0.0, 1.0, 0.0]) if abs(fwd[1]) < 0.95 else np.array([1.0, 0.0, 0.0])
+    right = np.cross(fwd, up_hint)
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    R_c2w = np.stack([right, down, fwd], axis=1)     # columns = camera axes in world
+    R_w2c = R_c2w.T
+    T = -R_w2c @ eye
+    # reference stores R = transposed W2C rotation (== C2W), T = W2C translation (dataset_readers)
+    return SynthCamera(uid, R_c2w, T, focal2fov(focal_px, width), focal2fov(focal_px, height), width, height, device)
+
+
+def make_cameras(n=36, width=1600, height=1200, device="cpu", focal_mult=1.2):
+    """3 rows x 12 cameras on arcs 2.0-2.5 units above the slab, looking at its centre."""
+    cams = []
+    rows = 3
+    per_row = max(1, n // rows)
+    target = np.array([0.0, 0.0, 0.3])
+    for i in range(n):
+        r, k = divmod(i, per_row)
+        r = min(r, rows - 1)
+        height_z = 2.0 + 0.25 * r
+        ang = (k / per_row) * 2.0 * math.pi + 0.13 * r
+        rad = 0.45 + 0.1 * r
+        eye = np.array([rad * math.cos(ang), 0.6 * rad * math.sin(ang), 0.3 + height_z])
+        cams.append(look_at_camera(i, eye, target, width, height, focal_mult * width, device))
+    return cams
+
+
+@dataclass
+class SynthScene:
+    xyz: torch.Tensor            # (P,3)
+    features_dc: torch.Tensor    # (P,1,3)
+    features_rest: torch.Tensor  # (P,15,3)
+    scaling: torch.Tensor        # (P,3) log-scale (pre-activation)
+    rotation: torch.Tensor       # (P,4) un-normalised quaternion (pre-activation)
+    opacity: torch.Tensor        # (P,1) logit (pre-activation)
+
+    def to(self, device):
+        return SynthScene(*(getattr(self, f).to(device) for f in
+                            ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity")))
+
+    @property
+    def P(self):
+        return self.xyz.shape[0]
+
+
+def make_scene(P, seed=0, scale_mean=0.006, scale_sigma=0.6):
+    """Plot-shaped slab: xyz ~ U([-1.5,1.5]x[-0.75,0.75]x[0,0.6]),
+    log-scale ~ N(log scale_mean, scale_sigma^2) per axis, quat ~ N(0,1)^4, opacity logit ~ N(0,2^2),
+    SH DC ~ N(0,1), higher bands ~ N(0,0.15^2)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    u = torch.rand(P, 3, generator=g)
+    xyz = torch.stack([u[:, 0] * 3.0 - 1.5, u[:, 1] * 1.5 - 0.75, u[:, 2] * 0.6], 1)
+    scaling = math.log(scale_mean) + scale_sigma * torch.randn(P, 3, generator=g)
+    rotation = torch.randn(P, 4, generator=g)
+    opacity = 2.0 * torch.randn(P, 1, generator=g)
+    f_dc = torch.randn(P, 1, 3, generator=g)
+    f_rest = 0.15 * torch.randn(P, 15, 3, generator=g)
+    return SynthScene(xyz.contiguous(), f_dc, f_rest, scaling, rotation, opacity)
+
+
+def small_test_scene(P=200, W=64, H=48, seed=0, scale=0.05, n_cams=4):
+    """A tiny scene for parity tests: fat Gaussians so a 64x48 image is well covered, one of
+    them behind the camera (culled), one far outside the frustum (FoV clamp / empty rect)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sc = make_scene(P, seed=seed, scale_mean=scale, scale_sigma=0.5)
+    sc.xyz[:, 0] *= 0.35
+    sc.xyz[:, 1] *= 0.5
+    if P > 4:
+        sc.xyz[1] = torch.tensor([0.0, 0.0, 5.0])       # behind / above the cameras -> near-culled
+        sc.xyz[2] = torch.tensor([40.0, 0.0, 0.3])      # far off-axis -> FoV clamp, empty rect
+        sc.features_dc[3] = torch.tensor([[-9.0, 0.2, 0.1]])   # forces an SH clamp on one channel
+        sc.opacity[4] = 12.0                                    # alpha saturates at 0.99
+        sc.scaling[4] = math.log(scale * 3)
+    cams = make_cameras(n_cams, W, H, focal_mult=1.2)
+    _ = g
+    return sc, cams
