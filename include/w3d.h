@@ -16,9 +16,10 @@
  *   w3d_knn_dist2
  *        <- simple_knn._C.distCUDA2            reference scene/gaussian_model.py:20,148
  *   w3d_l1_ssim_fwd_bwd (next-row N1)
- *        <- utils/loss_utils.py:17-63 as used at train_vanilla_3dgs.py:77-80
+ *        <- utils/loss_utils.py:17-63 (l1_loss, ssim) as used at train_vanilla_3dgs.py:77-80
  *   w3d_adam_step (next-row N2)
- *        <- torch.optim.Adam over the 6 parameter groups, scene/gaussian_model.py:172-182
+ *        <- torch.optim.Adam over the 6 parameter groups, scene/gaussian_model.py:172-182,
+ *           stepped at train_vanilla_3dgs.py:113-115
  *
  * Conventions: plain pointers and sizes only (no torch types).  Every pointer named in a
  * signature is a DEVICE pointer unless its name ends in _host.  All arrays are fp32, dense,
@@ -110,6 +111,26 @@ int w3d_backward(const w3d_view *view, int32_t P, const float *means3D, const fl
 
 /* mean squared distance to the 3 nearest other points; points (N,3) -> out (N,) */
 int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream);
+
+/* ---- next-row N1: fused photometric loss 0.8*L1 + 0.2*(1-SSIM) (lambda_dssim = 0.2), value and
+ * gradient in one call.  image, gt, dL_dimage: (C,H,W); loss_out: device scalar (overwritten). */
+int w3d_l1_ssim_sizes(int32_t C, int32_t H, int32_t W, uint64_t *scratch_bytes);
+int w3d_l1_ssim_fwd_bwd(int32_t C, int32_t H, int32_t W, const float *image, const float *gt,
+                        float lambda_dssim, float *loss_out, float *dL_dimage, void *scratch,
+                        w3d_stream_t stream);
+
+/* ---- next-row N2: one Adam step over n contiguous fp32 elements (torch.optim.Adam semantics,
+ * no weight decay / amsgrad): m,v updated in place, param -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).
+ * The four arrays must share their 16-B misalignment.  zero_grad != 0 also clears grad. */
+int w3d_adam_step(uint64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, float lr,
+                  float beta1, float beta2, float eps, float bias_correction1, float bias_correction2,
+                  int32_t zero_grad, w3d_stream_t stream);
+
+/* Diagnostics for bench.py's roofline leg: time the launches whose stage name contains
+ * `kernel_substr` ("*" = all, NULL/"" = off) with HIP events on their launch stream;
+ * w3d_profile_collect waits for them and writes "name count total_ms" lines into out. */
+int w3d_profile_enable(const char *kernel_substr);
+int w3d_profile_collect(char *out, uint64_t cap);
 
 /* Debug/inspection: copies of internal per-tile ranges (T,2) uint32 laid out as [start,end). */
 int w3d_debug_tile_ranges(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *ranges_out, w3d_stream_t stream);

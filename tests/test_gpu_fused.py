@@ -1,0 +1,94 @@
+"""-m gpu: the fused "next-row" kernels (N1 loss, N2 Adam) and one training step, against the
+torch restatements of the reference formulas (fp32 tolerance stated per check)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(3, 40, 56), (3, 75, 133), (3, 300, 400), (1, 17, 16)])
+def test_fused_l1_ssim_matches_torch(shape):
+    from w3d_amd.loss import photometric_loss, photometric_loss_torch
+    g = torch.Generator().manual_seed(shape[1])
+    gt = torch.rand(*shape, generator=g)
+    img = (gt + 0.1 * torch.randn(*shape, generator=g)).clamp(0, 1)
+    img[:, :3, :5] = gt[:, :3, :5]                      # exact zeros of |x-y|: sign(0) = 0
+    a = img.clone().requires_grad_(True)
+    ref = photometric_loss_torch(a, gt, 0.2)
+    ref.backward()
+    b = img.cuda().requires_grad_(True)
+    out = photometric_loss(b, gt.cuda(), 0.2)
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    gerr = (b.grad.cpu() - a.grad).abs().max() / a.grad.abs().max()
+    assert float(gerr) <= 2e-5, f"loss gradient rel err {float(gerr):.2e}"
+
+
+def test_fused_loss_against_golden():
+    """tests/golden/loss.npz holds l1 / ssim computed by the reference's own utils/loss_utils.py."""
+    import os
+    from w3d_amd.loss import photometric_loss
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss.npz"))
+    img1, img2 = torch.tensor(z["img1"]).cuda(), torch.tensor(z["img2"]).cuda()
+    want = 0.8 * float(z["l1"]) + 0.2 * (1.0 - float(z["ssim"]))
+    got = float(photometric_loss(img1, img2, 0.2))
+    assert abs(got - want) <= 2e-6
+
+
+@pytest.mark.parametrize("n,offset", [(1000, 0), (4099, 3), (5, 1), (1 << 20, 2)])
+def test_fused_adam_matches_torch(n, offset):
+    from w3d_amd.fused import adam_step
+    g = torch.Generator().manual_seed(n)
+    base = [torch.randn(n + 8, generator=g) for _ in range(3)] + [torch.rand(n + 8, generator=g)]
+    p0, g0, m0, v0 = [t[offset:offset + n].clone() for t in base]
+    p = torch.nn.Parameter(p0.clone())
+    optim = torch.optim.Adam([p], lr=0.01, eps=1e-15)
+    # prime torch's state with the same moments and step count
+    p.grad = g0.clone()
+    optim.step()
+    st = optim.state[p]
+    st["exp_avg"].copy_(m0)
+    st["exp_avg_sq"].copy_(v0)
+    with torch.no_grad():
+        p.copy_(p0)
+    optim.step()                                     # step 2 with the primed state
+    dev = [t.cuda() for t in base]
+    pc, gc, mc, vc = [t[offset:offset + n] for t in dev]
+    b1, b2 = 0.9, 0.999
+    adam_step(pc, gc, mc, vc, 0.01, b1, b2, 1e-15, 1 - b1 ** 2, 1 - b2 ** 2, zero_grad=True)
+    upd_ref, upd = p.detach() - p0, pc.cpu() - p0
+    assert float(((upd - upd_ref).abs() / (upd_ref.abs() + 1e-6)).max()) <= 2e-5
+    assert float((mc.cpu() - st["exp_avg"]).abs().max()) <= 1e-6
+    assert float((vc.cpu() - st["exp_avg_sq"]).abs().max()) <= 1e-6
+    assert float(gc.abs().max()) == 0
+    # neighbours outside the slice untouched
+    assert torch.equal(dev[0][:offset].cpu(), base[0][:offset]) and torch.equal(dev[0][offset + n:].cpu(), base[0][offset + n:])
+
+
+def test_training_step_decreases_loss_and_tracks_stats():
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.train import Trainer, render_views
+    dev = torch.device("cuda:0")
+    W, H = 160, 120
+    cams = [c.to(dev) for c in make_cameras(6, W, H)]
+    bg = torch.zeros(3, device=dev)
+    target = make_scene(4000, seed=5, scale_mean=0.03)
+    tm = GaussianModel(3, device=dev)
+    tm.create_from_tensors(target.xyz, target.features_dc, target.features_rest, target.scaling, target.rotation, target.opacity)
+    tm.active_sh_degree = 3
+    for cam, img in zip(cams, render_views(tm, cams, bg)):
+        cam.original_image = img.clamp(0, 1)
+    sc = make_scene(4000, seed=6, scale_mean=0.03)
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    m.active_sh_degree = 3
+    opt = OptimizationParams()
+    m.training_setup(opt)
+    tr = Trainer(m, cams, opt, bg, densify=False)
+    losses = [float(tr.step(i + 1)) for i in range(60)]
+    assert np.mean(losses[-10:]) < 0.9 * np.mean(losses[:10])
+    assert float(m.denom.max()) > 0 and float(m.xyz_gradient_accum.max()) > 0 and float(m.max_radii2D.max()) > 0
+    assert float(m.flat_grad.abs().max()) == 0          # bucket cleared by the fused step
+    assert torch.isfinite(m.flat).all()

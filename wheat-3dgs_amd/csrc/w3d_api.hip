@@ -6,7 +6,35 @@
 
 #include "w3d_common.h"
 
+#include <map>
+#include <string>
+#include <vector>
+
 static thread_local char g_err[512] = "";
+
+// ---- per-kernel event timing (diagnostic state; the only non-error global in the library)
+namespace {
+struct ProfRec { std::string name; hipEvent_t a, b; };
+std::vector<ProfRec> g_prof;
+std::string g_prof_filter;
+bool g_prof_on = false, g_prof_open = false;
+}  // namespace
+
+void w3d_prof_begin(const char *name, hipStream_t stream) {
+    g_prof_open = false;
+    if (!g_prof_on) return;
+    if (g_prof_filter != "*" && std::string(name).find(g_prof_filter) == std::string::npos) return;
+    ProfRec r;
+    r.name = name;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    hipEventRecord(r.a, stream);
+    g_prof.push_back(r);
+    g_prof_open = true;
+}
+void w3d_prof_end(hipStream_t stream) {
+    if (g_prof_open) hipEventRecord(g_prof.back().b, stream);
+    g_prof_open = false;
+}
 
 void w3d_set_error(const char *fmt, ...) {
     va_list ap;
@@ -48,6 +76,38 @@ static int check_variants(const w3d_view *v, const float *shs, const float *colo
 extern "C" {
 
 int w3d_version(void) { return 100; }
+
+int w3d_profile_enable(const char *kernel_substr) {
+    g_prof_on = kernel_substr && kernel_substr[0];
+    g_prof_filter = g_prof_on ? kernel_substr : "";
+    return W3D_OK;
+}
+
+// Waits for the recorded events, writes "name count total_ms\n" lines into out (NUL-terminated),
+// and clears the records.
+int w3d_profile_collect(char *out, uint64_t cap) {
+    std::map<std::string, std::pair<int, double>> agg;
+    for (auto &r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            agg[r.name].first += 1;
+            agg[r.name].second += ms;
+        }
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    std::string txt;
+    for (auto &kv : agg) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s %d %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        txt += line;
+    }
+    if (out && cap > 0) {
+        snprintf(out, cap, "%s", txt.c_str());
+    }
+    return W3D_OK;
+}
 
 const char *w3d_last_error(void) { return g_err; }
 

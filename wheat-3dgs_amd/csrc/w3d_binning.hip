@@ -268,6 +268,7 @@ int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state
         // ---- stable LSD radix sort of (depth bits, id), 4 x 8 bits; culled Gaussians carry key 0xFFFFFFFF
         const uint32_t n = (uint32_t)L.P, runs = L.sort_waves, blocks = (runs + 3) / 4;
         int src = 0;
+        W3D_PROF("depth_sort", stream);
         for (int pass = 0; pass < 4; pass++) {
             const int shift = 8 * pass;
             hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], n, L.sort_items, runs, shift, hist);
@@ -288,6 +289,7 @@ int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state
     const size_t lds16 = (size_t)bpw16 * wpb;
     if (lds16 > 64 * 1024)
         W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+    W3D_PROF("tile_count_scan", stream);
     hipLaunchKernelGGL(chunk_walk_kernel<0>, dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds16, stream, vals[0],
                        reinterpret_cast<const uint2 *>(state + L.o_rect), counters, L.chunk, L.C, T, (uint32_t)L.gx, wpb, cnt,
                        (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0);
@@ -312,6 +314,7 @@ int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, ch
     const size_t lds32 = (size_t)bpw32 * wpb;
     if (lds32 > 64 * 1024)
         W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+    W3D_PROF("fill_lists", stream);
     hipLaunchKernelGGL(chunk_walk_kernel<1>, dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds32, stream,
                        reinterpret_cast<const uint32_t *>(scratch + L.s_vals0), reinterpret_cast<const uint2 *>(state + L.o_rect),
                        reinterpret_cast<const uint32_t *>(state + L.o_counters), L.chunk, L.C, T, (uint32_t)L.gx, wpb,

@@ -108,6 +108,17 @@ void w3d_set_error(const char *fmt, ...);
         if (view_debug) W3D_HIP_CHECK(hipStreamSynchronize(stream));                         \
     } while (0)
 
+// optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg);
+// off by default, enabled per kernel-name substring through w3d_profile_enable().
+void w3d_prof_begin(const char *name, hipStream_t stream);
+void w3d_prof_end(hipStream_t stream);
+struct W3DProfScope {
+    hipStream_t s;
+    W3DProfScope(const char *name, hipStream_t stream) : s(stream) { w3d_prof_begin(name, stream); }
+    ~W3DProfScope() { w3d_prof_end(s); }
+};
+#define W3D_PROF(name, stream) W3DProfScope w3d_prof_scope_(name, stream)
+
 // kernels' host launchers (one per .hip file)
 int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,
                           const float *colors_precomp, const float *opacities, const float *scales,

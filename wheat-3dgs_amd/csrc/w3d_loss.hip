@@ -1,0 +1,182 @@
+// w3d_loss.hip — fused photometric loss 0.8*L1 + 0.2*(1-SSIM), value AND gradient w.r.t. the
+// rendered image in two LDS-tiled passes (replaces the five grouped 11x11
+// conv2d of reference utils/loss_utils.py:43-63 plus their autograd backward, as used at
+// train_vanilla_3dgs.py:77-80).  The 11x11 Gaussian window (sigma 1.5, zero padding) is
+// separable: every pass stages a (16+10)^2 halo tile in LDS, filters rows then columns.
+//   pass A: mu1, mu2, E[x^2], E[y^2], E[xy] -> ssim map (summed) and the three partial
+//           derivatives d ssim / d{mu1, E[x^2], E[xy]} written per pixel;
+//   pass B: the same window applied to those three maps (the adjoint of a symmetric zero-padded
+//           convolution is itself) and combined with x, y and sign(x-y).
+#include "w3d_common.h"
+
+namespace {
+
+#define LT 16            // output tile edge
+#define LH 5             // window half width
+#define LW (LT + 2 * LH) // 26
+
+struct GW11 { float w[11]; };   // window weights, passed by value as a kernel argument
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wv] = v;
+    __syncthreads();
+    const float s = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return s;
+}
+
+__global__ void __launch_bounds__(256)
+ssim_pass_a(int H, int W, const float *__restrict__ img, const float *__restrict__ gt, float *__restrict__ d_mu1,
+            float *__restrict__ d_ex2, float *__restrict__ d_exy, float *__restrict__ sums, GW11 gw) {
+    __shared__ float sx[LW][LW + 1], sy[LW][LW + 1];
+    __shared__ float h[5][LW][LT + 1];
+    __shared__ float red[4];
+    const int c = blockIdx.z;
+    const size_t plane = (size_t)c * H * W;
+    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < LW * LW; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = y0 + ly - LH, gx = x0 + lx - LH;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        sx[ly][lx] = in ? img[plane + (size_t)gy * W + gx] : 0.f;
+        sy[ly][lx] = in ? gt[plane + (size_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    float w[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) w[k] = gw.w[k];
+    // horizontal pass: LW rows x LT columns
+    for (int i = tid; i < LW * LT; i += 256) {
+        const int ly = i / LT, lx = i - ly * LT;
+        float a = 0, b = 0, aa = 0, bb = 0, ab = 0;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const float xv = sx[ly][lx + k], yv = sy[ly][lx + k], wk = w[k];
+            a += wk * xv; b += wk * yv; aa += wk * xv * xv; bb += wk * yv * yv; ab += wk * xv * yv;
+        }
+        h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = aa; h[3][ly][lx] = bb; h[4][ly][lx] = ab;
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    float mu1 = 0, mu2 = 0, ex2 = 0, ey2 = 0, exy = 0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        const float wk = w[k];
+        mu1 += wk * h[0][ly + k][lx]; mu2 += wk * h[1][ly + k][lx]; ex2 += wk * h[2][ly + k][lx];
+        ey2 += wk * h[3][ly + k][lx]; exy += wk * h[4][ly + k][lx];
+    }
+    const int gx = x0 + lx, gy = y0 + ly;
+    const bool in = gx < W && gy < H;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, m12 = mu1 * mu2;
+    const float s11 = ex2 - mu1s, s22 = ey2 - mu2s, s12 = exy - m12;
+    const float A = 2.f * m12 + C1, B = 2.f * s12 + C2, Cc = mu1s + mu2s + C1, D = s11 + s22 + C2;
+    const float inv = 1.f / (Cc * D);
+    const float ssim = A * B * inv;
+    float l1 = 0.f, sv = 0.f;
+    if (in) {
+        const size_t pix = plane + (size_t)gy * W + gx;
+        // d ssim / d mu1 with E[x^2], E[xy] held fixed; d/dE[x^2]; d/dE[xy]
+        const float dmu1 = (2.f * mu2 * (B - A) * Cc * D - A * B * 2.f * mu1 * (D - Cc)) * inv * inv;
+        d_mu1[pix] = dmu1;
+        d_ex2[pix] = -A * B * inv / D;
+        d_exy[pix] = 2.f * A * inv;
+        l1 = fabsf(sx[ly + LH][lx + LH] - sy[ly + LH][lx + LH]);
+        sv = ssim;
+    }
+    const float l1s = block_sum(l1, red);
+    const float svs = block_sum(sv, red);
+    if (tid == 0) { atomicAdd(&sums[0], l1s); atomicAdd(&sums[1], svs); }
+}
+
+__global__ void __launch_bounds__(256)
+ssim_pass_b(int H, int W, const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ d_mu1,
+            const float *__restrict__ d_ex2, const float *__restrict__ d_exy, float lambda, float inv_n,
+            float *__restrict__ grad, GW11 gw) {
+    __shared__ float s[3][LW][LW + 1];
+    __shared__ float h[3][LW][LT + 1];
+    const int c = blockIdx.z;
+    const size_t plane = (size_t)c * H * W;
+    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < LW * LW; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = y0 + ly - LH, gx = x0 + lx - LH;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t pix = plane + (size_t)gy * W + gx;
+        s[0][ly][lx] = in ? d_mu1[pix] : 0.f;
+        s[1][ly][lx] = in ? d_ex2[pix] : 0.f;
+        s[2][ly][lx] = in ? d_exy[pix] : 0.f;
+    }
+    __syncthreads();
+    float w[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) w[k] = gw.w[k];
+    for (int i = tid; i < LW * LT; i += 256) {
+        const int ly = i / LT, lx = i - ly * LT;
+        float a = 0, b = 0, cc = 0;
+#pragma unroll
+        for (int k = 0; k < 11; k++) { a += w[k] * s[0][ly][lx + k]; b += w[k] * s[1][ly][lx + k]; cc += w[k] * s[2][ly][lx + k]; }
+        h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = cc;
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    float c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) { c1 += w[k] * h[0][ly + k][lx]; c2 += w[k] * h[1][ly + k][lx]; c3 += w[k] * h[2][ly + k][lx]; }
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx < W && gy < H) {
+        const size_t pix = plane + (size_t)gy * W + gx;
+        const float x = img[pix], y = gt[pix];
+        const float d = x - y;
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        grad[pix] = (1.f - lambda) * inv_n * sgn - lambda * inv_n * (c1 + 2.f * x * c2 + y * c3);
+    }
+}
+
+__global__ void loss_finalize(const float *__restrict__ sums, float lambda, float inv_n, float *__restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        loss[0] = (1.f - lambda) * (sums[0] * inv_n) + lambda * (1.f - sums[1] * inv_n);
+}
+
+}  // namespace
+
+extern "C" int w3d_l1_ssim_sizes(int32_t C, int32_t H, int32_t W, uint64_t *scratch_bytes) {
+    if (C <= 0 || H <= 0 || W <= 0) { w3d_set_error("loss: bad sizes"); return W3D_ERR_INVALID; }
+    if (scratch_bytes) *scratch_bytes = 256 + 3 * w3d_align_up((uint64_t)C * H * W * 4);
+    return W3D_OK;
+}
+
+extern "C" int w3d_l1_ssim_fwd_bwd(int32_t C, int32_t H, int32_t W, const float *image, const float *gt,
+                                   float lambda_dssim, float *loss_out, float *dL_dimage, void *scratch,
+                                   w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (C <= 0 || H <= 0 || W <= 0 || !image || !gt || !loss_out || !dL_dimage || !scratch) {
+        w3d_set_error("loss: bad arguments");
+        return W3D_ERR_INVALID;
+    }
+    char *sc = static_cast<char *>(scratch);
+    const uint64_t plane = w3d_align_up((uint64_t)C * H * W * 4);
+    float *sums = reinterpret_cast<float *>(sc);
+    float *d_mu1 = reinterpret_cast<float *>(sc + 256), *d_ex2 = reinterpret_cast<float *>(sc + 256 + plane),
+          *d_exy = reinterpret_cast<float *>(sc + 256 + 2 * plane);
+    // exact fp32 window of the reference: exp(-(x-5)^2 / (2*1.5^2)) normalised
+    GW11 gw;
+    float sum = 0.f;
+    for (int i = 0; i < 11; i++) { gw.w[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); sum += gw.w[i]; }
+    for (int i = 0; i < 11; i++) gw.w[i] /= sum;
+    W3D_HIP_CHECK(hipMemsetAsync(sums, 0, 256, stream));
+    const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
+    const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
+    hipLaunchKernelGGL(ssim_pass_a, grid, dim3(256), 0, stream, H, W, image, gt, d_mu1, d_ex2, d_exy, sums, gw);
+    W3D_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(64), 0, stream, sums, lambda_dssim, inv_n, loss_out);
+    hipLaunchKernelGGL(ssim_pass_b, grid, dim3(256), 0, stream, H, W, image, gt, d_mu1, d_ex2, d_exy, lambda_dssim, inv_n,
+                       dL_dimage, gw);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}

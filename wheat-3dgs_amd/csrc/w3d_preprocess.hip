@@ -496,6 +496,7 @@ int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *me
     W3D_HIP_CHECK(hipMemsetAsync(state + L.o_rect, 0, (size_t)(L.P > 0 ? L.P : 1) * 8, stream));
     if (L.P == 0) return W3D_OK;
     const int block = 256, grid = (L.P + block - 1) / block;
+    W3D_PROF("preprocess_fwd", stream);
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(grid), dim3(block), 0, stream, v, L.P, L.gx, L.gy, means3D, shs,
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, radii,
                        reinterpret_cast<float2 *>(state + L.o_xy), reinterpret_cast<float4 *>(state + L.o_conic_op),
@@ -533,6 +534,7 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
                        reinterpret_cast<const ushort4 *>(state + L.o_rect),                                           \
                        reinterpret_cast<const uint8_t *>(state + L.o_clamped), (const uint32_t *)nullptr, grad2d,     \
                        dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
+    W3D_PROF("preprocess_bwd", stream);
     if (has_sh && has_sr) LAUNCH(true, true);
     else if (has_sh) LAUNCH(true, false);
     else if (has_sr) LAUNCH(false, true);

@@ -341,8 +341,11 @@ int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const 
         reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg, out_color, out_depth, out_alpha,                    \
         reinterpret_cast<float *>(state + L.o_final_T), reinterpret_cast<uint32_t *>(state + L.o_n_contrib), gt_mask, \
         num_obj, L.P, used_count, contrib_num
-    if (flash) hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, ARGS);
-    else hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, ARGS);
+    {
+        W3D_PROF("render_fwd", stream);
+        if (flash) hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, ARGS);
+        else hipLaunchKernelGGL(render_fwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, ARGS);
+    }
 #undef ARGS
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;
@@ -361,8 +364,11 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
         reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg,                                                 \
         reinterpret_cast<const float *>(state + L.o_final_T), reinterpret_cast<const uint32_t *>(state + L.o_n_contrib), \
         dL_dcolor, dL_ddepth, dL_dalpha, grad2d
-    if (dL_ddepth || dL_dalpha) hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, ARGS);
-    else hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, ARGS);
+    {
+        W3D_PROF("render_bwd", stream);
+        if (dL_ddepth || dL_dalpha) hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, ARGS);
+        else hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(blocks), dim3(256), 0, stream, ARGS);
+    }
 #undef ARGS
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;

@@ -1,0 +1,87 @@
+"""render() / flashsplat_render(): same names, arguments and returned dict keys as reference
+gaussian_renderer/__init__.py:22-106 and :109-218 (pinned by tests/golden/render_marshalling.json),
+so the reference's train / seg / render scripts can call this module unchanged."""
+import math
+
+import torch
+
+from .rasterizer import (FlashSplatRasterizationSettings, FlashSplatRasterizer, GaussianRasterizationSettings,
+                         GaussianRasterizer)
+
+
+def _sh_python(pc, viewpoint_camera):
+    from .sh import eval_sh
+    shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+    dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+    dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    return torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp) + 0.5, 0.0)
+
+
+def _settings(cls, cam, pc, bg_color, scaling_modifier, debug, **extra):
+    return cls(image_height=int(cam.image_height), image_width=int(cam.image_width),
+               tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color,
+               scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform,
+               projmatrix=cam.full_proj_transform, sh_degree=pc.active_sh_degree, campos=cam.camera_center,
+               prefiltered=False, debug=debug, **extra)
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    rasterizer = GaussianRasterizer(raster_settings=_settings(GaussianRasterizationSettings, viewpoint_camera, pc,
+                                                              bg_color, scaling_modifier, False))
+    scales = rotations = cov3D_precomp = shs = colors_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            colors_precomp = _sh_python(pc, viewpoint_camera)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+    rendered_image, radii, rendered_depth, rendered_alpha = rasterizer(
+        means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp, opacities=pc.get_opacity,
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "depth": rendered_depth, "alpha": rendered_alpha}
+
+
+def flashsplat_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, gt_mask=None,
+                      used_mask=None, unique_label=None, setpdb=False, obj_num=2):
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    rasterizer = FlashSplatRasterizer(raster_settings=_settings(
+        FlashSplatRasterizationSettings, viewpoint_camera, pc, bg_color, scaling_modifier, pipe.debug,
+        mask_grad=False, num_obj=obj_num))
+    sub = (lambda t: t[used_mask]) if used_mask is not None else (lambda t: t)
+    means3D, opacity = sub(xyz), sub(pc.get_opacity)
+    scales = rotations = cov3D_precomp = shs = colors_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = sub(pc.get_scaling), sub(pc.get_rotation)
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            colors_precomp = _sh_python(pc, viewpoint_camera)
+        else:
+            shs = sub(pc.get_features)
+    else:
+        colors_precomp = override_color
+    rendered_image, radii, depth, alpha, contrib_num, used_count, proj_xy, gs_depth = rasterizer(
+        gt_mask=gt_mask, unique_label=unique_label, means3D=means3D, means2D=screenspace_points, shs=shs,
+        colors_precomp=colors_precomp, opacities=opacity, scales=scales, rotations=rotations,
+        cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "alpha": alpha, "depth": depth, "contrib_num": contrib_num, "used_count": used_count,
+            "proj_xy": proj_xy, "gs_depth": gs_depth}

@@ -1,0 +1,69 @@
+"""Photometric loss of the training step: 0.8*L1 + 0.2*(1-SSIM) (reference
+train_vanilla_3dgs.py:77-79, utils/loss_utils.py:17-63; pinned by tests/golden/loss.npz).
+
+`l1_loss` / `ssim` / `psnr` restate the reference formulas with torch ops (host logic, CPU
+tests, and the parity check of the fused kernel).  `fused_l1_ssim` is the product path on the
+GPU: one hand-written HIP pass pair (csrc/w3d_loss.hip) that produces the scalar loss AND
+dL/dimage directly, replacing five grouped 11x11 convolutions forward plus their autograd
+backward.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def l1_loss(network_output, gt):
+    return torch.abs(network_output - gt).mean()
+
+
+def gaussian_window_1d(window_size=11, sigma=1.5):
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    return g / g.sum()
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    channel = img1.size(-3)
+    w1 = gaussian_window_1d(window_size).unsqueeze(1)
+    window = w1.mm(w1.t()).float()[None, None].expand(channel, 1, window_size, window_size).contiguous().to(img1)
+    pad = window_size // 2
+    x, y = (img1, img2) if img1.dim() == 4 else (img1[None], img2[None])
+    mu1 = F.conv2d(x, window, padding=pad, groups=channel)
+    mu2 = F.conv2d(y, window, padding=pad, groups=channel)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s11 = F.conv2d(x * x, window, padding=pad, groups=channel) - mu1_sq
+    s22 = F.conv2d(y * y, window, padding=pad, groups=channel) - mu2_sq
+    s12 = F.conv2d(x * y, window, padding=pad, groups=channel) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s11 + s22 + C2))
+    return m.mean() if size_average else m.mean(1).mean(1).mean(1)
+
+
+def psnr(img1, img2):
+    mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+def photometric_loss_torch(image, gt, lambda_dssim=0.2):
+    return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+
+
+class _FusedL1SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim):
+        from .fused import l1_ssim_fwd_bwd
+        loss, grad = l1_ssim_fwd_bwd(image, gt, lambda_dssim)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def photometric_loss(image, gt, lambda_dssim=0.2):
+    """0.8*L1 + 0.2*(1-SSIM).  GPU: fused HIP kernel; CPU tensors: the torch restatement."""
+    if image.is_cuda:
+        return _FusedL1SSIM.apply(image, gt, lambda_dssim)
+    return photometric_loss_torch(image, gt, lambda_dssim)

@@ -1,0 +1,114 @@
+"""The training step around the rasterizer — what "train iters/sec" measures.
+
+One step = the loop body of reference train_vanilla_3dgs.py:55-115: LR schedule, SH degree
+ramp, pick a camera, render(), 0.8*L1 + 0.2*(1-SSIM), backward, densification statistics,
+(densify / prune / opacity reset on their schedule), Adam step, zero_grad.
+
+View-parallel data parallelism (the reference itself is single-GPU): one process
+per GPU, every rank holds a full replica of the Gaussians and renders a DIFFERENT camera of the
+same step; then
+  * the densification statistics are exchanged BEFORE gradients are averaged — they are sums of
+    per-view gradient NORMS, visibility counts and a max of radii (scene/gaussian_model.py:461-463,
+    train_vanilla_3dgs.py:102-103), not functions of the averaged gradient;
+  * the 59 x P fp32 gradient bucket (GaussianModel.flat_grad, 236 B per Gaussian) is all-reduced
+    once over RCCL/xGMI and averaged;
+  * densify/prune then run identically on every rank (same statistics, same RNG seed for the
+    split samples) so the replicas stay in lock-step without a parameter broadcast.
+"""
+import torch
+import torch.distributed as dist
+
+from .gaussian_renderer import render
+from .loss import photometric_loss
+
+
+class PipelineParams:
+    """Defaults of reference arguments/__init__.py:64-69."""
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+
+
+def dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class Trainer:
+    def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
+                 densify=True, loss_fn=photometric_loss):
+        self.model, self.cameras, self.opt = model, cameras, opt
+        self.bg = background
+        self.pipe = pipe or PipelineParams()
+        self.extent = cameras_extent
+        self.densify = densify
+        self.loss_fn = loss_fn
+        self.rank, self.world = dist_info()
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.perm = torch.randperm(len(cameras), generator=g).tolist()
+        self.last = {}
+
+    def camera_for(self, iteration):
+        """rank r of N renders camera perm[(it*N + r) mod n] — N distinct views per step."""
+        return self.cameras[self.perm[((iteration - 1) * self.world + self.rank) % len(self.cameras)]]
+
+    # ------------------------------------------------------------------------------------------
+    def exchange(self, grad2d_norm, visible, radii):
+        """The one exchange step of the view-parallel loop.  Returns the reduced
+        (sum of per-view norms, visibility count, max radii)."""
+        m = self.model
+        if self.world > 1:
+            stats = torch.stack([grad2d_norm * visible, visible.to(grad2d_norm.dtype)])
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+            r = radii.clone()
+            dist.all_reduce(r, op=dist.ReduceOp.MAX)
+            dist.all_reduce(m.flat_grad, op=dist.ReduceOp.SUM)
+            m.flat_grad.div_(self.world)
+            return stats[0], stats[1], r
+        return grad2d_norm * visible, visible.to(grad2d_norm.dtype), radii
+
+    def step(self, iteration):
+        m, opt = self.model, self.opt
+        m.update_learning_rate(iteration)
+        if iteration % 1000 == 0:
+            m.oneupSHdegree()
+        cam = self.camera_for(iteration)
+        pkg = render(cam, m, self.pipe, self.bg)
+        image = pkg["render"]
+        loss = self.loss_fn(image, cam.original_image, opt.lambda_dssim)
+        loss.backward()
+        with torch.no_grad():
+            vis, radii = pkg["visibility_filter"], pkg["radii"]
+            gnorm = pkg["viewspace_points"].grad[:, :2].norm(dim=-1)
+            nsum, vcount, rmax = self.exchange(gnorm, vis, radii)
+            # the reference replaces nn.Parameters on densify / opacity reset, so their .grad is None
+            # and torch's Adam skips them in that iteration's step; `skip` reproduces that.
+            skip = set()
+            if iteration < opt.densify_until_iter:
+                m.max_radii2D = torch.max(m.max_radii2D, rmax.to(m.max_radii2D.dtype))
+                m.xyz_gradient_accum += nsum[:, None]
+                m.denom += vcount[:, None]
+                if self.densify:
+                    if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+                        size_threshold = 20 if iteration > opt.opacity_reset_interval else None
+                        torch.manual_seed(1234 + iteration)     # identical split samples on every rank
+                        m.densify_and_prune(opt.densify_grad_threshold, 0.005, self.extent, size_threshold)
+                        skip = {"xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"}
+                    if iteration % opt.opacity_reset_interval == 0:
+                        m.reset_opacity()
+                        skip.add("opacity")
+            if iteration < opt.iterations:
+                m.optimizer.step(zero_grad=True, skip=skip)
+        self.last = dict(loss=loss.detach(), num_rendered=None, image=image.detach())
+        return loss.detach()
+
+
+def render_views(model, cameras, background, pipe=None):
+    """Forward-only rendering of a list of views (what reference render.py:24-35 times)."""
+    pipe = pipe or PipelineParams()
+    out = []
+    with torch.no_grad():
+        for cam in cameras:
+            out.append(render(cam, model, pipe, background)["render"])
+    return out
