@@ -45,42 +45,77 @@ radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items,
     }
 }
 
-// exclusive scan of the whole [256][n_runs] matrix in row-major (digit-major) order; one block.
-__global__ void __launch_bounds__(1024)
-radix_scan_kernel(uint32_t *__restrict__ hist, uint32_t total) {
-    __shared__ uint32_t partial[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (total + 1023) / 1024;
-    const uint32_t beg = min(total, tid * per), end = min(total, beg + per);
-    uint32_t sum = 0;
-    for (uint32_t i = beg; i < end; i++) sum += hist[i];
-    partial[tid] = sum;
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over the threads of a block (<= 1024 threads); returns the block total in `total`
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_tot /* LDS [17] */, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) wave_tot[wv] = inc;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t v = (tid >= off) ? partial[tid - off] : 0;
-        __syncthreads();
-        partial[tid] += v;
-        __syncthreads();
+    if (wv == 0) {
+        const uint32_t t = lane < nw ? wave_tot[lane] : 0u;
+        const uint32_t ti = wave_inclusive_scan(t);
+        if (lane < nw) wave_tot[lane] = ti - t;
+        if (lane == nw - 1) wave_tot[16] = ti;
     }
-    uint32_t run = (tid == 0) ? 0 : partial[tid - 1];
-    for (uint32_t i = beg; i < end; i++) {
-        const uint32_t c = hist[i];
-        hist[i] = run;
-        run += c;
+    __syncthreads();
+    const uint32_t res = wave_tot[wv] + inc - v;
+    total = wave_tot[16];
+    __syncthreads();
+    return res;
+}
+
+// one block per digit: exclusive scan of that digit's row of per-run counts (in place) + row total
+__global__ void __launch_bounds__(256)
+radix_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t n_runs, uint32_t *__restrict__ rowtot) {
+    __shared__ uint32_t wave_tot[17];
+    uint32_t *row = hist + (size_t)blockIdx.x * n_runs;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_runs; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n_runs ? row[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan(v, wave_tot, tot);
+        if (i < n_runs) row[i] = carry + ex;
+        carry += tot;
     }
+    if (threadIdx.x == 0) rowtot[blockIdx.x] = carry;
 }
 
 __global__ void __launch_bounds__(256)
 radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                      uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t items,
-                     uint32_t n_runs, int shift, const uint32_t *__restrict__ offs /* scanned [256][n_runs] */) {
+                     uint32_t n_runs, int shift, const uint32_t *__restrict__ offs /* row-scanned [256][n_runs] */,
+                     const uint32_t *__restrict__ rowtot /* [256] */, uint32_t *__restrict__ num_visible) {
     __shared__ uint32_t cur_all[4][256];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
     if (run >= n_runs) return;
     volatile uint32_t *cur = cur_all[wv];
-    for (int i = lane; i < 256; i += 64) cur[i] = offs[(size_t)i * n_runs + run];
+    {
+        // digit bases = exclusive scan of the 256 row totals, 4 digits per lane
+        const uint4 t4 = reinterpret_cast<const uint4 *>(rowtot)[lane];
+        const uint32_t lsum = t4.x + t4.y + t4.z + t4.w;
+        const uint32_t ex = wave_inclusive_scan(lsum) - lsum;
+        const uint32_t b0 = ex, b1 = b0 + t4.x, b2 = b1 + t4.y, b3 = b2 + t4.z;
+        cur[4 * lane + 0] = b0 + offs[(size_t)(4 * lane + 0) * n_runs + run];
+        cur[4 * lane + 1] = b1 + offs[(size_t)(4 * lane + 1) * n_runs + run];
+        cur[4 * lane + 2] = b2 + offs[(size_t)(4 * lane + 2) * n_runs + run];
+        cur[4 * lane + 3] = b3 + offs[(size_t)(4 * lane + 3) * n_runs + run];
+        // depth keys are positive floats (top byte < 0x80); culled Gaussians carry 0xFFFFFFFF:
+        // in the last pass the base of digit 128 is the number of visible Gaussians.
+        if (num_visible && run == 0 && lane == 32) *num_visible = b0;
+    }
     __builtin_amdgcn_wave_barrier();
     const uint32_t beg = run * items, end = min(n, beg + items);
     const uint64_t lt = lanemask_lt();
@@ -192,49 +227,38 @@ seg_sum_kernel(const uint16_t *__restrict__ cnt, uint32_t C, uint32_t T, uint32_
     part[(size_t)sg * T + t] = s;
 }
 
-// one block: totals per tile -> exclusive scan -> tile_start[T+1]; part[][] becomes the
-// absolute list offset at which each segment starts inside its tile; counters[1] = R.
+// one block: totals per tile (coalesced over tiles) -> exclusive scan -> tile_start[T+1];
+// counters[1] = R.
 __global__ void __launch_bounds__(1024)
-tile_scan_kernel(uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, uint32_t *__restrict__ tile_start,
+tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, uint32_t *__restrict__ tile_start,
                  uint32_t *__restrict__ counters) {
-    __shared__ uint32_t partial[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (T + 1023) / 1024;
-    const uint32_t beg = min(T, tid * per), end = min(T, beg + per);
-    uint32_t sum = 0;
-    for (uint32_t t = beg; t < end; t++)
-        for (uint32_t s = 0; s < nseg; s++) sum += part[(size_t)s * T + t];
-    partial[tid] = sum;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t v = (tid >= off) ? partial[tid - off] : 0;
-        __syncthreads();
-        partial[tid] += v;
-        __syncthreads();
+    __shared__ uint32_t wave_tot[17];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < T; base += 1024) {
+        const uint32_t t = base + threadIdx.x;
+        uint32_t v = 0;
+        if (t < T)
+            for (uint32_t s = 0; s < nseg; s++) v += part[(size_t)s * T + t];
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan(v, wave_tot, tot);
+        if (t < T) tile_start[t] = carry + ex;
+        carry += tot;
     }
-    uint32_t run = (tid == 0) ? 0 : partial[tid - 1];
-    for (uint32_t t = beg; t < end; t++) {
-        tile_start[t] = run;
-        for (uint32_t s = 0; s < nseg; s++) {
-            const uint32_t c = part[(size_t)s * T + t];
-            part[(size_t)s * T + t] = run;
-            run += c;
-        }
-    }
-    if (tid == 1023) {
-        tile_start[T] = partial[1023];
-        counters[1] = partial[1023];
+    if (threadIdx.x == 0) {
+        tile_start[T] = carry;
+        counters[1] = carry;
     }
 }
 
 // off[c][t] = start of chunk c's entries inside tile t's list
 __global__ void __launch_bounds__(256)
-chunk_off_kernel(const uint16_t *__restrict__ cnt, const uint32_t *__restrict__ part, uint32_t C, uint32_t T, uint32_t seg,
-                 uint32_t *__restrict__ off) {
+chunk_off_kernel(const uint16_t *__restrict__ cnt, const uint32_t *__restrict__ part, const uint32_t *__restrict__ tile_start,
+                 uint32_t C, uint32_t T, uint32_t seg, uint32_t *__restrict__ off) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, sg = blockIdx.y;
     if (t >= T) return;
     const uint32_t c0 = sg * seg, c1 = min(C, c0 + seg);
-    uint32_t run = part[(size_t)sg * T + t];
+    uint32_t run = tile_start[t];
+    for (uint32_t s = 0; s < sg; s++) run += part[(size_t)s * T + t];
     for (uint32_t c = c0; c < c1; c++) {
         off[(size_t)c * T + t] = run;
         run += cnt[(size_t)c * T + t];
@@ -260,6 +284,7 @@ int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state
     uint32_t *keys[2] = {reinterpret_cast<uint32_t *>(scratch + L.s_keys0), reinterpret_cast<uint32_t *>(scratch + L.s_keys1)};
     uint32_t *vals[2] = {reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(scratch + L.s_vals1)};
     uint32_t *hist = reinterpret_cast<uint32_t *>(scratch + L.s_hist);
+    uint32_t *rowtot = reinterpret_cast<uint32_t *>(scratch + L.s_rowtot);
     uint16_t *cnt = reinterpret_cast<uint16_t *>(scratch + L.s_cnt);
     uint32_t *part = reinterpret_cast<uint32_t *>(scratch + L.s_part);
     uint32_t *off = reinterpret_cast<uint32_t *>(scratch + L.s_off);
@@ -273,10 +298,10 @@ int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state
             const int shift = 8 * pass;
             hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], n, L.sort_items, runs, shift, hist);
             W3D_LAUNCH_CHECK(v.debug, stream);
-            hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, 256u * runs);
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, stream, hist, runs, rowtot);
             W3D_LAUNCH_CHECK(v.debug, stream);
             hipLaunchKernelGGL(radix_scatter_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], vals[src], keys[src ^ 1],
-                               vals[src ^ 1], n, L.sort_items, runs, shift, hist);
+                               vals[src ^ 1], n, L.sort_items, runs, shift, hist, rowtot, pass == 3 ? counters : (uint32_t *)nullptr);
             W3D_LAUNCH_CHECK(v.debug, stream);
             src ^= 1;
         }
@@ -300,7 +325,7 @@ int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state
     W3D_LAUNCH_CHECK(v.debug, stream);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, part, T, (uint32_t)W3D_SCAN_SEGS, tile_start, counters);
     W3D_LAUNCH_CHECK(v.debug, stream);
-    hipLaunchKernelGGL(chunk_off_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, part, L.C, T, L.seg, off);
+    hipLaunchKernelGGL(chunk_off_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, part, tile_start, L.C, T, L.seg, off);
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;
 }

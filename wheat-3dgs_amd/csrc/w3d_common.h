@@ -38,6 +38,7 @@ struct W3DLayout {
     // ---- scratch buffer (forward temporaries)
     uint64_t s_keys0, s_keys1, s_vals0, s_vals1; // u32[P] each (depth keys, Gaussian ids)
     uint64_t s_hist;       // u32[256 * sort_waves] radix digit histograms
+    uint64_t s_rowtot;     // u32[256] per-digit totals of the current radix pass
     uint64_t s_cnt;        // u16[C*T] per-chunk per-tile counts
     uint64_t s_off;        // u32[C*T] per-chunk per-tile list offsets
     uint64_t s_part;       // u32[SEGS*T]
@@ -85,6 +86,7 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->s_vals0 = o; o += w3d_align_up(Pp * 4);
     L->s_vals1 = o; o += w3d_align_up(Pp * 4);
     L->s_hist = o;  o += w3d_align_up((uint64_t)256 * L->sort_waves * 4);
+    L->s_rowtot = o; o += w3d_align_up(256 * 4);
     L->s_cnt = o;   o += w3d_align_up((uint64_t)L->C * T * 2);
     L->s_off = o;   o += w3d_align_up((uint64_t)L->C * T * 4);
     L->s_part = o;  o += w3d_align_up((uint64_t)W3D_SCAN_SEGS * T * 4);

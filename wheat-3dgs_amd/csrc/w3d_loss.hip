@@ -88,9 +88,13 @@ ssim_pass_a(int H, int W, const float *__restrict__ img, const float *__restrict
         l1 = fabsf(sx[ly + LH][lx + LH] - sy[ly + LH][lx + LH]);
         sv = ssim;
     }
+    // per-block partials (no same-address atomics: 22k of them serialise to ~0.5 ms); reduced by loss_finalize
     const float l1s = block_sum(l1, red);
     const float svs = block_sum(sv, red);
-    if (tid == 0) { atomicAdd(&sums[0], l1s); atomicAdd(&sums[1], svs); }
+    if (tid == 0) {
+        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        sums[2 * bid] = l1s; sums[2 * bid + 1] = svs;
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -138,16 +142,22 @@ ssim_pass_b(int H, int W, const float *__restrict__ img, const float *__restrict
     }
 }
 
-__global__ void loss_finalize(const float *__restrict__ sums, float lambda, float inv_n, float *__restrict__ loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0)
-        loss[0] = (1.f - lambda) * (sums[0] * inv_n) + lambda * (1.f - sums[1] * inv_n);
+__global__ void __launch_bounds__(256)
+loss_finalize(const float *__restrict__ sums, uint32_t nblocks, float lambda, float inv_n, float *__restrict__ loss) {
+    __shared__ float red[4];
+    float a = 0.f, b = 0.f;
+    for (uint32_t i = threadIdx.x; i < nblocks; i += 256) { a += sums[2 * i]; b += sums[2 * i + 1]; }
+    const float l1 = block_sum(a, red);
+    const float sv = block_sum(b, red);
+    if (threadIdx.x == 0) loss[0] = (1.f - lambda) * (l1 * inv_n) + lambda * (1.f - sv * inv_n);
 }
 
 }  // namespace
 
 extern "C" int w3d_l1_ssim_sizes(int32_t C, int32_t H, int32_t W, uint64_t *scratch_bytes) {
     if (C <= 0 || H <= 0 || W <= 0) { w3d_set_error("loss: bad sizes"); return W3D_ERR_INVALID; }
-    if (scratch_bytes) *scratch_bytes = 256 + 3 * w3d_align_up((uint64_t)C * H * W * 4);
+    if (scratch_bytes) *scratch_bytes = 3 * w3d_align_up((uint64_t)C * H * W * 4) +
+                                       w3d_align_up((uint64_t)((W + LT - 1) / LT) * ((H + LT - 1) / LT) * C * 8);
     return W3D_OK;
 }
 
@@ -161,20 +171,19 @@ extern "C" int w3d_l1_ssim_fwd_bwd(int32_t C, int32_t H, int32_t W, const float 
     }
     char *sc = static_cast<char *>(scratch);
     const uint64_t plane = w3d_align_up((uint64_t)C * H * W * 4);
-    float *sums = reinterpret_cast<float *>(sc);
-    float *d_mu1 = reinterpret_cast<float *>(sc + 256), *d_ex2 = reinterpret_cast<float *>(sc + 256 + plane),
-          *d_exy = reinterpret_cast<float *>(sc + 256 + 2 * plane);
+    float *d_mu1 = reinterpret_cast<float *>(sc), *d_ex2 = reinterpret_cast<float *>(sc + plane),
+          *d_exy = reinterpret_cast<float *>(sc + 2 * plane);
+    float *sums = reinterpret_cast<float *>(sc + 3 * plane);
     // exact fp32 window of the reference: exp(-(x-5)^2 / (2*1.5^2)) normalised
     GW11 gw;
     float sum = 0.f;
     for (int i = 0; i < 11; i++) { gw.w[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); sum += gw.w[i]; }
     for (int i = 0; i < 11; i++) gw.w[i] /= sum;
-    W3D_HIP_CHECK(hipMemsetAsync(sums, 0, 256, stream));
     const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
     const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
     hipLaunchKernelGGL(ssim_pass_a, grid, dim3(256), 0, stream, H, W, image, gt, d_mu1, d_ex2, d_exy, sums, gw);
     W3D_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(64), 0, stream, sums, lambda_dssim, inv_n, loss_out);
+    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, stream, sums, (uint32_t)(grid.x * grid.y * grid.z), lambda_dssim, inv_n, loss_out);
     hipLaunchKernelGGL(ssim_pass_b, grid, dim3(256), 0, stream, H, W, image, gt, d_mu1, d_ex2, d_exy, lambda_dssim, inv_n,
                        dL_dimage, gw);
     W3D_HIP_CHECK(hipGetLastError());

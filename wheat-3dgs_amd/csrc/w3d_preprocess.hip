@@ -247,9 +247,9 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
     radii[g] = radius;
     keys[g] = key;
     vals[g] = (uint32_t)g;
-    // visible count: one atomic per wave
-    const unsigned long long vis = __ballot(radius > 0);
-    if ((threadIdx.x & 63) == 0 && vis) atomicAdd(&counters[0], (uint32_t)__popcll(vis));
+    // the visible count is NOT accumulated here (31k same-address atomics cost more than the whole
+    // kernel): the depth sort's last pass yields it for free (w3d_binning.hip).
+    (void)counters;
 }
 
 // proj_xy / gs_depth outputs of the FlashSplat variant (zeros for culled Gaussians)
