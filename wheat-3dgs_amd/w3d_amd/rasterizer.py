@@ -188,6 +188,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         color, radii, depth, alpha, saved, _ = _forward_impl(settings, means3D, sh, colors_precomp, opacities,
                                                              scales, rotations, cov3Ds_precomp)
         ctx.saved = saved
+        ctx.set_materialize_grads(False)   # unused depth/alpha outputs arrive as None, not zero images
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
         ctx.opac_shape = tuple(opacities.shape)
         ctx.mark_non_differentiable(radii)
