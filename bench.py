@@ -96,6 +96,23 @@ def workload_stats(model, cam, bg, dev):
                     mean_contrib=float(nc.float().mean()))
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/rNN/pmc_hbm_traffic.csv: FETCH_SIZE x2 + WRITE_SIZE, collected in separate --pmc passes);
+    None when no summary exists.  The counters cannot be read live from inside the process."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm_traffic.csv")))
+    if not files:
+        return None
+    best = None
+    for r in csv.DictReader(open(files[-1])):
+        if kernel in r["kernel"] and "<true>" not in r["kernel"].replace("<true, true>", ""):
+            mib = float(r["hbm_read_MiB_corrected_x2"]) + float(r["hbm_write_MiB"])
+            best = max(best or 0.0, mib)
+    return None if best is None else int(best * 1024 * 1024)
+
+
 def cpu_baseline(args):
     """The oracle (kind "port") timed on this box's host cores on a bounded sample: ONE full
     train-step's rasterizer work (forward + backward of one 1600x1200 view of the 2M scene)."""
@@ -207,7 +224,7 @@ def main():
             avg_ms = ms / cnt
             ach = algo.get(args.profile, 0.0) / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": args.profile, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.profile + "_kernel"),
                     "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
                     "algorithmic_bytes_per_launch": int(algo.get(args.profile, 0.0))}
         if args.all_stages:
