@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--all-stages", action="store_true", help="also print per-stage event times to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-loss", action="store_true", help="use the PyTorch conv2d SSIM instead of the fused kernel")
+    ap.add_argument("--autograd-path", action="store_true",
+                    help="run the drop-in render()+autograd step instead of the fused raw-parameter step")
     return ap.parse_args()
 
 
@@ -157,7 +159,7 @@ def main():
     sc, model, opt, cams = build_scene(args, dev)
     make_ground_truth(args, cams, dev, bg)
     loss_fn = photometric_loss_torch if args.torch_loss else photometric_loss
-    trainer = Trainer(model, cams, opt, bg, densify=False, loss_fn=loss_fn)
+    trainer = Trainer(model, cams, opt, bg, densify=False, loss_fn=loss_fn, fused=False if args.autograd_path else None)
 
     def sync():
         if world > 1:
@@ -241,7 +243,9 @@ def main():
                        "points": P, "image": [args.width, args.height], "views_per_step": world,
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
                        "visible_per_view": int(V), "tile_instances_per_view": int(R), "walked_instances_per_view": int(Rw),
-                       "loss": "torch conv2d" if args.torch_loss else "fused HIP L1+SSIM", "final_loss": round(final_loss, 6)},
+                       "loss": "torch conv2d" if args.torch_loss else "fused HIP L1+SSIM",
+                       "step": "fused raw-parameter kernels (no autograd)" if trainer.fused else "drop-in render() + autograd",
+                       "final_loss": round(final_loss, 6)},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -109,6 +109,41 @@ int w3d_backward(const w3d_view *view, int32_t P, const float *means3D, const fl
                  float *dL_dshs, float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
                  void *scratch, w3d_stream_t stream);
 
+/* ---- next-row N2 (fused activations): the same two calls on the PRE-ACTIVATION parameters exactly as
+ * GaussianModel stores them (reference scene/gaussian_model.py:101-121 applies exp / sigmoid /
+ * F.normalize / cat(dc, rest) on every render call).  The kernels apply the activations and chain
+ * their derivatives, so gradients land directly in the caller's parameter-gradient blocks
+ * (OVERWRITTEN) — no activation kernels, no cat/split, no autograd accumulation. */
+typedef struct w3d_raw_params {
+    const float *xyz;      /* (P,3) */
+    const float *f_dc;     /* (P,1,3) */
+    const float *f_rest;   /* (P,sh_coeffs-1,3) */
+    const float *opacity;  /* (P,1) logits */
+    const float *scaling;  /* (P,3) log-scales */
+    const float *rotation; /* (P,4) un-normalised quaternions */
+} w3d_raw_params;
+typedef struct w3d_raw_grads {
+    float *xyz, *f_dc, *f_rest, *opacity, *scaling, *rotation; /* same shapes as w3d_raw_params */
+} w3d_raw_grads;
+/* Optional by-products of the backward pass that the training loop needs (all nullable):
+ * dL_dmeans2D (P,3); grad2d_norm (P,) = ||dL_dmeans2D[:, :2]|| (0 for culled); and, when
+ * xyz_gradient_accum is given, the in-place updates of add_densification_stats + max_radii2D
+ * (scene/gaussian_model.py:461-463, train_vanilla_3dgs.py:102) for visible Gaussians. */
+typedef struct w3d_densify_stats {
+    float *dL_dmeans2D;
+    float *grad2d_norm;
+    const int32_t *radii;       /* (P,) from the forward */
+    float *xyz_gradient_accum;  /* (P,1) += norm */
+    float *denom;               /* (P,1) += 1   */
+    float *max_radii2D;         /* (P,)  = max(., radii) */
+} w3d_densify_stats;
+int w3d_forward_stage1_raw(const w3d_view *view, int32_t P, const w3d_raw_params *params, int32_t *radii,
+                           void *state, void *scratch, uint32_t *counts_host, w3d_stream_t stream);
+int w3d_backward_raw(const w3d_view *view, int32_t P, const w3d_raw_params *params, const void *state,
+                     const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth,
+                     const float *dL_dalpha, const w3d_raw_grads *grads, const w3d_densify_stats *stats,
+                     void *scratch, w3d_stream_t stream);
+
 /* mean squared distance to the 3 nearest other points; points (N,3) -> out (N,) */
 int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream);
 

@@ -212,7 +212,75 @@ int w3d_backward(const w3d_view *view, int32_t P, const float *means3D, const fl
     if (rc) return rc;
     return w3d_launch_preprocess_backward(L, *view, means3D, shs, colors_precomp, scales, rotations, cov3D_precomp, st,
                                           grad2d, dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dshs, dL_dopacity, dL_dscales,
-                                          dL_drots, dL_dcov3D, stream);
+                                          dL_drots, dL_dcov3D, nullptr, stream);
+}
+
+// ---- raw-parameter path: activations + dc/rest split fused into the kernels
+int w3d_forward_stage1_raw(const w3d_view *view, int32_t P, const w3d_raw_params *prm, int32_t *radii, void *state,
+                           void *scratch, uint32_t *counts_host, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    int rc = check_view(view);
+    if (rc) return rc;
+    W3DLayout L;
+    rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
+    if (rc) { w3d_set_error("bad sizes"); return rc; }
+    if (!state || !scratch) { w3d_set_error("state/scratch is NULL"); return W3D_ERR_INVALID; }
+    if (P > 0) {
+        if (!prm || !prm->xyz || !prm->f_dc || !prm->f_rest || !prm->opacity || !prm->scaling || !prm->rotation || !radii) {
+            w3d_set_error("raw parameter block holds a NULL pointer");
+            return W3D_ERR_INVALID;
+        }
+        if (view->sh_coeffs < 2 || view->sh_coeffs > 16 || view->sh_coeffs < (view->sh_degree + 1) * (view->sh_degree + 1)) {
+            w3d_set_error("raw path needs 2..16 SH coefficients covering the active degree");
+            return W3D_ERR_INVALID;
+        }
+    }
+    char *st = static_cast<char *>(state), *sc = static_cast<char *>(scratch);
+    rc = w3d_launch_preprocess(L, *view, prm ? prm->xyz : nullptr, prm ? prm->f_dc : nullptr, nullptr,
+                               prm ? prm->opacity : nullptr, prm ? prm->scaling : nullptr, prm ? prm->rotation : nullptr,
+                               nullptr, radii, st, sc, prm ? prm->f_rest : nullptr, stream);
+    if (rc) return rc;
+    rc = w3d_launch_sort_and_count(L, *view, st, sc, stream);
+    if (rc) return rc;
+    if (counts_host) {
+        W3D_HIP_CHECK(hipMemcpyAsync(counts_host, st + L.o_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        W3D_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    return W3D_OK;
+}
+
+int w3d_backward_raw(const w3d_view *view, int32_t P, const w3d_raw_params *prm, const void *state,
+                     const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                     const w3d_raw_grads *grads, const w3d_densify_stats *stats, void *scratch, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    int rc = check_view(view);
+    if (rc) return rc;
+    W3DLayout L;
+    rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
+    if (rc) { w3d_set_error("bad sizes"); return rc; }
+    if (P == 0) return W3D_OK;
+    if (!state || !scratch || !dL_dcolor || !prm || !grads || !grads->xyz || !grads->f_dc || !grads->f_rest ||
+        !grads->opacity || !grads->scaling || !grads->rotation) {
+        w3d_set_error("NULL buffer");
+        return W3D_ERR_INVALID;
+    }
+    if (stats && stats->xyz_gradient_accum && (!stats->denom || !stats->max_radii2D || !stats->radii)) {
+        w3d_set_error("fused statistics need accum, denom, max_radii2D and radii together");
+        return W3D_ERR_INVALID;
+    }
+    const char *st = static_cast<const char *>(state);
+    float *grad2d = static_cast<float *>(scratch);
+    rc = w3d_launch_render_backward(L, *view, st, point_list, dL_dcolor, dL_ddepth, dL_dalpha, grad2d, stream);
+    if (rc) return rc;
+    W3DRawBwdArgs ra = {};
+    ra.f_rest = prm->f_rest; ra.opacity_logit = prm->opacity; ra.dL_df_rest = grads->f_rest;
+    if (stats) {
+        ra.gnorm_out = stats->grad2d_norm; ra.radii = stats->radii; ra.accum = stats->xyz_gradient_accum;
+        ra.denom = stats->denom; ra.max_radii = stats->max_radii2D;
+    }
+    return w3d_launch_preprocess_backward(L, *view, prm->xyz, prm->f_dc, nullptr, prm->scaling, prm->rotation, nullptr, st,
+                                          grad2d, grads->xyz, stats ? stats->dL_dmeans2D : nullptr, nullptr, grads->f_dc,
+                                          grads->opacity, grads->scaling, grads->rotation, nullptr, &ra, stream);
 }
 
 int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream_) {

@@ -121,11 +121,19 @@ struct W3DProfScope {
 };
 #define W3D_PROF(name, stream) W3DProfScope w3d_prof_scope_(name, stream)
 
+// extra arguments of the raw-parameter backward (NULL for the activated-parameter API)
+struct W3DRawBwdArgs {
+    const float *f_rest, *opacity_logit;
+    float *dL_df_rest, *gnorm_out;
+    const int32_t *radii;
+    float *accum, *denom, *max_radii;
+};
+
 // kernels' host launchers (one per .hip file)
 int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,
                           const float *colors_precomp, const float *opacities, const float *scales,
                           const float *rotations, const float *cov3D_precomp, int32_t *radii, char *state,
-                          char *scratch, float *proj_xy_unused, hipStream_t stream);
+                          char *scratch, const float *f_rest_raw, hipStream_t stream);
 int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream);
 int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
                           uint64_t list_capacity, hipStream_t stream);
@@ -142,7 +150,7 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
                                    const float *cov3D_precomp, const char *state, const float *grad2d,
                                    float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors, float *dL_dshs,
                                    float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
-                                   hipStream_t stream);
+                                   const struct W3DRawBwdArgs *rawargs, hipStream_t stream);
 int w3d_launch_knn(int32_t N, const float *points, float *out, hipStream_t stream);
 
 // per-Gaussian 2-D gradient record accumulated by the blend backward (16 floats = one 64-B line)

@@ -121,28 +121,48 @@ __device__ __forceinline__ void xform4x4(const float *m, const float *p, float *
     o[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
 }
 
-// SH -> RGB (+0.5, clamp at 0).  sh points at this Gaussian's (M,3) block.
-__device__ __forceinline__ void sh_to_rgb(int deg, const float *__restrict__ sh, const float *pos, const float *campos,
+// 4-byte-aligned 16-byte vector (gfx950 handles unaligned dwordx4 global accesses)
+struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
+
+// Loads the active SH coefficients of one Gaussian into c[3k + ch].
+//   interleaved layout: sh -> this Gaussian's (M,3) block (reference get_features layout);
+//   split layout (raw path): dc -> (1,3) block, rest -> ((M-1),3) block, as GaussianModel stores them.
+__device__ __forceinline__ void load_sh(int deg, const float *__restrict__ sh, const float *__restrict__ dc,
+                                        const float *__restrict__ rest, float *c) {
+    const int ncoef = (deg + 1) * (deg + 1);
+    if (sh) {
+        const int nvec = (ncoef * 3 + 3) / 4;
+        if ((reinterpret_cast<uintptr_t>(sh) & 15) == 0) {
+            const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
+#pragma unroll
+            for (int i = 0; i < 12; i++)
+                if (i < nvec) { float4 t = sh4[i]; c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 48; i++)
+                if (i < ncoef * 3) c[i] = sh[i];
+        }
+    } else {
+        c[0] = dc[0]; c[1] = dc[1]; c[2] = dc[2];
+        const int nrest = (ncoef - 1) * 3;            // 0, 9, 24 or 45 floats
+        const F4U *r4 = reinterpret_cast<const F4U *>(rest);
+#pragma unroll
+        for (int i = 0; i < 11; i++)
+            if (4 * i + 3 < nrest) { F4U t = r4[i]; c[3 + 4 * i] = t.x; c[4 + 4 * i] = t.y; c[5 + 4 * i] = t.z; c[6 + 4 * i] = t.w; }
+#pragma unroll
+        for (int i = 0; i < 45; i++)
+            if (i >= (nrest & ~3) && i < nrest) c[3 + i] = rest[i];
+    }
+}
+
+// SH -> RGB (+0.5, clamp at 0) from preloaded coefficients c[3k + ch].
+__device__ __forceinline__ void sh_to_rgb(int deg, const float *c, const float *pos, const float *campos,
                                           float *rgb, uint32_t &clamped) {
 #pragma clang fp contract(off)
     float d0 = pos[0] - campos[0], d1 = pos[1] - campos[1], d2 = pos[2] - campos[2];
     float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
     float x = d0 / len, y = d1 / len, z = d2 / len;
     float r[3];
-    // coefficient k, channel ch lives at sh[3k + ch]; 16-B vector loads when the block is aligned
-    const float4 *sh4 = reinterpret_cast<const float4 *>(sh);
-    float c[48];
-    const int ncoef = (deg + 1) * (deg + 1);
-    const int nvec = (ncoef * 3 + 3) / 4;
-    if ((reinterpret_cast<uintptr_t>(sh) & 15) == 0) {
-#pragma unroll
-        for (int i = 0; i < 12; i++)
-            if (i < nvec) { float4 t = sh4[i]; c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 48; i++)
-            if (i < ncoef * 3) c[i] = sh[i];
-    }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
 #define SH(k) c[(k)*3 + ch]
@@ -171,9 +191,21 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float *__restrict__ sh,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Activations of the raw (pre-activation) parameter path — what GaussianModel's getters apply
+// (reference scene/gaussian_model.py:33-41,101-121): exp, sigmoid, F.normalize.
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ void act_normalize(const float *r, float *q, float &inv_norm) {
+    const float n = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    inv_norm = 1.0f / fmaxf(n, 1e-12f);
+    q[0] = r[0] * inv_norm; q[1] = r[1] * inv_norm; q[2] = r[2] * inv_norm; q[3] = r[3] * inv_norm;
+}
+
+// RAW: `shs` is f_dc (P,1,3), `f_rest` is (P,M-1,3), opacities are logits, scales are log-scales,
+// rotations are un-normalised quaternions; the activations are applied here.
+template <bool RAW>
 __global__ void __launch_bounds__(256)
 preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict__ means3D,
-                      const float *__restrict__ shs, const float *__restrict__ colors_precomp,
+                      const float *__restrict__ shs, const float *__restrict__ f_rest, const float *__restrict__ colors_precomp,
                       const float *__restrict__ opacities, const float *__restrict__ scales,
                       const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
                       int32_t *__restrict__ radii, float2 *__restrict__ xy, float4 *__restrict__ conic_op,
@@ -203,6 +235,12 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
             float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
             const float4 q4 = reinterpret_cast<const float4 *>(rotations)[g];
             float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            if (RAW) {
+                s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+                float inv_n;
+                const float r[4] = {q[0], q[1], q[2], q[3]};
+                act_normalize(r, q, inv_n);
+            }
             cov3d_from_scale_rot(s, v.scale_modifier, q, c3);
         }
         Geo geo;
@@ -234,12 +272,15 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
         if (colors_precomp) {
             rgb[0] = colors_precomp[3 * (size_t)g]; rgb[1] = colors_precomp[3 * (size_t)g + 1]; rgb[2] = colors_precomp[3 * (size_t)g + 2];
         } else {
-            sh_to_rgb(v.sh_degree, shs + (size_t)g * v.sh_coeffs * 3, p, cam.campos, rgb, cl);
+            float c[48];
+            if (RAW) load_sh(v.sh_degree, nullptr, shs + 3 * (size_t)g, f_rest + (size_t)g * (v.sh_coeffs - 1) * 3, c);
+            else load_sh(v.sh_degree, shs + (size_t)g * v.sh_coeffs * 3, nullptr, nullptr, c);
+            sh_to_rgb(v.sh_degree, c, p, cam.campos, rgb, cl);
         }
         radius = r;
         key = __float_as_uint(pv[2]);
         xy[g] = make_float2(px, py);
-        conic_op[g] = make_float4(conx, cony, conz, opacities[g]);
+        conic_op[g] = make_float4(conx, cony, conz, RAW ? act_sigmoid(opacities[g]) : opacities[g]);
         rgbd[g] = make_float4(rgb[0], rgb[1], rgb[2], pv[2]);
         rect[g] = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
         clamped_out[g] = (uint8_t)cl;
@@ -272,19 +313,33 @@ __global__ void flash_extras_kernel(int P, const uint32_t *__restrict__ keys_unu
 // ---------------------------------------------------------------------------------------------
 // Backward of the per-Gaussian stages (Appendix A.5).  visible <=> the forward wrote a record,
 // flagged by rect having a non-empty area (rect is zero-initialised per call for culled ones).
-template <bool HAS_SH, bool HAS_SCALE_ROT>
+// Extra pointers of the raw (pre-activation) path; all NULL otherwise.
+struct RawBwd {
+    const float *f_rest;       // (P, M-1, 3)
+    const float *opacity_logit;  // (P,)
+    float *dL_df_rest;         // (P, M-1, 3)
+    float *gnorm_out;          // (P,) ||dL/dmean2D.xy|| (0 for culled), nullable
+    const int32_t *radii;      // (P,) for the fused statistics, nullable
+    float *accum, *denom, *max_radii;   // densification statistics updated in place, nullable
+};
+
+// RAW: shs/dL_dshs are the f_dc blocks, scales/rotations/opacity are pre-activation and the
+// gradients are chained through exp / normalize / sigmoid before being written.
+template <bool HAS_SH, bool HAS_SCALE_ROT, bool RAW>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
                       const float *__restrict__ scales, const float *__restrict__ rotations,
-                      const float *__restrict__ cov3D_precomp, const int32_t *__restrict__ visible_radii_unused,
+                      const float *__restrict__ cov3D_precomp, RawBwd raw,
                       const ushort4 *__restrict__ rect, const uint8_t *__restrict__ clamped,
-                      const uint32_t *__restrict__ keys_unused, const float *__restrict__ grad2d,
+                      const float *__restrict__ grad2d,
                       float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dcolors,
                       float *__restrict__ dL_dshs, float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
                       float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= P) return;
     const int Mc = v.sh_coeffs;
+    float inv_qnorm = 1.f;
+    float q_act[4] = {1.f, 0.f, 0.f, 0.f}, s_act[3] = {0.f, 0.f, 0.f};
     const ushort4 rc = rect[g];
     const bool vis = ((int)rc.z - (int)rc.x) * ((int)rc.w - (int)rc.y) > 0;
     float dmean[3] = {0.f, 0.f, 0.f};
@@ -293,10 +348,18 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     float dcol[3] = {0.f, 0.f, 0.f};
-    float *dsh = HAS_SH ? dL_dshs + (size_t)g * Mc * 3 : nullptr;
+    // coefficient k, channel c of the SH gradient: interleaved (P,M,3) or split dc | rest blocks
+    float *dsh = HAS_SH ? (RAW ? dL_dshs + 3 * (size_t)g : dL_dshs + (size_t)g * Mc * 3) : nullptr;
+    float *dsh_rest = (HAS_SH && RAW) ? raw.dL_df_rest + (size_t)g * (Mc - 1) * 3 : nullptr;
+#define DSH(k, c) (*((RAW && (k) > 0) ? (dsh_rest + 3 * ((k)-1) + (c)) : (dsh + 3 * (k) + (c))))
     if (!vis) {
         if (HAS_SH) {
-            for (int i = 0; i < Mc * 3; i++) dsh[i] = 0.f;
+            if (RAW) {
+                dsh[0] = dsh[1] = dsh[2] = 0.f;
+                for (int i = 0; i < (Mc - 1) * 3; i++) dsh_rest[i] = 0.f;
+            } else {
+                for (int i = 0; i < Mc * 3; i++) dsh[i] = 0.f;
+            }
         }
     } else {
         Cam cam;
@@ -317,6 +380,13 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
             s[0] = scales[3 * (size_t)g]; s[1] = scales[3 * (size_t)g + 1]; s[2] = scales[3 * (size_t)g + 2];
             const float4 q4 = reinterpret_cast<const float4 *>(rotations)[g];
             q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+            if (RAW) {
+                s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+                const float r4[4] = {q[0], q[1], q[2], q[3]};
+                act_normalize(r4, q, inv_qnorm);
+                s_act[0] = s[0]; s_act[1] = s[1]; s_act[2] = s[2];
+                q_act[0] = q[0]; q_act[1] = q[1]; q_act[2] = q[2]; q_act[3] = q[3];
+            }
             cov3d_from_scale_rot(s, v.scale_modifier, q, c3);
         } else {
 #pragma unroll
@@ -379,7 +449,9 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
         // (iv) colour
         if (HAS_SH) {
             const int deg = v.sh_degree;
-            const float *sh = shs + (size_t)g * Mc * 3;
+            float sh[48];
+            if (RAW) load_sh(deg, nullptr, shs + 3 * (size_t)g, raw.f_rest + (size_t)g * (Mc - 1) * 3, sh);
+            else load_sh(deg, shs + (size_t)g * Mc * 3, nullptr, nullptr, sh);
             const uint32_t cl = clamped[g];
             const float dRGB[3] = {(cl & 1u) ? 0.f : dcol[0], (cl & 2u) ? 0.f : dcol[1], (cl & 4u) ? 0.f : dcol[2]};
             const float d0 = p[0] - cam.campos[0], d1 = p[1] - cam.campos[1], d2 = p[2] - cam.campos[2];
@@ -401,10 +473,10 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
             for (int k = 0; k < 16; k++) {   // static indices keep B[] in registers
                 if (k < Mc) {
                     const float b = (k < ncoef) ? B[k] : 0.f;
-                    dsh[3 * k + 0] = b * dRGB[0]; dsh[3 * k + 1] = b * dRGB[1]; dsh[3 * k + 2] = b * dRGB[2];
+                    DSH(k, 0) = b * dRGB[0]; DSH(k, 1) = b * dRGB[1]; DSH(k, 2) = b * dRGB[2];
                 }
             }
-            for (int k = 16; k < Mc; k++) { dsh[3 * k + 0] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+            for (int k = 16; k < Mc; k++) { DSH(k, 0) = 0.f; DSH(k, 1) = 0.f; DSH(k, 2) = 0.f; }
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
 #define SH(k) sh[(k)*3 + ch]
@@ -469,8 +541,29 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
             drot[3] = 2.f * (-2.f * z * GR[0][0] - r * GR[0][1] + x * GR[0][2] + r * GR[1][0] - 2.f * z * GR[1][1] + y * GR[1][2] + x * GR[2][0] + y * GR[2][1]);
         }
     }
+#undef DSH
+    if (RAW) {
+        // chain through the activations: s = exp(ls), o = sigmoid(lo), q = r / |r|
+        dscale[0] *= s_act[0]; dscale[1] *= s_act[1]; dscale[2] *= s_act[2];
+        if (vis) {
+            const float o = act_sigmoid(raw.opacity_logit[g]);
+            dop *= o * (1.f - o);
+        }
+        const float qd = q_act[0] * drot[0] + q_act[1] * drot[1] + q_act[2] * drot[2] + q_act[3] * drot[3];
+#pragma unroll
+        for (int i = 0; i < 4; i++) drot[i] = (drot[i] - q_act[i] * qd) * inv_qnorm;
+        const float gn = sqrtf(dm2[0] * dm2[0] + dm2[1] * dm2[1]);
+        if (raw.gnorm_out) raw.gnorm_out[g] = vis ? gn : 0.f;
+        if (raw.accum && vis) {
+            // add_densification_stats + max_radii2D update (scene/gaussian_model.py:461-463,
+            // train_vanilla_3dgs.py:102) fused for the single-GPU step
+            raw.accum[g] += gn;
+            raw.denom[g] += 1.f;
+            raw.max_radii[g] = fmaxf(raw.max_radii[g], (float)raw.radii[g]);
+        }
+    }
     dL_dmeans3D[3 * (size_t)g] = dmean[0]; dL_dmeans3D[3 * (size_t)g + 1] = dmean[1]; dL_dmeans3D[3 * (size_t)g + 2] = dmean[2];
-    dL_dmeans2D[3 * (size_t)g] = dm2[0]; dL_dmeans2D[3 * (size_t)g + 1] = dm2[1]; dL_dmeans2D[3 * (size_t)g + 2] = 0.f;
+    if (dL_dmeans2D) { dL_dmeans2D[3 * (size_t)g] = dm2[0]; dL_dmeans2D[3 * (size_t)g + 1] = dm2[1]; dL_dmeans2D[3 * (size_t)g + 2] = 0.f; }
     dL_dopacity[g] = dop;
     if (!HAS_SH && dL_dcolors) {
         dL_dcolors[3 * (size_t)g] = dcol[0]; dL_dcolors[3 * (size_t)g + 1] = dcol[1]; dL_dcolors[3 * (size_t)g + 2] = dcol[2];
@@ -490,19 +583,22 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
 int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,
                           const float *colors_precomp, const float *opacities, const float *scales,
                           const float *rotations, const float *cov3D_precomp, int32_t *radii, char *state,
-                          char *scratch, float *, hipStream_t stream) {
+                          char *scratch, const float *f_rest_raw, hipStream_t stream) {
     // counters and the rect array start at zero each call (rect == 0 marks a culled Gaussian)
     W3D_HIP_CHECK(hipMemsetAsync(state + L.o_counters, 0, 64, stream));
     W3D_HIP_CHECK(hipMemsetAsync(state + L.o_rect, 0, (size_t)(L.P > 0 ? L.P : 1) * 8, stream));
     if (L.P == 0) return W3D_OK;
     const int block = 256, grid = (L.P + block - 1) / block;
     W3D_PROF("preprocess_fwd", stream);
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(grid), dim3(block), 0, stream, v, L.P, L.gx, L.gy, means3D, shs,
-                       colors_precomp, opacities, scales, rotations, cov3D_precomp, radii,
-                       reinterpret_cast<float2 *>(state + L.o_xy), reinterpret_cast<float4 *>(state + L.o_conic_op),
-                       reinterpret_cast<float4 *>(state + L.o_rgbd), reinterpret_cast<ushort4 *>(state + L.o_rect),
-                       reinterpret_cast<uint8_t *>(state + L.o_clamped), reinterpret_cast<uint32_t *>(scratch + L.s_keys0),
-                       reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(state + L.o_counters));
+#define ARGS                                                                                                          \
+    v, L.P, L.gx, L.gy, means3D, shs, f_rest_raw, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, \
+        reinterpret_cast<float2 *>(state + L.o_xy), reinterpret_cast<float4 *>(state + L.o_conic_op),                \
+        reinterpret_cast<float4 *>(state + L.o_rgbd), reinterpret_cast<ushort4 *>(state + L.o_rect),                 \
+        reinterpret_cast<uint8_t *>(state + L.o_clamped), reinterpret_cast<uint32_t *>(scratch + L.s_keys0),         \
+        reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(state + L.o_counters)
+    if (f_rest_raw) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(grid), dim3(block), 0, stream, ARGS);
+    else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(grid), dim3(block), 0, stream, ARGS);
+#undef ARGS
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;
 }
@@ -523,22 +619,28 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
                                    const float *cov3D_precomp, const char *state, const float *grad2d,
                                    float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors, float *dL_dshs,
                                    float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
-                                   hipStream_t stream) {
+                                   const W3DRawBwdArgs *rawargs, hipStream_t stream) {
     if (L.P == 0) return W3D_OK;
     const int block = 256, grid = (L.P + block - 1) / block;
     const bool has_sh = (shs != nullptr), has_sr = (scales != nullptr);
     (void)colors_precomp;
-#define LAUNCH(A, B)                                                                                                  \
-    hipLaunchKernelGGL((preprocess_bwd_kernel<A, B>), dim3(grid), dim3(block), 0, stream, v, L.P, means3D, shs, scales, \
-                       rotations, cov3D_precomp, (const int32_t *)nullptr,                                            \
-                       reinterpret_cast<const ushort4 *>(state + L.o_rect),                                           \
-                       reinterpret_cast<const uint8_t *>(state + L.o_clamped), (const uint32_t *)nullptr, grad2d,     \
-                       dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
+    RawBwd raw = {};
+    if (rawargs) {
+        raw.f_rest = rawargs->f_rest; raw.opacity_logit = rawargs->opacity_logit; raw.dL_df_rest = rawargs->dL_df_rest;
+        raw.gnorm_out = rawargs->gnorm_out; raw.radii = rawargs->radii; raw.accum = rawargs->accum;
+        raw.denom = rawargs->denom; raw.max_radii = rawargs->max_radii;
+    }
+#define LAUNCH(A, B, C)                                                                                                  \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<A, B, C>), dim3(grid), dim3(block), 0, stream, v, L.P, means3D, shs, scales, \
+                       rotations, cov3D_precomp, raw, reinterpret_cast<const ushort4 *>(state + L.o_rect),               \
+                       reinterpret_cast<const uint8_t *>(state + L.o_clamped), grad2d, dL_dmeans3D, dL_dmeans2D,         \
+                       dL_dcolors, dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
     W3D_PROF("preprocess_bwd", stream);
-    if (has_sh && has_sr) LAUNCH(true, true);
-    else if (has_sh) LAUNCH(true, false);
-    else if (has_sr) LAUNCH(false, true);
-    else LAUNCH(false, false);
+    if (rawargs) LAUNCH(true, true, true);
+    else if (has_sh && has_sr) LAUNCH(true, true, false);
+    else if (has_sh) LAUNCH(true, false, false);
+    else if (has_sr) LAUNCH(false, true, false);
+    else LAUNCH(false, false, false);
 #undef LAUNCH
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;

@@ -37,13 +37,19 @@ def dist_info():
 
 class Trainer:
     def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
-                 densify=True, loss_fn=photometric_loss):
+                 densify=True, loss_fn=photometric_loss, fused=None):
         self.model, self.cameras, self.opt = model, cameras, opt
         self.bg = background
         self.pipe = pipe or PipelineParams()
         self.extent = cameras_extent
         self.densify = densify
         self.loss_fn = loss_fn
+        # fused=None: use the fused raw-parameter step whenever the model lives on the GPU, the
+        # default pipeline flags are in force and the loss is the standard photometric one
+        if fused is None:
+            fused = bool(model.flat.is_cuda and loss_fn is photometric_loss and
+                         not self.pipe.convert_SHs_python and not self.pipe.compute_cov3D_python)
+        self.fused = fused
         self.rank, self.world = dist_info()
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.perm = torch.randperm(len(cameras), generator=g).tolist()
@@ -68,7 +74,61 @@ class Trainer:
             return stats[0], stats[1], r
         return grad2d_norm * visible, visible.to(grad2d_norm.dtype), radii
 
+    def _post_backward(self, iteration, nsum, vcount, rmax, stats_done):
+        """Densification bookkeeping + optimizer step shared by both step flavours."""
+        m, opt = self.model, self.opt
+        # the reference replaces nn.Parameters on densify / opacity reset, so their .grad is None
+        # and torch's Adam skips them in that iteration's step; `skip` reproduces that.
+        skip = set()
+        if iteration < opt.densify_until_iter:
+            if not stats_done:
+                m.max_radii2D = torch.max(m.max_radii2D, rmax.to(m.max_radii2D.dtype))
+                m.xyz_gradient_accum += nsum[:, None]
+                m.denom += vcount[:, None]
+            if self.densify:
+                if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+                    size_threshold = 20 if iteration > opt.opacity_reset_interval else None
+                    torch.manual_seed(1234 + iteration)     # identical split samples on every rank
+                    m.densify_and_prune(opt.densify_grad_threshold, 0.005, self.extent, size_threshold)
+                    skip = {"xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"}
+                if iteration % opt.opacity_reset_interval == 0:
+                    m.reset_opacity()
+                    skip.add("opacity")
+        return skip
+
+    def step_fused(self, iteration):
+        """The same step with everything between the parameter buffers and the image fused into
+        the HIP kernels (fused_step.py): raw-parameter forward, fused loss value+gradient,
+        raw-parameter backward writing the flat gradient bucket and — on one GPU — the
+        densification statistics.  No autograd graph is built."""
+        from .fused import l1_ssim_fwd_bwd
+        from .fused_step import backward_raw, render_raw
+        m, opt = self.model, self.opt
+        m.update_learning_rate(iteration)
+        if iteration % 1000 == 0:
+            m.oneupSHdegree()
+        cam = self.camera_for(iteration)
+        with torch.no_grad():
+            pkg = render_raw(cam, m, self.bg)
+            loss, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
+            tracking = iteration < opt.densify_until_iter
+            single = self.world == 1
+            gnorm, _ = backward_raw(m, pkg["handle"], dimg, update_stats=(tracking and single), want_norm=not single)
+            if not single:
+                vis = pkg["radii"] > 0
+                nsum, vcount, rmax = self.exchange(gnorm, vis, pkg["radii"])
+            else:
+                nsum = vcount = rmax = None
+            skip = self._post_backward(iteration, nsum, vcount, rmax, stats_done=single)
+            if iteration < opt.iterations:
+                # the next backward overwrites the whole bucket: no zeroing pass needed
+                m.optimizer.step(zero_grad=bool(skip), skip=skip)
+        self.last = dict(loss=loss, image=pkg["render"], radii=pkg["radii"])
+        return loss
+
     def step(self, iteration):
+        if self.fused:
+            return self.step_fused(iteration)
         m, opt = self.model, self.opt
         m.update_learning_rate(iteration)
         if iteration % 1000 == 0:
@@ -82,22 +142,7 @@ class Trainer:
             vis, radii = pkg["visibility_filter"], pkg["radii"]
             gnorm = pkg["viewspace_points"].grad[:, :2].norm(dim=-1)
             nsum, vcount, rmax = self.exchange(gnorm, vis, radii)
-            # the reference replaces nn.Parameters on densify / opacity reset, so their .grad is None
-            # and torch's Adam skips them in that iteration's step; `skip` reproduces that.
-            skip = set()
-            if iteration < opt.densify_until_iter:
-                m.max_radii2D = torch.max(m.max_radii2D, rmax.to(m.max_radii2D.dtype))
-                m.xyz_gradient_accum += nsum[:, None]
-                m.denom += vcount[:, None]
-                if self.densify:
-                    if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
-                        size_threshold = 20 if iteration > opt.opacity_reset_interval else None
-                        torch.manual_seed(1234 + iteration)     # identical split samples on every rank
-                        m.densify_and_prune(opt.densify_grad_threshold, 0.005, self.extent, size_threshold)
-                        skip = {"xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"}
-                    if iteration % opt.opacity_reset_interval == 0:
-                        m.reset_opacity()
-                        skip.add("opacity")
+            skip = self._post_backward(iteration, nsum, vcount, rmax, stats_done=False)
             if iteration < opt.iterations:
                 m.optimizer.step(zero_grad=True, skip=skip)
         self.last = dict(loss=loss.detach(), num_rendered=None, image=image.detach())
