@@ -35,9 +35,11 @@ def _settings(cam, bg, sh_degree, scale_modifier, dev, flash=None):
     return FlashSplatRasterizationSettings(**kw, mask_grad=False, num_obj=flash)
 
 
-def run_hip(d, cam, bg, sh_degree=3, scale_modifier=1.0, grads=None):
+def run_hip(d, cam, bg, sh_degree=3, scale_modifier=1.0, grads=None, tile_cull=True):
     """forward (+ backward with the given image gradients) on cuda:0 through the drop-in module."""
     from diff_gaussian_rasterization import GaussianRasterizer
+    import w3d_amd.rasterizer as wr
+    wr.TILE_CULL = tile_cull
     dev = torch.device("cuda:0")
     t = {k: (None if v is None else v.to(dev).requires_grad_(True)) for k, v in d.items()}
     means2D = torch.zeros_like(t["means3D"], requires_grad=True)
@@ -84,11 +86,40 @@ def check_images(out, ref, tag=""):
 
 
 def check_integers(out, o, ref):
+    """tile_cull off: radii, per-tile ranges and depth-ordered lists are bit-identical to the oracle's."""
     np.testing.assert_array_equal(out["radii"], ref["radii"])
     ranges, pl = o.binning()
     assert out["num_rendered"] == o.num_rendered()
     np.testing.assert_array_equal(out["ranges"], ranges)
     np.testing.assert_array_equal(out["point_list"], pl)
+
+
+def check_culled_lists(out, o, ref, W, H):
+    """tile_cull on: every per-tile list is a SUBSEQUENCE of the oracle's (order preserved) and every
+    dropped (Gaussian, tile) instance has alpha < 1/255 on all pixels of the tile under the oracle's own
+    formula — i.e. it could not have contributed."""
+    np.testing.assert_array_equal(out["radii"], ref["radii"])
+    ranges, pl = o.binning()
+    g = o.geom()
+    gx = (W + 15) // 16
+    dropped = 0
+    for t, ((b, e), (cb, ce)) in enumerate(zip(ranges, out["ranges"])):
+        full, kept = pl[b:e], out["point_list"][cb:ce]
+        it = iter(full.tolist())
+        assert all(any(k == f for f in it) for k in kept.tolist()), f"tile {t}: culled list is not a subsequence"
+        gone = np.setdiff1d(full, kept)
+        if gone.size == 0:
+            continue
+        dropped += gone.size
+        x0, y0 = (t % gx) * 16, (t // gx) * 16
+        ys, xs = np.mgrid[y0:min(y0 + 16, H), x0:min(x0 + 16, W)]
+        dx = g["xy"][gone, 0][:, None, None] - xs[None].astype(np.float32)
+        dy = g["xy"][gone, 1][:, None, None] - ys[None].astype(np.float32)
+        co = g["conic_opacity"][gone]
+        power = -0.5 * (co[:, 0, None, None] * dx * dx + co[:, 2, None, None] * dy * dy) - co[:, 1, None, None] * dx * dy
+        alpha = np.where(power > 0, 0.0, co[:, 3, None, None] * np.exp(np.minimum(power, 0.0)))
+        assert alpha.max() < 1.0 / 255.0, f"tile {t}: a dropped instance reaches alpha {alpha.max():.5f}"
+    return dropped
 
 
 def check_grads(g, gref, vis, tag="", tol=1e-4):
@@ -134,17 +165,21 @@ def test_forward_backward_parity(P, W, H, deg, pc, pcov, bg, mod, da):
         o = make_oracle(cam, bg, sh_degree=deg, scale_modifier=mod)
         ref = o.forward(**np_inputs(d))
         gref = o.backward(gc, gd, ga)
-        out, g = run_hip(d, cam, bg, sh_degree=deg, scale_modifier=mod, grads=(gc, gd, ga))
-        tag = f"[P={P} {W}x{H} deg={deg} cam={ci}] "
-        check_integers(out, o, ref)
-        check_images(out, ref, tag)
         vis = ref["radii"] > 0
         assert vis.sum() > 0.5 * P
-        check_grads(g, gref, vis, tag)
-        # state kept for backward
         ft, nc = o.pixel_state()
-        assert (out["n_contrib"] != nc).mean() <= 2e-3
-        assert np.abs(out["final_T"] - ft).max() <= 2e-2
+        for cull in (False, True):
+            out, g = run_hip(d, cam, bg, sh_degree=deg, scale_modifier=mod, grads=(gc, gd, ga), tile_cull=cull)
+            tag = f"[P={P} {W}x{H} deg={deg} cam={ci} cull={cull}] "
+            if cull:
+                dropped = check_culled_lists(out, o, ref, W, H)
+                assert dropped > 0.1 * o.num_rendered(), "culling removed suspiciously little"
+            else:
+                check_integers(out, o, ref)
+                assert (out["n_contrib"] != nc).mean() <= 2e-3       # state kept for backward
+            check_images(out, ref, tag)
+            check_grads(g, gref, vis, tag)
+            assert np.abs(out["final_T"] - ft).max() <= 2e-2
         o.free()
 
 
@@ -153,8 +188,8 @@ def test_python_branches_agree():
     (gaussian_renderer/__init__.py:66-84); so must we, bit for bit on the integer outputs."""
     sc, cams = small_test_scene(P=400, W=96, H=64, seed=3)
     cam, bg = cams[1], (0.0, 0.0, 0.0)
-    a, _ = run_hip(view_inputs(sc, cam), cam, bg)
-    b, _ = run_hip(view_inputs(sc, cam, precomp_color=True, precomp_cov=True), cam, bg)
+    a, _ = run_hip(view_inputs(sc, cam), cam, bg, tile_cull=False)
+    b, _ = run_hip(view_inputs(sc, cam, precomp_color=True, precomp_cov=True), cam, bg, tile_cull=False)
     np.testing.assert_array_equal(a["radii"], b["radii"])
     np.testing.assert_array_equal(a["point_list"], b["point_list"])
     assert np.abs(a["color"] - b["color"]).max() <= 1e-5
@@ -189,10 +224,12 @@ def test_edge_cases():
     d1["opacities"][0] = 0.9
     o = make_oracle(cam, bg)
     ref = o.forward(**np_inputs(d1))
-    out, _ = run_hip(d1, cam, bg)
+    out, _ = run_hip(d1, cam, bg, tile_cull=False)
     check_integers(out, o, ref)
     check_images(out, ref, "[huge] ")
     assert out["num_rendered"] == 4 * 3
+    out, _ = run_hip(d1, cam, bg, tile_cull=True)
+    check_images(out, ref, "[huge, culled] ")
     # (d) error behaviour of the boundary
     with pytest.raises(Exception):
         rast(means3D=z(4, 3), means2D=z(4, 3), shs=z(4, 16, 3), colors_precomp=z(4, 3), opacities=z(4, 1),
@@ -215,9 +252,12 @@ def test_duplicate_gaussians_tie_order():
     d = {k: (None if v is None else torch.cat([v, v[:60]], 0).contiguous()) for k, v in d.items()}
     o = make_oracle(cam, bg)
     ref = o.forward(**np_inputs(d))
-    out, _ = run_hip(d, cam, bg)
+    out, _ = run_hip(d, cam, bg, tile_cull=False)
     check_integers(out, o, ref)
     check_images(out, ref, "[dups] ")
+    out, _ = run_hip(d, cam, bg, tile_cull=True)
+    check_culled_lists(out, o, ref, 64, 48)
+    check_images(out, ref, "[dups, culled] ")
 
 
 @pytest.mark.parametrize("num_obj", [1, 5])

@@ -31,7 +31,7 @@ radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items,
     __shared__ uint32_t h_all[4][256];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
-    volatile uint32_t *h = h_all[wv];
+    uint32_t *h = h_all[wv];
     for (int i = lane; i < 256; i += 64) h[i] = 0;
     __builtin_amdgcn_wave_barrier();
     if (run < n_runs) {
@@ -101,7 +101,7 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
     if (run >= n_runs) return;
-    volatile uint32_t *cur = cur_all[wv];
+    uint32_t *cur = cur_all[wv];
     {
         // digit bases = exclusive scan of the 256 row totals, 4 digits per lane
         const uint4 t4 = reinterpret_cast<const uint4 *>(rowtot)[lane];
@@ -152,9 +152,10 @@ __device__ __forceinline__ void divmod_small(uint32_t k, uint32_t w, float inv_w
 
 // One wave per depth-contiguous chunk.  MODE 0: count (u16 LDS counters, dumps the row of the
 // count matrix).  MODE 1: fill (u32 LDS cursors initialised from the offset matrix; writes list).
-template <int MODE>
+template <int MODE, bool CULL>
 __global__ void __launch_bounds__(256)
-chunk_walk_kernel(const uint32_t *__restrict__ sorted_ids, const uint2 *__restrict__ rect, const uint32_t *__restrict__ counters,
+chunk_walk_kernel(const uint32_t *__restrict__ sorted_ids, const uint2 *__restrict__ rect,
+                  const uint2 *__restrict__ tile_mask, const uint32_t *__restrict__ counters,
                   uint32_t chunk, uint32_t C, uint32_t T, uint32_t gx, uint32_t waves_per_block,
                   uint16_t *__restrict__ cnt, const uint32_t *__restrict__ off, uint32_t *__restrict__ point_list,
                   uint64_t capacity) {
@@ -165,8 +166,11 @@ chunk_walk_kernel(const uint32_t *__restrict__ sorted_ids, const uint2 *__restri
     if (c >= C) return;
     const uint32_t V = counters[0];
     const uint32_t Tpad = (T + 63u) & ~63u;
-    volatile uint16_t *h16 = reinterpret_cast<volatile uint16_t *>(smem) + (size_t)wv * Tpad;
-    volatile uint32_t *h32 = reinterpret_cast<volatile uint32_t *>(smem) + (size_t)wv * Tpad;
+    // plain (non-volatile) LDS accesses: a wave's LDS operations complete in issue order, and the compiler
+    // keeps may-alias loads/stores in program order; `volatile` would make the backend drain vmcnt/lgkmcnt
+    // around every access and serialise the loop on the latency of the previous list store.
+    uint16_t *h16 = reinterpret_cast<uint16_t *>(smem) + (size_t)wv * Tpad;
+    uint32_t *h32 = reinterpret_cast<uint32_t *>(smem) + (size_t)wv * Tpad;
     if (MODE == 0) {
         for (uint32_t t = lane; t < Tpad; t += 64) h16[t] = 0;
     } else {
@@ -179,22 +183,34 @@ chunk_walk_kernel(const uint32_t *__restrict__ sorted_ids, const uint2 *__restri
         const uint32_t nb = min(64u, s_end - base);
         uint32_t my_g = 0;
         uint2 my_rc = make_uint2(0u, 0u);
+        uint2 my_mask = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
         if (lane < nb) {
             my_g = sorted_ids[base + lane];
             my_rc = rect[my_g];
+            if (CULL) my_mask = tile_mask[my_g];   // bit k: k-th tile of the rect (row-major) can be reached
         }
+        // make the batch loads land HERE: otherwise the wait sits inside the j loop as vmcnt(0) and every
+        // iteration also waits for the previous iteration's list stores
+        asm volatile("" : "+v"(my_g), "+v"(my_rc.x), "+v"(my_rc.y), "+v"(my_mask.x), "+v"(my_mask.y));
         for (uint32_t j = 0; j < nb; j++) {
             const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)j);
             const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)my_rc.x, (int)j);
             const uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)my_rc.y, (int)j);
+            uint64_t mask = ~0ull;
+            if (CULL) mask = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_mask.x, (int)j) |
+                             ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_mask.y, (int)j) << 32);
             const uint32_t minx = r0 & 0xFFFFu, miny = r0 >> 16, maxx = r1 & 0xFFFFu, maxy = r1 >> 16;
             const uint32_t w = maxx - minx, n = w * (maxy - miny);
             const float inv_w = 1.0f / (float)w;
             for (uint32_t kb = 0; kb < n; kb += 64) {
                 const uint32_t k = kb + lane;
+                bool hit = false;
+                uint32_t ty = 0, tx = 0;
                 if (k < n) {
-                    uint32_t ty, tx;
                     divmod_small(k, w, inv_w, ty, tx);
+                    hit = !CULL || n > 64u || ((mask >> k) & 1ull);   // rects of more than 64 tiles are not culled
+                }
+                if (hit) {
                     const uint32_t t = (miny + ty) * gx + minx + tx;
                     if (MODE == 0) {
                         h16[t] = (uint16_t)(h16[t] + 1);
@@ -312,12 +328,19 @@ int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state
     const uint32_t wpb = pick_waves_per_block(bpw16);
     if (wpb == 0) { w3d_set_error("image has too many tiles (%u) for the LDS-resident binning", T); return W3D_ERR_UNSUPPORTED; }
     const size_t lds16 = (size_t)bpw16 * wpb;
-    if (lds16 > 64 * 1024)
-        W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+    if (lds16 > 64 * 1024) {
+        W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+        W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+    }
     W3D_PROF("tile_count_scan", stream);
-    hipLaunchKernelGGL(chunk_walk_kernel<0>, dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds16, stream, vals[0],
-                       reinterpret_cast<const uint2 *>(state + L.o_rect), counters, L.chunk, L.C, T, (uint32_t)L.gx, wpb, cnt,
-                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0);
+#define WALK_ARGS(ids)                                                                                                    \
+    ids, reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint2 *>(state + L.o_tile_mask)
+    if (v.tile_cull)
+        hipLaunchKernelGGL((chunk_walk_kernel<0, true>), dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds16, stream, WALK_ARGS(vals[0]),
+                           counters, L.chunk, L.C, T, (uint32_t)L.gx, wpb, cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0);
+    else
+        hipLaunchKernelGGL((chunk_walk_kernel<0, false>), dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds16, stream, WALK_ARGS(vals[0]),
+                           counters, L.chunk, L.C, T, (uint32_t)L.gx, wpb, cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0);
     W3D_LAUNCH_CHECK(v.debug, stream);
     // ---- offsets
     const uint32_t tb = (T + 255) / 256;
@@ -337,13 +360,21 @@ int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, ch
     const uint32_t wpb = pick_waves_per_block(bpw32);
     if (wpb == 0) { w3d_set_error("image has too many tiles (%u) for the LDS-resident binning", T); return W3D_ERR_UNSUPPORTED; }
     const size_t lds32 = (size_t)bpw32 * wpb;
-    if (lds32 > 64 * 1024)
-        W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+    if (lds32 > 64 * 1024) {
+        W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+        W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+    }
     W3D_PROF("fill_lists", stream);
-    hipLaunchKernelGGL(chunk_walk_kernel<1>, dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds32, stream,
-                       reinterpret_cast<const uint32_t *>(scratch + L.s_vals0), reinterpret_cast<const uint2 *>(state + L.o_rect),
-                       reinterpret_cast<const uint32_t *>(state + L.o_counters), L.chunk, L.C, T, (uint32_t)L.gx, wpb,
-                       (uint16_t *)nullptr, reinterpret_cast<const uint32_t *>(scratch + L.s_off), point_list, list_capacity);
+    const uint32_t *ids = reinterpret_cast<const uint32_t *>(scratch + L.s_vals0);
+    if (v.tile_cull)
+        hipLaunchKernelGGL((chunk_walk_kernel<1, true>), dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds32, stream, WALK_ARGS(ids),
+                           reinterpret_cast<const uint32_t *>(state + L.o_counters), L.chunk, L.C, T, (uint32_t)L.gx, wpb,
+                           (uint16_t *)nullptr, reinterpret_cast<const uint32_t *>(scratch + L.s_off), point_list, list_capacity);
+    else
+        hipLaunchKernelGGL((chunk_walk_kernel<1, false>), dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds32, stream, WALK_ARGS(ids),
+                           reinterpret_cast<const uint32_t *>(state + L.o_counters), L.chunk, L.C, T, (uint32_t)L.gx, wpb,
+                           (uint16_t *)nullptr, reinterpret_cast<const uint32_t *>(scratch + L.s_off), point_list, list_capacity);
+#undef WALK_ARGS
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;
 }

@@ -191,6 +191,41 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float *c, const float *
 }
 
 // ---------------------------------------------------------------------------------------------
+// Exact footprint test (tile_cull): can ANY pixel centre of tile (tx,ty) reach alpha >= 1/255 for this
+// Gaussian?  alpha = o*exp(-q(d)) with q(d) = 0.5*(A dx^2 + C dy^2) + B dx dy, so the question is
+// whether min over the tile's pixel box of q is <= tau = ln(255 o).  q is convex with its minimum at
+// the Gaussian's centre: either the centre lies in the box, or the box minimum sits on one of the
+// four edges, where it is a clamped 1-D parabola minimum.  tau carries a +1e-3 safety margin, far
+// above the fp32 rounding of either this test or the blend kernels' power, so an instance is only
+// dropped when it provably contributes nothing: every output is unchanged, R and R_walk shrink.
+__device__ __forceinline__ bool footprint_hits_tile(float mx, float my, float A, float B, float C, float tau,
+                                                    uint32_t tx, uint32_t ty, float wmax, float hmax) {
+    const float x0 = (float)(tx * W3D_TILE), y0 = (float)(ty * W3D_TILE);
+    const float x1 = fminf(x0 + (float)(W3D_TILE - 1), wmax), y1 = fminf(y0 + (float)(W3D_TILE - 1), hmax);
+    const float dxl = mx - x1, dxh = mx - x0, dyl = my - y1, dyh = my - y0;
+    if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;
+    if (!(A > 0.f && C > 0.f)) return true;
+    const float iA = 1.0f / A, iC = 1.0f / C;
+    float best;
+    {
+        const float dy = fminf(fmaxf(-B * dxl * iC, dyl), dyh);
+        best = 0.5f * (A * dxl * dxl + C * dy * dy) + B * dxl * dy;
+    }
+    {
+        const float dy = fminf(fmaxf(-B * dxh * iC, dyl), dyh);
+        best = fminf(best, 0.5f * (A * dxh * dxh + C * dy * dy) + B * dxh * dy);
+    }
+    {
+        const float dx = fminf(fmaxf(-B * dyl * iA, dxl), dxh);
+        best = fminf(best, 0.5f * (A * dx * dx + C * dyl * dyl) + B * dx * dyl);
+    }
+    {
+        const float dx = fminf(fmaxf(-B * dyh * iA, dxl), dxh);
+        best = fminf(best, 0.5f * (A * dx * dx + C * dyh * dyh) + B * dx * dyh);
+    }
+    return !(best > tau);
+}
+
 // Activations of the raw (pre-activation) parameter path — what GaussianModel's getters apply
 // (reference scene/gaussian_model.py:33-41,101-121): exp, sigmoid, F.normalize.
 __device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -210,7 +245,8 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
                       const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
                       int32_t *__restrict__ radii, float2 *__restrict__ xy, float4 *__restrict__ conic_op,
                       float4 *__restrict__ rgbd, ushort4 *__restrict__ rect, uint8_t *__restrict__ clamped_out,
-                      uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ counters) {
+                      uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ counters,
+                      uint2 *__restrict__ tile_mask) {
 #pragma clang fp contract(off)
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= P) return;
@@ -280,7 +316,25 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
         radius = r;
         key = __float_as_uint(pv[2]);
         xy[g] = make_float2(px, py);
-        conic_op[g] = make_float4(conx, cony, conz, RAW ? act_sigmoid(opacities[g]) : opacities[g]);
+        const float opac = RAW ? act_sigmoid(opacities[g]) : opacities[g];
+        conic_op[g] = make_float4(conx, cony, conz, opac);
+        if (v.tile_cull) {
+            // which tiles of the rect can this Gaussian reach at all?  (rects of > 64 tiles are left whole)
+            const int rw = maxx - minx, rn = rw * (maxy - miny);
+            uint64_t m = ~0ull;
+            if (rn <= 64) {
+                // o <= 1/255 can never reach alpha >= 1/255: tau < 0 drops every tile
+                const float tau = (opac > 0.f) ? (__logf(255.0f * opac) + 1e-3f) : -1.0f;
+                m = 0ull;
+                int k = 0;
+                for (int ty = miny; ty < maxy; ty++)
+                    for (int tx = minx; tx < maxx; tx++, k++)
+                        if (footprint_hits_tile(px, py, conx, cony, conz, tau, (uint32_t)tx, (uint32_t)ty,
+                                                (float)(v.image_width - 1), (float)(v.image_height - 1)))
+                            m |= 1ull << k;
+            }
+            tile_mask[g] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+        }
         rgbd[g] = make_float4(rgb[0], rgb[1], rgb[2], pv[2]);
         rect[g] = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
         clamped_out[g] = (uint8_t)cl;
@@ -595,7 +649,8 @@ int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *me
         reinterpret_cast<float2 *>(state + L.o_xy), reinterpret_cast<float4 *>(state + L.o_conic_op),                \
         reinterpret_cast<float4 *>(state + L.o_rgbd), reinterpret_cast<ushort4 *>(state + L.o_rect),                 \
         reinterpret_cast<uint8_t *>(state + L.o_clamped), reinterpret_cast<uint32_t *>(scratch + L.s_keys0),         \
-        reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(state + L.o_counters)
+        reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(state + L.o_counters),       \
+        reinterpret_cast<uint2 *>(state + L.o_tile_mask)
     if (f_rest_raw) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(grid), dim3(block), 0, stream, ARGS);
     else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(grid), dim3(block), 0, stream, ARGS);
 #undef ARGS

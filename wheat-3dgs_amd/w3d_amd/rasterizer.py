@@ -8,12 +8,19 @@ memory (outputs, state, scratch, lists all come from its caching allocator, so t
 ``torch.cuda.empty_cache()`` calls — run_3d_seg.py:99 — keep working) and the stream.
 """
 import ctypes
+import os
 from typing import NamedTuple, Optional
 
 import torch
 
 from . import _lib
 from ._lib import W3DView, check, lib, ptr, stream_ptr
+
+
+# Exact footprint culling of tile instances (w3d_view.tile_cull): outputs are unchanged, the per-tile
+# lists are about half as long.  Set False (or W3D_TILE_CULL=0) to get the published bounding-square
+# lists, e.g. to compare them entry by entry with another implementation.
+TILE_CULL = os.environ.get("W3D_TILE_CULL", "1") != "0"
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -83,6 +90,7 @@ class _View:
         v.prefiltered, v.debug = int(bool(s.prefiltered)), int(bool(s.debug))
         v.bg, v.viewmatrix = self.bg.data_ptr(), self.vm.data_ptr()
         v.projmatrix, v.campos = self.pm.data_ptr(), self.cp.data_ptr()
+        v.tile_cull = int(bool(TILE_CULL))
         self.c = v
 
 
