@@ -143,91 +143,129 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
 }
 
 // ------------------------------------------------------------------------------ tile counting
-__device__ __forceinline__ void divmod_small(uint32_t k, uint32_t w, float inv_w, uint32_t &q, uint32_t &r) {
-    q = (uint32_t)((float)k * inv_w);
-    if (q * w > k) q--;
-    if ((q + 1) * w <= k) q++;
-    r = k - q * w;
-}
-
 // One wave per depth-contiguous chunk.  MODE 0: count (u16 LDS counters, dumps the row of the
 // count matrix).  MODE 1: fill (u32 LDS cursors initialised from the offset matrix; writes list).
+//
+// The walk is serial in the Gaussians of the chunk (that is what makes the counting sort stable)
+// but everything that does not depend on the LDS cursors is hoisted: each lane first derives, for
+// ITS OWN Gaussian of the 64-batch, the rect base tile, width, tile count and a 16.16 reciprocal of
+// the width (so lane -> (tx,ty) is a multiply and a shift, no division in the serial part); the
+// serial loop then only broadcasts those with v_readlane.  Two consecutive Gaussians whose rects
+// hold <= 32 tiles each and do not overlap are handled by ONE iteration (lanes 0-31 / 32-63): with
+// disjoint tiles no ordering question arises between them.
+// Depth-ordered packed records {id, rect lo, rect hi, -} + tile mask, so that the (chunk, band) walkers —
+// which re-read their chunk once per band and per pass — stream them coalesced instead of gathering.
+__global__ void __launch_bounds__(256)
+gather_sorted_kernel(const uint32_t *__restrict__ sorted_ids, const uint2 *__restrict__ rect,
+                     const uint2 *__restrict__ tile_mask, const uint32_t *__restrict__ counters, uint32_t P,
+                     uint4 *__restrict__ rec, uint2 *__restrict__ rec_mask, int cull) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= P || s >= counters[0]) return;
+    const uint32_t g = sorted_ids[s];
+    const uint2 rc = rect[g];
+    rec[s] = make_uint4(g, rc.x, rc.y, 0u);
+    rec_mask[s] = cull ? tile_mask[g] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+}
+
 template <int MODE, bool CULL>
 __global__ void __launch_bounds__(256)
-chunk_walk_kernel(const uint32_t *__restrict__ sorted_ids, const uint2 *__restrict__ rect,
-                  const uint2 *__restrict__ tile_mask, const uint32_t *__restrict__ counters,
-                  uint32_t chunk, uint32_t C, uint32_t T, uint32_t gx, uint32_t waves_per_block,
+chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_mask,
+                  const uint32_t *__restrict__ counters,
+                  uint32_t chunk, uint32_t C, uint32_t T, uint32_t gx, uint32_t gy, uint32_t band_rows,
                   uint16_t *__restrict__ cnt, const uint32_t *__restrict__ off, uint32_t *__restrict__ point_list,
                   uint64_t capacity) {
+    // blockIdx.y = band of tile rows this wave is responsible for: the LDS array only spans the band
+    // (a few KB, so 8 waves per SIMD fit), and Gaussians whose rect misses the band are compacted
+    // away BEFORE the serial loop, so the serial work per wave shrinks with the band height while
+    // the number of independent waves grows by the number of bands.
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wv >= waves_per_block) return;
-    const uint32_t c = blockIdx.x * waves_per_block + wv;
+    const uint32_t c = blockIdx.x * 4 + wv;
     if (c >= C) return;
+    const uint32_t y0 = blockIdx.y * band_rows, y1 = min(gy, y0 + band_rows);
+    const uint32_t tb0 = y0 * gx, Tb = (y1 - y0) * gx;           // first tile / tile count of the band
+    const uint32_t Tbpad = (band_rows * gx + 63u) & ~63u;
     const uint32_t V = counters[0];
-    const uint32_t Tpad = (T + 63u) & ~63u;
+    (void)T;
     // plain (non-volatile) LDS accesses: a wave's LDS operations complete in issue order, and the compiler
     // keeps may-alias loads/stores in program order; `volatile` would make the backend drain vmcnt/lgkmcnt
     // around every access and serialise the loop on the latency of the previous list store.
-    uint16_t *h16 = reinterpret_cast<uint16_t *>(smem) + (size_t)wv * Tpad;
-    uint32_t *h32 = reinterpret_cast<uint32_t *>(smem) + (size_t)wv * Tpad;
+    uint16_t *h16 = reinterpret_cast<uint16_t *>(smem) + (size_t)wv * Tbpad;
+    uint32_t *h32 = reinterpret_cast<uint32_t *>(smem) + (size_t)wv * Tbpad;
     if (MODE == 0) {
-        for (uint32_t t = lane; t < Tpad; t += 64) h16[t] = 0;
+        for (uint32_t t = lane; t < Tbpad; t += 64) h16[t] = 0;
     } else {
-        const uint32_t *row = off + (size_t)c * T;
-        for (uint32_t t = lane; t < T; t += 64) h32[t] = row[t];
+        const uint32_t *row = off + (size_t)c * T + tb0;
+        for (uint32_t t = lane; t < Tb; t += 64) h32[t] = row[t];
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t s_beg = min(V, c * chunk), s_end = min(V, s_beg + chunk);
+#define RL(x, i) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (int)(i)))
+    auto touch = [&](bool hit, uint32_t t, uint32_t g) {
+        if (hit) {
+            if (MODE == 0) {
+                h16[t] = (uint16_t)(h16[t] + 1);
+            } else {
+                const uint32_t pos = h32[t];
+                h32[t] = pos + 1;
+                if (pos < capacity) point_list[pos] = g;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // software pipeline: the records of batch b+1 are in flight while batch b is walked
+    uint4 nx_rec = make_uint4(0u, 0u, 0u, 0u);
+    uint2 nx_mask = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (s_beg + lane < s_end) { nx_rec = rec[s_beg + lane]; nx_mask = rec_mask[s_beg + lane]; }
     for (uint32_t base = s_beg; base < s_end; base += 64) {
         const uint32_t nb = min(64u, s_end - base);
-        uint32_t my_g = 0;
-        uint2 my_rc = make_uint2(0u, 0u);
+        const uint4 cur_rec = nx_rec;
+        const uint2 cur_mask = nx_mask;
+        if (base + 64 + lane < s_end) { nx_rec = rec[base + 64 + lane]; nx_mask = rec_mask[base + 64 + lane]; }
+        uint32_t my_g = 0, my_minx = 0, my_miny = 0, my_w = 1, my_n = 0, my_magic = 0;
         uint2 my_mask = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        bool relevant = false;
         if (lane < nb) {
-            my_g = sorted_ids[base + lane];
-            my_rc = rect[my_g];
-            if (CULL) my_mask = tile_mask[my_g];   // bit k: k-th tile of the rect (row-major) can be reached
+            my_g = cur_rec.x;
+            const uint2 rc = make_uint2(cur_rec.y, cur_rec.z);
+            const uint32_t minx = rc.x & 0xFFFFu, miny = rc.x >> 16, maxx = rc.y & 0xFFFFu, maxy = rc.y >> 16;
+            relevant = miny < y1 && maxy > y0;                   // rect reaches into this band
+            if (CULL) my_mask = cur_mask;                        // bit k: k-th tile of the rect (row-major) can be reached
+            my_minx = minx; my_miny = miny;
+            my_w = maxx - minx;
+            my_n = my_w * (maxy - miny);
+            my_magic = 65536u / max(my_w, 1u) + 1u;              // floor(k / w) == (k * magic) >> 16 for k < 64, w <= 64
         }
-        // make the batch loads land HERE: otherwise the wait sits inside the j loop as vmcnt(0) and every
-        // iteration also waits for the previous iteration's list stores
-        asm volatile("" : "+v"(my_g), "+v"(my_rc.x), "+v"(my_rc.y), "+v"(my_mask.x), "+v"(my_mask.y));
-        for (uint32_t j = 0; j < nb; j++) {
-            const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)my_g, (int)j);
-            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)my_rc.x, (int)j);
-            const uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)my_rc.y, (int)j);
-            uint64_t mask = ~0ull;
-            if (CULL) mask = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_mask.x, (int)j) |
-                             ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)my_mask.y, (int)j) << 32);
-            const uint32_t minx = r0 & 0xFFFFu, miny = r0 >> 16, maxx = r1 & 0xFFFFu, maxy = r1 >> 16;
-            const uint32_t w = maxx - minx, n = w * (maxy - miny);
-            const float inv_w = 1.0f / (float)w;
-            for (uint32_t kb = 0; kb < n; kb += 64) {
-                const uint32_t k = kb + lane;
-                bool hit = false;
-                uint32_t ty = 0, tx = 0;
-                if (k < n) {
-                    divmod_small(k, w, inv_w, ty, tx);
-                    hit = !CULL || n > 64u || ((mask >> k) & 1ull);   // rects of more than 64 tiles are not culled
+        uint64_t todo = __ballot(relevant);
+        while (todo) {
+            const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+            todo &= todo - 1;
+            const uint32_t n0 = RL(my_n, j);
+            const uint32_t g = RL(my_g, j), w = RL(my_w, j), minx = RL(my_minx, j), miny = RL(my_miny, j);
+            if (n0 <= 64u) {
+                const uint32_t mg = RL(my_magic, j);
+                const uint64_t mask = CULL ? ((uint64_t)RL(my_mask.x, j) | ((uint64_t)RL(my_mask.y, j) << 32)) : ~0ull;
+                const uint32_t ty = __umul24(lane, mg) >> 16;
+                const uint32_t tx = lane - __umul24(ty, w);
+                const uint32_t row = miny + ty;
+                const bool hit = lane < n0 && ((mask >> lane) & 1ull) && row >= y0 && row < y1;
+                touch(hit, __umul24(row - y0, gx) + minx + tx, g);
+            } else {
+                // big footprint (> 64 tiles): never culled, generic division
+                for (uint32_t kb = 0; kb < n0; kb += 64) {
+                    const uint32_t k = kb + lane;
+                    const uint32_t ty = k / w, tx = k - ty * w;
+                    const uint32_t row = miny + ty;
+                    touch(k < n0 && row >= y0 && row < y1, (row - y0) * gx + minx + tx, g);
                 }
-                if (hit) {
-                    const uint32_t t = (miny + ty) * gx + minx + tx;
-                    if (MODE == 0) {
-                        h16[t] = (uint16_t)(h16[t] + 1);
-                    } else {
-                        const uint32_t pos = h32[t];
-                        h32[t] = pos + 1;
-                        if (pos < capacity) point_list[pos] = g;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
             }
         }
     }
+#undef RL
     if (MODE == 0) {
         __builtin_amdgcn_wave_barrier();
-        uint16_t *row = cnt + (size_t)c * T;
-        for (uint32_t t = lane; t < T; t += 64) row[t] = h16[t];
+        uint16_t *row = cnt + (size_t)c * T + tb0;
+        for (uint32_t t = lane; t < Tb; t += 64) row[t] = h16[t];
     }
 }
 
@@ -286,12 +324,20 @@ __global__ void copy_ranges_kernel(const uint32_t *__restrict__ tile_start, uint
     if (t < T) { out[2 * t] = tile_start[t]; out[2 * t + 1] = tile_start[t + 1]; }
 }
 
-uint32_t pick_waves_per_block(uint64_t bytes_per_wave) {
-    uint64_t w = (160u * 1024u) / (bytes_per_wave ? bytes_per_wave : 1);
-    if (w > 4) w = 4;
-    return (uint32_t)w;
+// Bands of tile rows for the chunk walk: each (chunk, band) pair is one wave.  Narrow bands cut the
+// serial work per wave and its LDS footprint (4 waves x Tband x 4 B per workgroup); every band adds a
+// redundant pass over the chunk's 20-B Gaussian records.  Keep the LDS of a workgroup <= 16 KB.
+struct W3DBands { uint32_t rows, count, tbpad; };
+W3DBands w3d_pick_bands(const W3DLayout &L) {
+    W3DBands b;
+    uint32_t rows = 1024u / (uint32_t)L.gx;          // ~1024 tiles per band
+    if (rows < 1) rows = 1;
+    if (rows > (uint32_t)L.gy) rows = (uint32_t)L.gy;
+    b.rows = rows;
+    b.count = ((uint32_t)L.gy + rows - 1) / rows;
+    b.tbpad = (rows * (uint32_t)L.gx + 63u) & ~63u;
+    return b;
 }
-
 }  // namespace
 
 int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream) {
@@ -324,23 +370,28 @@ int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state
         // after 4 passes the sorted ids are back in vals[0]
     }
     // ---- per-chunk per-tile counts
-    const uint64_t bpw16 = (uint64_t)((T + 63u) & ~63u) * 2;
-    const uint32_t wpb = pick_waves_per_block(bpw16);
-    if (wpb == 0) { w3d_set_error("image has too many tiles (%u) for the LDS-resident binning", T); return W3D_ERR_UNSUPPORTED; }
-    const size_t lds16 = (size_t)bpw16 * wpb;
-    if (lds16 > 64 * 1024) {
-        W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-        W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-    }
+    const W3DBands bands = w3d_pick_bands(L);
     W3D_PROF("tile_count_scan", stream);
-#define WALK_ARGS(ids)                                                                                                    \
-    ids, reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint2 *>(state + L.o_tile_mask)
-    if (v.tile_cull)
-        hipLaunchKernelGGL((chunk_walk_kernel<0, true>), dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds16, stream, WALK_ARGS(vals[0]),
-                           counters, L.chunk, L.C, T, (uint32_t)L.gx, wpb, cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0);
-    else
-        hipLaunchKernelGGL((chunk_walk_kernel<0, false>), dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds16, stream, WALK_ARGS(vals[0]),
-                           counters, L.chunk, L.C, T, (uint32_t)L.gx, wpb, cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t)0);
+#define WALK_ARGS(ids) reinterpret_cast<const uint4 *>(scratch + L.s_rec), reinterpret_cast<const uint2 *>(scratch + L.s_rec_mask)
+    if (L.P > 0) {
+        hipLaunchKernelGGL(gather_sorted_kernel, dim3((L.P + 255) / 256), dim3(256), 0, stream, vals[0],
+                           reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint2 *>(state + L.o_tile_mask),
+                           counters, (uint32_t)L.P, reinterpret_cast<uint4 *>(scratch + L.s_rec),
+                           reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);
+        W3D_LAUNCH_CHECK(v.debug, stream);
+    }
+    {
+        const dim3 grid((L.C + 3) / 4, bands.count);
+        const size_t lds = (size_t)bands.tbpad * 2 * 4;
+        if (v.tile_cull)
+            hipLaunchKernelGGL((chunk_walk_kernel<0, true>), grid, dim3(256), lds, stream, WALK_ARGS(vals[0]), counters, L.chunk,
+                               L.C, T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, (const uint32_t *)nullptr,
+                               (uint32_t *)nullptr, (uint64_t)0);
+        else
+            hipLaunchKernelGGL((chunk_walk_kernel<0, false>), grid, dim3(256), lds, stream, WALK_ARGS(vals[0]), counters, L.chunk,
+                               L.C, T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, (const uint32_t *)nullptr,
+                               (uint32_t *)nullptr, (uint64_t)0);
+    }
     W3D_LAUNCH_CHECK(v.debug, stream);
     // ---- offsets
     const uint32_t tb = (T + 255) / 256;
@@ -356,24 +407,20 @@ int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state
 int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
                           uint64_t list_capacity, hipStream_t stream) {
     const uint32_t T = (uint32_t)L.T;
-    const uint64_t bpw32 = (uint64_t)((T + 63u) & ~63u) * 4;
-    const uint32_t wpb = pick_waves_per_block(bpw32);
-    if (wpb == 0) { w3d_set_error("image has too many tiles (%u) for the LDS-resident binning", T); return W3D_ERR_UNSUPPORTED; }
-    const size_t lds32 = (size_t)bpw32 * wpb;
-    if (lds32 > 64 * 1024) {
-        W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
-        W3D_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(chunk_walk_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
-    }
+    const W3DBands bands = w3d_pick_bands(L);
+    const dim3 grid((L.C + 3) / 4, bands.count);
+    const size_t lds = (size_t)bands.tbpad * 4 * 4;
     W3D_PROF("fill_lists", stream);
-    const uint32_t *ids = reinterpret_cast<const uint32_t *>(scratch + L.s_vals0);
     if (v.tile_cull)
-        hipLaunchKernelGGL((chunk_walk_kernel<1, true>), dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds32, stream, WALK_ARGS(ids),
-                           reinterpret_cast<const uint32_t *>(state + L.o_counters), L.chunk, L.C, T, (uint32_t)L.gx, wpb,
-                           (uint16_t *)nullptr, reinterpret_cast<const uint32_t *>(scratch + L.s_off), point_list, list_capacity);
+        hipLaunchKernelGGL((chunk_walk_kernel<1, true>), grid, dim3(256), lds, stream, WALK_ARGS(ids),
+                           reinterpret_cast<const uint32_t *>(state + L.o_counters), L.chunk, L.C, T, (uint32_t)L.gx,
+                           (uint32_t)L.gy, bands.rows, (uint16_t *)nullptr,
+                           reinterpret_cast<const uint32_t *>(scratch + L.s_off), point_list, list_capacity);
     else
-        hipLaunchKernelGGL((chunk_walk_kernel<1, false>), dim3((L.C + wpb - 1) / wpb), dim3(64 * wpb), lds32, stream, WALK_ARGS(ids),
-                           reinterpret_cast<const uint32_t *>(state + L.o_counters), L.chunk, L.C, T, (uint32_t)L.gx, wpb,
-                           (uint16_t *)nullptr, reinterpret_cast<const uint32_t *>(scratch + L.s_off), point_list, list_capacity);
+        hipLaunchKernelGGL((chunk_walk_kernel<1, false>), grid, dim3(256), lds, stream, WALK_ARGS(ids),
+                           reinterpret_cast<const uint32_t *>(state + L.o_counters), L.chunk, L.C, T, (uint32_t)L.gx,
+                           (uint32_t)L.gy, bands.rows, (uint16_t *)nullptr,
+                           reinterpret_cast<const uint32_t *>(scratch + L.s_off), point_list, list_capacity);
 #undef WALK_ARGS
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;

@@ -342,6 +342,9 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
     radii[g] = radius;
     keys[g] = key;
     vals[g] = (uint32_t)g;
+    // an all-zero rect marks a culled Gaussian for the binning walk and for the backward pass; written
+    // here for EVERY Gaussian so that no stale bytes of a recycled state buffer can ever be read
+    if (radius == 0) rect[g] = make_ushort4(0, 0, 0, 0);
     // the visible count is NOT accumulated here (31k same-address atomics cost more than the whole
     // kernel): the depth sort's last pass yields it for free (w3d_binning.hip).
     (void)counters;
@@ -638,10 +641,11 @@ int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *me
                           const float *colors_precomp, const float *opacities, const float *scales,
                           const float *rotations, const float *cov3D_precomp, int32_t *radii, char *state,
                           char *scratch, const float *f_rest_raw, hipStream_t stream) {
-    // counters and the rect array start at zero each call (rect == 0 marks a culled Gaussian)
-    W3D_HIP_CHECK(hipMemsetAsync(state + L.o_counters, 0, 64, stream));
-    W3D_HIP_CHECK(hipMemsetAsync(state + L.o_rect, 0, (size_t)(L.P > 0 ? L.P : 1) * 8, stream));
-    if (L.P == 0) return W3D_OK;
+    // counters: [0] is written by the depth sort's last pass, [1] by the tile scan
+    if (L.P == 0) {
+        W3D_HIP_CHECK(hipMemsetAsync(state + L.o_counters, 0, 64, stream));
+        return W3D_OK;
+    }
     const int block = 256, grid = (L.P + block - 1) / block;
     W3D_PROF("preprocess_fwd", stream);
 #define ARGS                                                                                                          \

@@ -317,6 +317,11 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     }
 }
 
+__global__ void __launch_bounds__(256) zero_f4_kernel(float4 *__restrict__ p, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 __global__ void copy_pixel_state_kernel(const float *__restrict__ fT, const uint32_t *__restrict__ nc, size_t n,
                                         float *__restrict__ fT_out, uint32_t *__restrict__ nc_out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,7 +362,11 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
     const uint32_t T = (uint32_t)L.T;
     uint32_t blocks = (T + 3) / 4;
     blocks = (blocks + 7) / 8 * 8;
-    W3D_HIP_CHECK(hipMemsetAsync(grad2d, 0, (size_t)(L.P > 0 ? L.P : 1) * W3D_G2D_STRIDE * sizeof(float), stream));
+    {
+        // the record array starts at zero (own kernel rather than hipMemsetAsync: strictly stream-ordered)
+        const size_t n4 = (size_t)(L.P > 0 ? L.P : 1) * W3D_G2D_STRIDE / 4;
+        hipLaunchKernelGGL(zero_f4_kernel, dim3(2048), dim3(256), 0, stream, reinterpret_cast<float4 *>(grad2d), n4);
+    }
 #define ARGS                                                                                                      \
     T, (uint32_t)L.gx, L.W, L.H, reinterpret_cast<const uint32_t *>(state + L.o_tile_start), point_list,          \
         reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_conic_op), \
