@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 mkdir -p ../lib
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -munsafe-fp-atomics -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -munsafe-fp-atomics -fno-slp-vectorize -Wall -Wno-unused-function"
 pids=()
 for f in w3d_preprocess w3d_binning w3d_render w3d_knn w3d_api w3d_loss w3d_adam; do
   [ -f $f.hip ] || continue

@@ -199,9 +199,40 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
 }
 
 // ------------------------------------------------------------------------------ backward
+// Nine (ten with depth) per-Gaussian sums are reduced over the wave stage by stage so that the
+// DPP adds of different values interleave (no hazard nops); the totals land in lane 63.
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += dpp_mov<0xB1>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += dpp_mov<0x4E>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += dpp_mov<0x141>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += dpp_mov<0x140>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += dpp_mov<0x142, 0xA>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += dpp_mov<0x143, 0xC>(v[i]);
+}
+
+struct Staged { float4 a, b, c; };
+__device__ __forceinline__ Staged gather_entry(uint32_t g, const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
+                                               const float4 *__restrict__ rgbd) {
+    const float2 p = xy[g];
+    const float4 co = conic_op[g];
+    Staged s;
+    const float pmin = (co.w > 0.f) ? (-__logf(255.0f * co.w) - 1e-4f) : 1.0f;
+    s.a = make_float4(p.x, p.y, pmin, __uint_as_float(g));
+    s.b = co;
+    s.c = rgbd[g];
+    return s;
+}
+
 // HAS_DA: gradients w.r.t. the depth and alpha images are present.
 template <bool HAS_DA>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, HAS_DA ? 3 : 4)   // 2nd argument = waves per SIMD: caps VGPRs at 128 / 168
 render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restrict__ tile_start,
                   const uint32_t *__restrict__ point_list, const float2 *__restrict__ xy,
                   const float4 *__restrict__ conic_op, const float4 *__restrict__ rgbd, const float *__restrict__ bg,
@@ -217,16 +248,19 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     const uint32_t lx = lane & 7, ly = lane >> 3;
     const size_t HW = (size_t)H * W;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    float pxf[4], pyf[4], Tr[4], Tfin[4], bgdot[4];
+    // per-pixel state, 4 pixels per lane.  ar* = colour (depth, alpha) composited BEHIND the entry being
+    // visited; it is advanced right after an entry is processed (A <- a*c + (1-a)*A), which is the same
+    // arithmetic, in the same order, as the textbook "last_alpha / last_color" formulation but needs no
+    // copies of the previous contributor.  Pixel coordinates are rebuilt from the lane id on the fly.
+    const float pxb = (float)(tx0 + lx), pyb = (float)(ty0 + ly);
+    float Tr[4], Tfin[4];
     float dp0[4], dp1[4], dp2[4], dpd[4], dpa[4];
     float ar0[4], ar1[4], ar2[4], ard[4], ara[4];
-    float lc0[4], lc1[4], lc2[4], ld[4], la[4];
     uint32_t last[4];
     uint32_t maxc = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t px = tx0 + (k & 1) * 8 + lx, py = ty0 + (k >> 1) * 8 + ly;
-        pxf[k] = (float)px; pyf[k] = (float)py;
         const bool in = (px < (uint32_t)W) && (py < (uint32_t)H);
         const size_t pix = (size_t)py * W + px;
         Tfin[k] = in ? final_T[pix] : 0.f;
@@ -237,79 +271,97 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         dp2[k] = in ? dL_dcolor[2 * HW + pix] : 0.f;
         dpd[k] = (HAS_DA && in && dL_ddepth) ? dL_ddepth[pix] : 0.f;
         dpa[k] = (HAS_DA && in && dL_dalpha_px) ? dL_dalpha_px[pix] : 0.f;
-        bgdot[k] = bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k];
         ar0[k] = ar1[k] = ar2[k] = ard[k] = ara[k] = 0.f;
-        lc0[k] = lc1[k] = lc2[k] = ld[k] = la[k] = 0.f;
         maxc = max(maxc, last[k]);
     }
     maxc = wave_max_u32(maxc);
     if (maxc == 0) return;
     const uint32_t start = tile_start[tile];
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    const bool has_bg = (bg0 != 0.f) || (bg1 != 0.f) || (bg2 != 0.f);     // wave-uniform: black background skips the term
     const int nb = (int)((maxc + 63) / 64);
+    // software pipeline over the 64-entry batches (walked back to front): while batch b is consumed from
+    // LDS, the records of batch b-1 are already in flight to registers and the ids of batch b-2 to `ids`.
+    auto batch_id = [&](int b) -> uint32_t {
+        const uint32_t i = (uint32_t)b * 64u + lane;
+        return (b >= 0 && i < maxc) ? point_list[start + i] : 0xFFFFFFFFu;
+    };
+    Staged nxt;
+    {
+        const uint32_t g = batch_id(nb - 1);
+        nxt = (g != 0xFFFFFFFFu) ? gather_entry(g, xy, conic_op, rgbd) : Staged{};
+    }
+    uint32_t ids = batch_id(nb - 2);
     for (int b = nb - 1; b >= 0; b--) {
         const uint32_t n = min(64u, maxc - (uint32_t)b * 64u);
-        stage_entries(s, lane, n, point_list + start + (uint32_t)b * 64u, xy, conic_op, rgbd);
+        s.a[lane] = nxt.a; s.b[lane] = nxt.b; s.c[lane] = nxt.c;
+        __builtin_amdgcn_wave_barrier();
+        if (b > 0) {
+            nxt = (ids != 0xFFFFFFFFu) ? gather_entry(ids, xy, conic_op, rgbd) : Staged{};
+            ids = batch_id(b - 2);
+        }
         for (int j = (int)n - 1; j >= 0; j--) {
             const float4 ea = s.a[j], eb = s.b[j], ec = s.c[j];
             const uint32_t idx0 = (uint32_t)b * 64u + (uint32_t)j;   // 0-based position in the tile list
-            float gmx = 0.f, gmy = 0.f, gcx = 0.f, gcy = 0.f, gcz = 0.f, gop = 0.f, gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f;
+            // per-lane partial sums of this tile instance.  Geometry enters through the five moments of
+            // m = dL/dG * G:  S1 = sum m dx, S2 = sum m dy, Sxx = sum m dx^2, Sxy = sum m dx dy, Syy = sum m dy^2;
+            // dL/dmean2D and dL/dconic are linear in them and are formed AFTER the wave reduction.
+            // v: S1, S2, Sxx, Sxy, Syy, opacity, r, g, b [, depth]
+            float v[HAS_DA ? 10 : 9];
+#pragma unroll
+            for (int i = 0; i < (HAS_DA ? 10 : 9); i++) v[i] = 0.f;
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const float dx = ea.x - pxf[k], dy = ea.y - pyf[k];
+                const float dx = ea.x - (pxb + (float)((k & 1) * 8)), dy = ea.y - (pyb + (float)((k >> 1) * 8));
                 const float power = -0.5f * (eb.x * dx * dx + eb.z * dy * dy) - eb.y * dx * dy;
                 const bool cand = idx0 < last[k] && power <= 0.f && power >= ea.z;
                 if (__ballot(cand) == 0ull) continue;
-                const float G = __builtin_amdgcn_exp2f(power * LOG2E);
-                const float alpha = fminf(0.99f, eb.w * G);
-                const bool ok = cand && alpha >= (1.0f / 255.0f);
+                const float Graw = __builtin_amdgcn_exp2f(power * LOG2E);
+                const float araw = fminf(0.99f, eb.w * Graw);
+                const bool ok = cand && araw >= (1.0f / 255.0f);
                 if (__ballot(ok) == 0ull) continue;
                 any = any || ok;
-                const float one_m_a = 1.f - alpha;
-                const float inv = __builtin_amdgcn_rcpf(one_m_a);
+                // Branch-free per lane: a lane that does not blend this Gaussian runs the same recurrences
+                // with alpha = G = 0, which leaves T and the suffix accumulators untouched and adds zeros.
+                const float alpha = ok ? araw : 0.f;
+                const float G = ok ? Graw : 0.f;
+                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                 const float Tn = Tr[k] * inv;
                 const float dch = alpha * Tn;
-                // suffix colour seen behind this Gaussian
-                const float n0 = la[k] * lc0[k] + (1.f - la[k]) * ar0[k];
-                const float n1 = la[k] * lc1[k] + (1.f - la[k]) * ar1[k];
-                const float n2 = la[k] * lc2[k] + (1.f - la[k]) * ar2[k];
-                float dL_dalpha = (ec.x - n0) * dp0[k] + (ec.y - n1) * dp1[k] + (ec.z - n2) * dp2[k];
-                float nd = 0.f, na = 0.f;
+                const float d0 = ec.x - ar0[k], d1 = ec.y - ar1[k], d2 = ec.z - ar2[k];
+                float dL_dalpha = d0 * dp0[k] + d1 * dp1[k] + d2 * dp2[k];
+                ar0[k] += alpha * d0; ar1[k] += alpha * d1; ar2[k] += alpha * d2;   // A <- a c + (1-a) A
                 if (HAS_DA) {
-                    nd = la[k] * ld[k] + (1.f - la[k]) * ard[k];
-                    na = la[k] + (1.f - la[k]) * ara[k];
-                    dL_dalpha += (ec.w - nd) * dpd[k] + (1.f - na) * dpa[k];
+                    const float dd = ec.w - ard[k], da = 1.f - ara[k];
+                    dL_dalpha += dd * dpd[k] + da * dpa[k];
+                    ard[k] += alpha * dd; ara[k] += alpha * da;
+                    v[9] += dch * dpd[k];
                 }
+                Tr[k] = Tn;
                 dL_dalpha *= Tn;
-                dL_dalpha += (-Tfin[k] * inv) * bgdot[k];
-                const float dL_dG = eb.w * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * eb.x - gdy * eb.y;
-                const float dG_ddely = -gdy * eb.z - gdx * eb.y;
-                if (ok) {
-                    Tr[k] = Tn;
-                    ar0[k] = n0; ar1[k] = n1; ar2[k] = n2;
-                    lc0[k] = ec.x; lc1[k] = ec.y; lc2[k] = ec.z;
-                    if (HAS_DA) { ard[k] = nd; ara[k] = na; ld[k] = ec.w; }
-                    la[k] = alpha;
-                    gr += dch * dp0[k]; gg += dch * dp1[k]; gb += dch * dp2[k];
-                    if (HAS_DA) gd += dch * dpd[k];
-                    gmx += dL_dG * dG_ddelx; gmy += dL_dG * dG_ddely;
-                    gcx += -0.5f * gdx * dx * dL_dG; gcy += -0.5f * gdx * dy * dL_dG; gcz += -0.5f * gdy * dy * dL_dG;
-                    gop += G * dL_dalpha;
-                }
+                if (has_bg) dL_dalpha -= (Tfin[k] * inv) * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);
+                const float m = eb.w * dL_dalpha * G;      // dL/dG * G
+                const float mx = m * dx, my = m * dy;
+                v[0] += mx; v[1] += my;
+                v[2] += mx * dx; v[3] += mx * dy; v[4] += my * dy;
+                v[5] += G * dL_dalpha;
+                v[6] += dch * dp0[k]; v[7] += dch * dp1[k]; v[8] += dch * dp2[k];
             }
             if (__ballot(any) == 0ull) continue;
-            // one wave reduction per tile instance, then one 40-B record update
-            const float s0 = wave_sum(gmx) * ddelx_dx, s1 = wave_sum(gmy) * ddely_dy;
-            const float s2 = wave_sum(gcx), s3 = wave_sum(gcy), s4 = wave_sum(gcz), s5 = wave_sum(gop);
-            const float s6 = wave_sum(gr), s7 = wave_sum(gg), s8 = wave_sum(gb);
-            const float s9 = HAS_DA ? wave_sum(gd) : 0.f;
-            float val = s0;
-            val = lane == 1 ? s1 : val; val = lane == 2 ? s2 : val; val = lane == 3 ? s3 : val;
-            val = lane == 4 ? s4 : val; val = lane == 5 ? s5 : val; val = lane == 6 ? s6 : val;
-            val = lane == 7 ? s7 : val; val = lane == 8 ? s8 : val; val = lane == 9 ? s9 : val;
+            // one wave reduction per tile instance, then one 36/40-B record update
+            wave_sum_n(v);
+            float tot[HAS_DA ? 10 : 9];
+#pragma unroll
+            for (int i = 0; i < (HAS_DA ? 10 : 9); i++) tot[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i]), 63));
+            // record: [0] dL/dmean2D.x [1] .y [2] dL/dconic.x [3] .y (half) [4] .z [5] opacity [6..8] rgb [9] depth
+            float val = -(eb.x * tot[0] + eb.y * tot[1]) * ddelx_dx;
+            val = lane == 1u ? -(eb.z * tot[1] + eb.y * tot[0]) * ddely_dy : val;
+            val = lane == 2u ? -0.5f * tot[2] : val;
+            val = lane == 3u ? -0.5f * tot[3] : val;
+            val = lane == 4u ? -0.5f * tot[4] : val;
+#pragma unroll
+            for (int i = 5; i < (HAS_DA ? 10 : 9); i++) val = (lane == (uint32_t)i) ? tot[i] : val;
             const uint32_t g = __float_as_uint(ea.w);
             if (lane < (HAS_DA ? 10u : 9u)) atomicAdd(&grad2d[(size_t)g * W3D_G2D_STRIDE + lane], val);
         }
