@@ -88,8 +88,11 @@ int w3d_forward_stage1(const w3d_view *view, int32_t P, const float *means3D, co
                        const float *rotations, const float *cov3D_precomp, int32_t *radii, void *state,
                        void *scratch, uint32_t *counts_host, w3d_stream_t stream);
 
-/* Stage 2: fill the per-tile depth-ordered lists (point_list, capacity in entries, must be
- * >= num_rendered) and blend front-to-back.  out_color (3,H,W), out_depth (1,H,W), out_alpha
+/* Stage 2: fill the per-tile depth-ordered lists (point_list, capacity in entries) and blend
+ * front-to-back.  The capacity must be >= num_rendered for correct output; if it is smaller (a caller
+ * that sized the buffer speculatively to avoid stage 1's host sync) nothing is written or read beyond
+ * it, the outputs of that view are incomplete, and the caller must repeat the view with a larger list
+ * once it has seen num_rendered (the counters are the first two uint32 of `state`).  out_color (3,H,W), out_depth (1,H,W), out_alpha
  * (1,H,W).  FlashSplat extras are all nullable: gt_mask (H,W) fp32 labels in [0,num_obj],
  * used_count (num_obj+1,P) is ACCUMULATED into (caller zero-fills), contrib_num (H,W) int32,
  * proj_xy (P,2), gs_depth (P,). */

@@ -139,3 +139,46 @@ def test_fused_raw_step_equals_autograd_step():
     assert torch.equal(ma.denom, mb.denom)
     assert float((ma.xyz_gradient_accum - mb.xyz_gradient_accum).abs().max() / ma.xyz_gradient_accum.abs().max()) <= 2e-4
     assert torch.equal(ma.max_radii2D, mb.max_radii2D)
+
+
+def test_speculative_list_capacity_overflow_is_repeated():
+    """The fused forward sizes the per-tile list buffer from previous views and never syncs with the host;
+    when the guess is too small the view must be repeated, with the same result as a run whose guess held."""
+    from w3d_amd import fused_step
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    W, H = 160, 120
+    cams = [c.to(dev) for c in make_cameras(4, W, H)]
+    g = torch.Generator().manual_seed(1)
+    for cam in cams:
+        cam.original_image = torch.rand(3, H, W, generator=g).to(dev)
+    bg = torch.zeros(3, device=dev)
+    sc = make_scene(5000, seed=3, scale_mean=0.03)
+    finals, retries = [], []
+    for sabotage in (False, True):
+        m = GaussianModel(3, device=dev)
+        m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+        m.active_sh_degree = 3
+        opt = OptimizationParams()
+        m.training_setup(opt)
+        tr = Trainer(m, cams, opt, bg, densify=False)
+        calls = {"n": 0}
+        orig = fused_step.render_raw
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return orig(*a, **k)
+        fused_step.render_raw = counting
+        try:
+            for it in range(1, 5):
+                fused_step._capacity.known = 100 if sabotage else 10_000_000      # far too small / generous
+                tr.step(it)
+        finally:
+            fused_step.render_raw = orig
+        finals.append(m.flat.clone())
+        retries.append(calls["n"])
+    assert retries[0] == 4 and retries[1] == 8          # every sabotaged view was rendered twice
+    assert float((finals[0] - finals[1]).abs().max()) <= 1e-5
+    assert float(m.denom.max()) > 0

@@ -263,6 +263,8 @@ def test_duplicate_gaussians_tie_order():
 @pytest.mark.parametrize("num_obj", [1, 5])
 def test_flashsplat_parity(num_obj):
     from flashsplat_rasterization import GaussianRasterizer
+    import w3d_amd.rasterizer as wr
+    wr.TILE_CULL = True
     dev = torch.device("cuda:0")
     P, W, H = 600, 96, 80
     sc, cams = small_test_scene(P=P, W=W, H=H, seed=21)

@@ -165,8 +165,8 @@ int w3d_forward_stage2(const w3d_view *view, int32_t P, void *state, void *scrat
     char *st = static_cast<char *>(state), *sc = static_cast<char *>(scratch);
     rc = w3d_launch_fill_lists(L, *view, st, sc, point_list, list_capacity, stream);
     if (rc) return rc;
-    rc = w3d_launch_render(L, *view, st, point_list, out_color, out_depth, out_alpha, gt_mask, num_obj, used_count,
-                           contrib_num, stream);
+    rc = w3d_launch_render(L, *view, st, point_list, list_capacity, out_color, out_depth, out_alpha, gt_mask, num_obj,
+                           used_count, contrib_num, stream);
     if (rc) return rc;
     if (proj_xy || gs_depth) {
         // radii are not kept in the state; visibility is re-derived from the tile rectangle

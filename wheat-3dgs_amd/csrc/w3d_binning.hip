@@ -330,7 +330,9 @@ __global__ void copy_ranges_kernel(const uint32_t *__restrict__ tile_start, uint
 struct W3DBands { uint32_t rows, count, tbpad; };
 W3DBands w3d_pick_bands(const W3DLayout &L) {
     W3DBands b;
-    uint32_t rows = 1024u / (uint32_t)L.gx;          // ~1024 tiles per band
+    uint32_t band_tiles = 1024u;                     // ~1024 tiles per band
+    if (const char *e = getenv("W3D_TUNE_BAND_TILES")) band_tiles = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : band_tiles;
+    uint32_t rows = band_tiles / (uint32_t)L.gx;
     if (rows < 1) rows = 1;
     if (rows > (uint32_t)L.gy) rows = (uint32_t)L.gy;
     b.rows = rows;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/w3d.h"
 
@@ -25,7 +26,7 @@ struct W3DLayout {
     uint32_t C;       // number of chunks
     uint32_t seg;     // chunks per scan segment
     // ---- state buffer (kept until backward)
-    uint64_t o_counters;   // u32[16]: [0]=num_visible [1]=num_rendered [2]=error flags
+    uint64_t o_counters;   // u32[16]: [0]=num_visible [1]=num_rendered [3]=capacity of the list buffer given to stage 2
     uint64_t o_xy;         // float2[P]
     uint64_t o_conic_op;   // float4[P]
     uint64_t o_rgbd;       // float4[P]  (r,g,b,depth)
@@ -57,7 +58,9 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->T = L->gx * L->gy;
     if (L->gx > 65535 || L->gy > 65535) return W3D_ERR_UNSUPPORTED;
     uint64_t Pp = P > 0 ? (uint64_t)P : 1;
-    uint64_t chunk = (Pp + W3D_MAX_CHUNKS - 1) / W3D_MAX_CHUNKS;
+    uint64_t max_chunks = W3D_MAX_CHUNKS;
+    if (const char *e = getenv("W3D_TUNE_CHUNKS")) max_chunks = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : max_chunks;
+    uint64_t chunk = (Pp + max_chunks - 1) / max_chunks;
     chunk = (chunk + 63) / 64 * 64;
     if (chunk < 64) chunk = 64;
     if (chunk > W3D_CHUNK_MAX) chunk = W3D_CHUNK_MAX;
@@ -142,9 +145,9 @@ int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *me
 int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream);
 int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
                           uint64_t list_capacity, hipStream_t stream);
-int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const uint32_t *point_list, float *out_color,
-                      float *out_depth, float *out_alpha, const float *gt_mask, int32_t num_obj, float *used_count,
-                      int32_t *contrib_num, hipStream_t stream);
+int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const uint32_t *point_list, uint64_t list_capacity,
+                      float *out_color, float *out_depth, float *out_alpha, const float *gt_mask, int32_t num_obj,
+                      float *used_count, int32_t *contrib_num, hipStream_t stream);
 int w3d_launch_flash_extras(const W3DLayout &L, const w3d_view &v, const int32_t *radii_unused, char *state,
                             float *proj_xy, float *gs_depth, hipStream_t stream);
 int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char *state, const uint32_t *point_list,

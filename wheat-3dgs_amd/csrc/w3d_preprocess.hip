@@ -382,7 +382,11 @@ struct RawBwd {
 
 // RAW: shs/dL_dshs are the f_dc blocks, scales/rotations/opacity are pre-activation and the
 // gradients are chained through exp / normalize / sigmoid before being written.
-template <bool HAS_SH, bool HAS_SCALE_ROT, bool RAW>
+// FAST16 (16 SH coefficients, the only case Wheat-3DGS uses): the SH gradient rows of the workgroup's
+// 256 Gaussians are staged in LDS (row stride 49 floats: conflict-free) and written out as one
+// contiguous, fully coalesced span instead of 45-48 dword stores per lane at a 180/192-B stride.
+#define W3D_SHROW 49
+template <bool HAS_SH, bool HAS_SCALE_ROT, bool RAW, bool FAST16>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
                       const float *__restrict__ scales, const float *__restrict__ rotations,
@@ -392,8 +396,11 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
                       float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dcolors,
                       float *__restrict__ dL_dshs, float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
                       float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= P) return;
+    __shared__ float sh_stage[(HAS_SH && FAST16) ? 256 * W3D_SHROW : 1];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = gid < P;
+    if (!(HAS_SH && FAST16) && !active) return;
+    const int g = active ? gid : P - 1;       // FAST16: idle lanes of the last block still reach the barrier
     const int Mc = v.sh_coeffs;
     float inv_qnorm = 1.f;
     float q_act[4] = {1.f, 0.f, 0.f, 0.f}, s_act[3] = {0.f, 0.f, 0.f};
@@ -408,10 +415,14 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
     // coefficient k, channel c of the SH gradient: interleaved (P,M,3) or split dc | rest blocks
     float *dsh = HAS_SH ? (RAW ? dL_dshs + 3 * (size_t)g : dL_dshs + (size_t)g * Mc * 3) : nullptr;
     float *dsh_rest = (HAS_SH && RAW) ? raw.dL_df_rest + (size_t)g * (Mc - 1) * 3 : nullptr;
-#define DSH(k, c) (*((RAW && (k) > 0) ? (dsh_rest + 3 * ((k)-1) + (c)) : (dsh + 3 * (k) + (c))))
+#define DSH(k, c) (*(FAST16 ? (sh_stage + threadIdx.x * W3D_SHROW + 3 * (k) + (c)) \
+                            : ((RAW && (k) > 0) ? (dsh_rest + 3 * ((k)-1) + (c)) : (dsh + 3 * (k) + (c)))))
     if (!vis) {
         if (HAS_SH) {
-            if (RAW) {
+            if (FAST16) {
+#pragma unroll
+                for (int i = 0; i < 48; i++) sh_stage[threadIdx.x * W3D_SHROW + i] = 0.f;
+            } else if (RAW) {
                 dsh[0] = dsh[1] = dsh[2] = 0.f;
                 for (int i = 0; i < (Mc - 1) * 3; i++) dsh_rest[i] = 0.f;
             } else {
@@ -599,6 +610,21 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
         }
     }
 #undef DSH
+    if (HAS_SH && FAST16) {
+        // coalesced write-out of the block's SH gradient rows
+        __syncthreads();
+        const size_t g0 = (size_t)blockIdx.x * 256;
+        const int rows = (int)min((size_t)256, (size_t)P - g0);
+        if (RAW) {
+            float *ddc = dL_dshs + g0 * 3, *drest = raw.dL_df_rest + g0 * 45;
+            for (int e = threadIdx.x; e < rows * 3; e += 256) ddc[e] = sh_stage[(e / 3) * W3D_SHROW + e % 3];
+            for (int e = threadIdx.x; e < rows * 45; e += 256) drest[e] = sh_stage[(e / 45) * W3D_SHROW + 3 + e % 45];
+        } else {
+            float *dall = dL_dshs + g0 * 48;
+            for (int e = threadIdx.x; e < rows * 48; e += 256) dall[e] = sh_stage[(e / 48) * W3D_SHROW + e % 48];
+        }
+        if (!active) return;
+    }
     if (RAW) {
         // chain through the activations: s = exp(ls), o = sigmoid(lo), q = r / |r|
         dscale[0] *= s_act[0]; dscale[1] *= s_act[1]; dscale[2] *= s_act[2];
@@ -690,7 +716,12 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
         raw.denom = rawargs->denom; raw.max_radii = rawargs->max_radii;
     }
 #define LAUNCH(A, B, C)                                                                                                  \
-    hipLaunchKernelGGL((preprocess_bwd_kernel<A, B, C>), dim3(grid), dim3(block), 0, stream, v, L.P, means3D, shs, scales, \
+    if (A && v.sh_coeffs == 16)                                                                                          \
+        LAUNCH2(A, B, C, true);                                                                                          \
+    else                                                                                                                 \
+        LAUNCH2(A, B, C, false)
+#define LAUNCH2(A, B, C, D)                                                                                              \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<A, B, C, D>), dim3(grid), dim3(block), 0, stream, v, L.P, means3D, shs, scales, \
                        rotations, cov3D_precomp, raw, reinterpret_cast<const ushort4 *>(state + L.o_rect),               \
                        reinterpret_cast<const uint8_t *>(state + L.o_clamped), grad2d, dL_dmeans3D, dL_dmeans2D,         \
                        dL_dcolors, dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
@@ -701,6 +732,7 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
     else if (has_sr) LAUNCH(false, true, false);
     else LAUNCH(false, false, false);
 #undef LAUNCH
+#undef LAUNCH2
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;
 }

@@ -89,11 +89,14 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_alpha,
                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                   const float *__restrict__ gt_mask, int num_obj, int P, float *__restrict__ used_count,
-                  int32_t *__restrict__ contrib_num) {
+                  int32_t *__restrict__ contrib_num, uint32_t list_cap, uint32_t *__restrict__ counters) {
     __shared__ StagedLDS lds[4];
     __shared__ int s_labels[4][FLASH ? 256 : 1];
     uint32_t tile;
     if (!wave_to_tile(T, tile)) return;
+    // the list buffer may be smaller than the lists (speculative sizing, see w3d_forward_stage2): never read
+    // past it; the capacity is published for the backward pass
+    if (tile == 0 && (threadIdx.x & 63) == 0) counters[3] = list_cap;
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     StagedLDS &s = lds[wv];
     const uint32_t tx0 = (tile % gx) * W3D_TILE, ty0 = (tile / gx) * W3D_TILE;
@@ -135,7 +138,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         }
         __builtin_amdgcn_wave_barrier();
     }
-    const uint32_t start = tile_start[tile], end = tile_start[tile + 1];
+    const uint32_t start = min(tile_start[tile], list_cap), end = min(tile_start[tile + 1], list_cap);
     for (uint32_t base = start; base < end; base += 64) {
         if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
         const uint32_t n = min(64u, end - base);
@@ -238,7 +241,8 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   const float4 *__restrict__ conic_op, const float4 *__restrict__ rgbd, const float *__restrict__ bg,
                   const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                   const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
-                  const float *__restrict__ dL_dalpha_px, float *__restrict__ grad2d) {
+                  const float *__restrict__ dL_dalpha_px, float *__restrict__ grad2d,
+                  const uint32_t *__restrict__ counters) {
     __shared__ StagedLDS lds[4];
     uint32_t tile;
     if (!wave_to_tile(T, tile)) return;
@@ -276,7 +280,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     }
     maxc = wave_max_u32(maxc);
     if (maxc == 0) return;
-    const uint32_t start = tile_start[tile];
+    const uint32_t start = min(tile_start[tile], counters[3]);
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const bool has_bg = (bg0 != 0.f) || (bg1 != 0.f) || (bg2 != 0.f);     // wave-uniform: black background skips the term
     const int nb = (int)((maxc + 63) / 64);
@@ -385,9 +389,9 @@ __global__ void copy_pixel_state_kernel(const float *__restrict__ fT, const uint
 
 }  // namespace
 
-int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const uint32_t *point_list, float *out_color,
-                      float *out_depth, float *out_alpha, const float *gt_mask, int32_t num_obj, float *used_count,
-                      int32_t *contrib_num, hipStream_t stream) {
+int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const uint32_t *point_list, uint64_t list_capacity,
+                      float *out_color, float *out_depth, float *out_alpha, const float *gt_mask, int32_t num_obj,
+                      float *used_count, int32_t *contrib_num, hipStream_t stream) {
     const uint32_t T = (uint32_t)L.T;
     uint32_t blocks = (T + 3) / 4;
     blocks = (blocks + 7) / 8 * 8;   // the XCD-contiguous map needs a multiple of 8 blocks
@@ -397,7 +401,8 @@ int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const 
         reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_conic_op),     \
         reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg, out_color, out_depth, out_alpha,                    \
         reinterpret_cast<float *>(state + L.o_final_T), reinterpret_cast<uint32_t *>(state + L.o_n_contrib), gt_mask, \
-        num_obj, L.P, used_count, contrib_num
+        num_obj, L.P, used_count, contrib_num, (uint32_t)(list_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : list_capacity),      \
+        reinterpret_cast<uint32_t *>(state + L.o_counters)
     {
         W3D_PROF("render_fwd", stream);
         if (flash) hipLaunchKernelGGL(render_fwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, ARGS);
@@ -424,7 +429,7 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
         reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_conic_op), \
         reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg,                                                 \
         reinterpret_cast<const float *>(state + L.o_final_T), reinterpret_cast<const uint32_t *>(state + L.o_n_contrib), \
-        dL_dcolor, dL_ddepth, dL_dalpha, grad2d
+        dL_dcolor, dL_ddepth, dL_dalpha, grad2d, reinterpret_cast<const uint32_t *>(state + L.o_counters)
     {
         W3D_PROF("render_bwd", stream);
         if (dL_ddepth || dL_dalpha) hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(blocks), dim3(256), 0, stream, ARGS);

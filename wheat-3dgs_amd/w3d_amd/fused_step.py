@@ -44,9 +44,47 @@ def _raw_params(model):
     return p
 
 
-def render_raw(cam, model, bg_color, scaling_modifier=1.0):
+class ListCapacity:
+    """Speculative sizing of the per-tile list buffer so that the forward needs NO host sync.
+
+    The list length R (= num_rendered) is only known on the device after stage 1.  The synchronous path
+    copies it to the host and waits (one pipeline bubble per view).  Here the list is allocated from the
+    largest R seen so far (x `slack`); stage 2 is enqueued immediately; R travels to pinned host memory
+    with an async copy + event, and `finish()` — called after the backward has been enqueued, so the GPU
+    always has work queued — reports whether the guess held.  The fill kernel never writes past the
+    capacity it was given; on overflow the caller grows the capacity and repeats the view."""
+
+    def __init__(self, slack=1.25):
+        self.slack = slack
+        self.known = 0          # largest R observed
+
+    def guess(self):
+        return int(self.known * self.slack) + 1024 if self.known else 0
+
+    def observe(self, R):
+        self.known = max(self.known, int(R))
+
+
+_capacity = ListCapacity()
+
+
+def finish(handle):
+    """Wait for the counters of an asynchronous forward; True if the list capacity sufficed."""
+    pend = handle.get("pending")
+    if pend is None:
+        return True
+    pinned, ev = pend
+    ev.synchronize()
+    handle["num_visible"], handle["num_rendered"] = int(pinned[0]), int(pinned[1])
+    handle["pending"] = None
+    _capacity.observe(handle["num_rendered"])
+    return handle["num_rendered"] <= handle["capacity"]
+
+
+def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True):
     """Forward on the raw parameters.  Returns the dict of render() (minus viewspace_points) plus a
-    `handle` for backward_raw()."""
+    `handle` for backward_raw().  sync=False: no host synchronisation (see ListCapacity); the caller
+    must call finish(handle) before trusting the outputs."""
     dev = model.flat.device
     if not model.flat.is_cuda:
         raise RuntimeError("the fused step needs the model on the GPU; there is no CPU path")
@@ -64,17 +102,31 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0):
         state = torch.empty(sb.value, dtype=torch.uint8, device=dev)
         scratch = torch.empty(tb.value, dtype=torch.uint8, device=dev)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
-        counts = (ctypes.c_uint32 * 2)()
-        check(lib.w3d_forward_stage1_raw(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(radii), ptr(state),
-                                         ptr(scratch), ctypes.cast(counts, _vp), stream))
-        R = int(counts[1])
+        guess = 0 if sync else _capacity.guess()
+        pending = None
+        if guess == 0:
+            counts = (ctypes.c_uint32 * 2)()
+            check(lib.w3d_forward_stage1_raw(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(radii), ptr(state),
+                                             ptr(scratch), ctypes.cast(counts, _vp), stream))
+            R, V = int(counts[1]), int(counts[0])
+            _capacity.observe(R)
+        else:
+            check(lib.w3d_forward_stage1_raw(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(radii), ptr(state),
+                                             ptr(scratch), None, stream))
+            pinned = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            pinned.copy_(state[:8].view(torch.int32), non_blocking=True)     # counters sit at offset 0 of the state
+            ev = torch.cuda.Event()
+            ev.record()
+            pending = (pinned, ev)
+            R, V = guess, -1
         plist = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
         alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
         check(lib.w3d_forward_stage2(ctypes.byref(view.c), P, ptr(state), ptr(scratch), ptr(plist), ctypes.c_uint64(R),
                                      ptr(color), ptr(depth), ptr(alpha), None, 0, None, None, None, None, stream))
-    handle = dict(view=view, P=P, state=state, point_list=plist, radii=radii, num_rendered=R, num_visible=int(counts[0]))
+    handle = dict(view=view, P=P, state=state, point_list=plist, radii=radii, num_rendered=R, num_visible=V,
+                  capacity=R, pending=pending)
     return {"render": color, "radii": radii, "depth": depth, "alpha": alpha, "handle": handle}
 
 

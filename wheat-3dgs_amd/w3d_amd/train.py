@@ -102,18 +102,29 @@ class Trainer:
         raw-parameter backward writing the flat gradient bucket and — on one GPU — the
         densification statistics.  No autograd graph is built."""
         from .fused import l1_ssim_fwd_bwd
-        from .fused_step import backward_raw, render_raw
+        from .fused_step import backward_raw, finish, render_raw
         m, opt = self.model, self.opt
         m.update_learning_rate(iteration)
         if iteration % 1000 == 0:
             m.oneupSHdegree()
         cam = self.camera_for(iteration)
         with torch.no_grad():
-            pkg = render_raw(cam, m, self.bg)
-            loss, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
             tracking = iteration < opt.densify_until_iter
             single = self.world == 1
-            gnorm, _ = backward_raw(m, pkg["handle"], dimg, update_stats=(tracking and single), want_norm=not single)
+            # statistics are updated inside the backward kernel only when the list-capacity guess is known to
+            # hold (synchronous forward); with the speculative forward they are applied after finish()
+            fused_stats = False
+            while True:
+                pkg = render_raw(cam, m, self.bg, sync=False)
+                loss, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
+                gnorm, _ = backward_raw(m, pkg["handle"], dimg, update_stats=fused_stats, want_norm=True)
+                if finish(pkg["handle"]):        # the only host wait of the step, with the backward already queued
+                    break
+            if single and tracking:
+                vis = pkg["radii"] > 0
+                m.xyz_gradient_accum += gnorm[:, None]          # gnorm is 0 on culled Gaussians
+                m.denom += vis[:, None]
+                m.max_radii2D = torch.max(m.max_radii2D, pkg["radii"].to(m.max_radii2D.dtype))
             if not single:
                 vis = pkg["radii"] > 0
                 nsum, vcount, rmax = self.exchange(gnorm, vis, pkg["radii"])
@@ -153,7 +164,13 @@ def render_views(model, cameras, background, pipe=None):
     """Forward-only rendering of a list of views (what reference render.py:24-35 times)."""
     pipe = pipe or PipelineParams()
     out = []
+    raw = (hasattr(model, "flat") and model.flat.is_cuda and not pipe.convert_SHs_python
+           and not pipe.compute_cov3D_python)
     with torch.no_grad():
         for cam in cameras:
-            out.append(render(cam, model, pipe, background)["render"])
+            if raw:      # pre-activation parameters straight into the kernels (no exp/sigmoid/normalize/cat launches)
+                from .fused_step import render_raw
+                out.append(render_raw(cam, model, background)["render"])
+            else:
+                out.append(render(cam, model, pipe, background)["render"])
     return out
