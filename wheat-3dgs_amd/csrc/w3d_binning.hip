@@ -28,20 +28,20 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x
 __global__ void __launch_bounds__(256)
 radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items, uint32_t n_runs, int shift,
                   uint32_t *__restrict__ hist /* [256][n_runs] */) {
-    __shared__ uint32_t h_all[4][256];
+    __shared__ uint32_t h_all[4][W3D_RADIX_BINS];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
     uint32_t *h = h_all[wv];
-    for (int i = lane; i < 256; i += 64) h[i] = 0;
+    for (int i = lane; i < W3D_RADIX_BINS; i += 64) h[i] = 0;
     __builtin_amdgcn_wave_barrier();
     if (run < n_runs) {
         const uint32_t beg = run * items, end = min(n, beg + items);
         for (uint32_t i = beg + lane; i < end; i += 64) {
-            const uint32_t d = (keys[i] >> shift) & 255u;
+            const uint32_t d = (keys[i] >> shift) & (W3D_RADIX_BINS - 1u);
             atomicAdd(const_cast<uint32_t *>(&h_all[wv][d]), 1u);
         }
         __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < 256; i += 64) hist[(size_t)i * n_runs + run] = h[i];
+        for (int i = lane; i < W3D_RADIX_BINS; i += 64) hist[(size_t)i * n_runs + run] = h[i];
     }
 }
 
@@ -96,25 +96,33 @@ __global__ void __launch_bounds__(256)
 radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                      uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t items,
                      uint32_t n_runs, int shift, const uint32_t *__restrict__ offs /* row-scanned [256][n_runs] */,
-                     const uint32_t *__restrict__ rowtot /* [256] */, uint32_t *__restrict__ num_visible) {
-    __shared__ uint32_t cur_all[4][256];
+                     const uint32_t *__restrict__ rowtot /* [BINS] */, uint32_t *__restrict__ num_visible) {
+    __shared__ uint32_t cur_all[4][W3D_RADIX_BINS];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
     if (run >= n_runs) return;
     uint32_t *cur = cur_all[wv];
     {
-        // digit bases = exclusive scan of the 256 row totals, 4 digits per lane
-        const uint4 t4 = reinterpret_cast<const uint4 *>(rowtot)[lane];
-        const uint32_t lsum = t4.x + t4.y + t4.z + t4.w;
-        const uint32_t ex = wave_inclusive_scan(lsum) - lsum;
-        const uint32_t b0 = ex, b1 = b0 + t4.x, b2 = b1 + t4.y, b3 = b2 + t4.z;
-        cur[4 * lane + 0] = b0 + offs[(size_t)(4 * lane + 0) * n_runs + run];
-        cur[4 * lane + 1] = b1 + offs[(size_t)(4 * lane + 1) * n_runs + run];
-        cur[4 * lane + 2] = b2 + offs[(size_t)(4 * lane + 2) * n_runs + run];
-        cur[4 * lane + 3] = b3 + offs[(size_t)(4 * lane + 3) * n_runs + run];
-        // depth keys are positive floats (top byte < 0x80); culled Gaussians carry 0xFFFFFFFF:
-        // in the last pass the base of digit 128 is the number of visible Gaussians.
-        if (num_visible && run == 0 && lane == 32) *num_visible = b0;
+        // digit bases = exclusive scan of the row totals, BINS/64 consecutive digits per lane
+        constexpr int PER = W3D_RADIX_BINS / 64;
+        uint32_t tot[PER];
+        uint32_t lsum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; i += 4) {
+            const uint4 t4 = reinterpret_cast<const uint4 *>(rowtot)[(lane * PER + i) / 4];
+            tot[i] = t4.x; tot[i + 1] = t4.y; tot[i + 2] = t4.z; tot[i + 3] = t4.w;
+            lsum += t4.x + t4.y + t4.z + t4.w;
+        }
+        uint32_t base = wave_inclusive_scan(lsum) - lsum;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const uint32_t d = lane * PER + i;
+            cur[d] = base + offs[(size_t)d * n_runs + run];
+            // depth keys are positive floats (top bit clear); culled Gaussians carry 0xFFFFFFFF: in the last
+            // pass the base of the first digit with the top key bit set is the number of visible Gaussians.
+            if (num_visible && run == 0 && d == (1u << (31 - W3D_RADIX_BITS * (W3D_RADIX_PASSES - 1)))) *num_visible = base;
+            base += tot[i];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t beg = run * items, end = min(n, beg + items);
@@ -124,11 +132,11 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
         const bool valid = i < end;
         const uint32_t key = valid ? keys_in[i] : 0u;
         const uint32_t val = valid ? vals_in[i] : 0u;
-        const uint32_t d = (key >> shift) & 255u;
+        const uint32_t d = (key >> shift) & (W3D_RADIX_BINS - 1u);
         // lanes holding the same digit (stable rank = number of such lanes below me)
         uint64_t peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < W3D_RADIX_BITS; b++) {
             const uint64_t m = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
@@ -353,30 +361,32 @@ int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state
     uint32_t *part = reinterpret_cast<uint32_t *>(scratch + L.s_part);
     uint32_t *off = reinterpret_cast<uint32_t *>(scratch + L.s_off);
     const uint32_t T = (uint32_t)L.T;
+    const uint32_t *sorted_ids = vals[0];
     if (L.P > 0) {
-        // ---- stable LSD radix sort of (depth bits, id), 4 x 8 bits; culled Gaussians carry key 0xFFFFFFFF
+        // ---- stable LSD radix sort of (depth bits, id), PASSES x BITS bits; culled Gaussians carry key 0xFFFFFFFF
         const uint32_t n = (uint32_t)L.P, runs = L.sort_waves, blocks = (runs + 3) / 4;
         int src = 0;
         W3D_PROF("depth_sort", stream);
-        for (int pass = 0; pass < 4; pass++) {
-            const int shift = 8 * pass;
+        for (int pass = 0; pass < W3D_RADIX_PASSES; pass++) {
+            const int shift = W3D_RADIX_BITS * pass;
             hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], n, L.sort_items, runs, shift, hist);
             W3D_LAUNCH_CHECK(v.debug, stream);
-            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, stream, hist, runs, rowtot);
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(W3D_RADIX_BINS), dim3(256), 0, stream, hist, runs, rowtot);
             W3D_LAUNCH_CHECK(v.debug, stream);
             hipLaunchKernelGGL(radix_scatter_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], vals[src], keys[src ^ 1],
-                               vals[src ^ 1], n, L.sort_items, runs, shift, hist, rowtot, pass == 3 ? counters : (uint32_t *)nullptr);
+                               vals[src ^ 1], n, L.sort_items, runs, shift, hist, rowtot,
+                               pass == W3D_RADIX_PASSES - 1 ? counters : (uint32_t *)nullptr);
             W3D_LAUNCH_CHECK(v.debug, stream);
             src ^= 1;
         }
-        // after 4 passes the sorted ids are back in vals[0]
+        sorted_ids = vals[src];
     }
     // ---- per-chunk per-tile counts
     const W3DBands bands = w3d_pick_bands(L);
     W3D_PROF("tile_count_scan", stream);
 #define WALK_ARGS(ids) reinterpret_cast<const uint4 *>(scratch + L.s_rec), reinterpret_cast<const uint2 *>(scratch + L.s_rec_mask)
     if (L.P > 0) {
-        hipLaunchKernelGGL(gather_sorted_kernel, dim3((L.P + 255) / 256), dim3(256), 0, stream, vals[0],
+        hipLaunchKernelGGL(gather_sorted_kernel, dim3((L.P + 255) / 256), dim3(256), 0, stream, sorted_ids,
                            reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint2 *>(state + L.o_tile_mask),
                            counters, (uint32_t)L.P, reinterpret_cast<uint4 *>(scratch + L.s_rec),
                            reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);

@@ -15,7 +15,10 @@
 // Upper bounds of the binning geometry (see w3d_binning.hip).
 #define W3D_MAX_CHUNKS 2048       // depth-contiguous chunks of Gaussians, one wave each
 #define W3D_CHUNK_MAX 65472       // per-chunk Gaussian count must fit a u16 counter (multiple of 64)
-#define W3D_SCAN_SEGS 16          // segments of the chunk axis in the offset scan
+#define W3D_SCAN_SEGS 16
+#define W3D_RADIX_BITS 8          // depth sort: 4 LSD passes of 8 bits (measured: 3 x 11 bits is slower — the
+#define W3D_RADIX_BINS (1 << W3D_RADIX_BITS)   // runs x bins histogram matrix grows 8x and dominates)
+#define W3D_RADIX_PASSES 4          // segments of the chunk axis in the offset scan
 
 static inline uint64_t w3d_align_up(uint64_t x, uint64_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -39,8 +42,8 @@ struct W3DLayout {
     uint64_t state_bytes;
     // ---- scratch buffer (forward temporaries)
     uint64_t s_keys0, s_keys1, s_vals0, s_vals1; // u32[P] each (depth keys, Gaussian ids)
-    uint64_t s_hist;       // u32[256 * sort_waves] radix digit histograms
-    uint64_t s_rowtot;     // u32[256] per-digit totals of the current radix pass
+    uint64_t s_hist;       // u32[BINS * sort_waves] radix digit histograms
+    uint64_t s_rowtot;     // u32[BINS] per-digit totals of the current radix pass
     uint64_t s_cnt;        // u16[C*T] per-chunk per-tile counts
     uint64_t s_off;        // u32[C*T] per-chunk per-tile list offsets
     uint64_t s_part;       // u32[SEGS*T]
@@ -81,7 +84,9 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->o_n_contrib = o;  o += w3d_align_up(HW * 4);
     L->state_bytes = o;
     // radix sort geometry: one wave per contiguous run of sort_items keys
-    uint64_t items = (Pp + 2047) / 2048;         // aim at <= 2048 waves
+    uint64_t max_runs = 2048;                    // aim at <= 2048 waves
+    if (const char *e = getenv("W3D_TUNE_SORT_RUNS")) max_runs = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : max_runs;
+    uint64_t items = (Pp + max_runs - 1) / max_runs;
     items = (items + 63) / 64 * 64;
     if (items < 1024) items = 1024;
     L->sort_items = (uint32_t)items;
@@ -91,8 +96,8 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->s_keys1 = o; o += w3d_align_up(Pp * 4);
     L->s_vals0 = o; o += w3d_align_up(Pp * 4);
     L->s_vals1 = o; o += w3d_align_up(Pp * 4);
-    L->s_hist = o;  o += w3d_align_up((uint64_t)256 * L->sort_waves * 4);
-    L->s_rowtot = o; o += w3d_align_up(256 * 4);
+    L->s_hist = o;  o += w3d_align_up((uint64_t)W3D_RADIX_BINS * L->sort_waves * 4);
+    L->s_rowtot = o; o += w3d_align_up(W3D_RADIX_BINS * 4);
     L->s_cnt = o;   o += w3d_align_up((uint64_t)L->C * T * 2);
     L->s_off = o;   o += w3d_align_up((uint64_t)L->C * T * 4);
     L->s_part = o;  o += w3d_align_up((uint64_t)W3D_SCAN_SEGS * T * 4);
