@@ -70,6 +70,12 @@ typedef struct w3d_view {
                               * 1: additionally drop (Gaussian, tile) instances whose footprint provably
                               * cannot reach alpha >= 1/255 on any pixel of the tile — identical images and
                               * gradients, about half the list entries */
+    int32_t depth_layers;    /* 0/1: bin every visible Gaussian, blend in one pass.  2: bin and blend the front
+                              * ~28 % of the depth-ordered Gaussians first, then bin the rest only into tiles
+                              * that are still open (not every pixel saturated) and resume them — identical
+                              * outputs; since saturated tiles are the norm in dense scenes most of the binning
+                              * work disappears.  Needs the asynchronous forward (counts_host == NULL): the total
+                              * list length is only known after the front layer has been blended. */
 } w3d_view;
 
 int w3d_version(void);

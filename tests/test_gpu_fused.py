@@ -180,5 +180,45 @@ def test_speculative_list_capacity_overflow_is_repeated():
         finals.append(m.flat.clone())
         retries.append(calls["n"])
     assert retries[0] == 4 and retries[1] == 8          # every sabotaged view was rendered twice
-    assert float((finals[0] - finals[1]).abs().max()) <= 1e-5
+    # same parameters after 4 Adam steps (float-atomic ordering noise can flip the sign of a near-zero
+    # gradient, which Adam turns into a 2*lr difference on that element: bound the bulk tightly, the max loosely)
+    diff = (finals[0] - finals[1]).abs()
+    assert float((diff > 1e-5).float().mean()) <= 1e-3 and float(diff.max()) <= 0.2
     assert float(m.denom.max()) > 0
+
+
+def test_depth_layered_forward_is_bit_identical_and_backward_matches():
+    """depth_layers = 2 (front layer, then only the still-open tiles) against the single-pass forward:
+    same bits in every output image and in the per-pixel state, same gradients up to atomic ordering."""
+    from w3d_amd import fused_step
+    from w3d_amd.fused_step import render_raw, backward_raw, finish
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    dev = torch.device("cuda:0")
+    for (P, W, H, scale) in ((40_000, 320, 240, 0.012), (3000, 200, 152, 0.05), (300_000, 800, 600, 0.006)):
+        cams = [c.to(dev) for c in make_cameras(3, W, H)]
+        sc = make_scene(P, seed=P, scale_mean=scale)
+        m = GaussianModel(3, device=dev)
+        m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+        m.active_sh_degree = 3
+        m.training_setup(OptimizationParams())
+        bg = torch.tensor([0.2, 0.1, 0.0], device=dev)
+        g = torch.Generator().manual_seed(P)
+        dimg = torch.randn(3, H, W, generator=g).to(dev)
+        for cam in cams[:2]:
+            ref = render_raw(cam, m, bg, sync=True)                       # single pass, exact list size
+            backward_raw(m, ref["handle"], dimg)
+            gref = m.flat_grad.clone()
+            fused_step._capacity.known = ref["handle"]["num_rendered"]   # generous guess -> async + layered
+            fused_step.DEPTH_LAYERS = True
+            lay = render_raw(cam, m, bg, sync=False)
+            assert lay["handle"]["view"].c.depth_layers == 2
+            backward_raw(m, lay["handle"], dimg)
+            assert finish(lay["handle"])
+            glay = m.flat_grad.clone()
+            for k in ("render", "depth", "alpha", "radii"):
+                assert torch.equal(ref[k], lay[k]), k
+            # the layered forward bins fewer instances (closed tiles drop out of the back layer)
+            assert lay["handle"]["num_rendered"] <= ref["handle"]["num_rendered"]
+            err = float((glay - gref).abs().max() / gref.abs().max())
+            assert err <= 1e-4, err

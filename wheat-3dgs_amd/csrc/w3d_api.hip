@@ -73,6 +73,23 @@ static int check_variants(const w3d_view *v, const float *shs, const float *colo
     return W3D_OK;
 }
 
+// depth sort, tile counting of the first (or only) layer, optional host read-back of the counters
+static int finish_stage1(const W3DLayout &L, const w3d_view &view, char *st, char *sc, uint32_t *counts_host, hipStream_t stream) {
+    if (view.depth_layers == 2 && counts_host) {
+        w3d_set_error("depth_layers = 2 needs the asynchronous forward (counts_host must be NULL)");
+        return W3D_ERR_INVALID;
+    }
+    int rc = w3d_launch_depth_sort(L, view, st, sc, stream);
+    if (rc) return rc;
+    rc = w3d_launch_tile_count(L, view, st, sc, view.depth_layers == 2 ? 1 : 0, stream);
+    if (rc) return rc;
+    if (counts_host) {
+        W3D_HIP_CHECK(hipMemcpyAsync(counts_host, st + L.o_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        W3D_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    return W3D_OK;
+}
+
 extern "C" {
 
 int w3d_version(void) { return 100; }
@@ -140,13 +157,8 @@ int w3d_forward_stage1(const w3d_view *view, int32_t P, const float *means3D, co
     rc = w3d_launch_preprocess(L, *view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii,
                                st, sc, nullptr, stream);
     if (rc) return rc;
-    rc = w3d_launch_sort_and_count(L, *view, st, sc, stream);
-    if (rc) return rc;
-    if (counts_host) {
-        W3D_HIP_CHECK(hipMemcpyAsync(counts_host, st + L.o_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        W3D_HIP_CHECK(hipStreamSynchronize(stream));
-    }
-    return W3D_OK;
+    rc = finish_stage1(L, *view, st, sc, counts_host, stream);
+    return rc;
 }
 
 int w3d_forward_stage2(const w3d_view *view, int32_t P, void *state, void *scratch, uint32_t *point_list,
@@ -163,10 +175,27 @@ int w3d_forward_stage2(const w3d_view *view, int32_t P, void *state, void *scrat
     if (list_capacity > 0 && !point_list) { w3d_set_error("point_list is NULL"); return W3D_ERR_INVALID; }
     if (gt_mask && used_count && num_obj < 0) { w3d_set_error("num_obj must be >= 0"); return W3D_ERR_INVALID; }
     char *st = static_cast<char *>(state), *sc = static_cast<char *>(scratch);
-    rc = w3d_launch_fill_lists(L, *view, st, sc, point_list, list_capacity, stream);
+    const bool flash = gt_mask || used_count || contrib_num || proj_xy || gs_depth;
+    if (view->depth_layers == 2 && !flash) {
+        // front layer, then only the tiles it left open
+        for (int layer = 1; layer <= 2; layer++) {
+            if (layer == 2) {
+                rc = w3d_launch_tile_count(L, *view, st, sc, 2, stream);
+                if (rc) return rc;
+            }
+            rc = w3d_launch_fill_lists(L, *view, st, sc, point_list, list_capacity, layer, stream);
+            if (rc) return rc;
+            rc = w3d_launch_render(L, *view, st, point_list, list_capacity, out_color, out_depth, out_alpha, nullptr, 0,
+                                   nullptr, nullptr, layer, stream);
+            if (rc) return rc;
+        }
+        return W3D_OK;
+    }
+    if (view->depth_layers == 2) { w3d_set_error("depth_layers = 2 is not available for the FlashSplat outputs"); return W3D_ERR_UNSUPPORTED; }
+    rc = w3d_launch_fill_lists(L, *view, st, sc, point_list, list_capacity, 0, stream);
     if (rc) return rc;
     rc = w3d_launch_render(L, *view, st, point_list, list_capacity, out_color, out_depth, out_alpha, gt_mask, num_obj,
-                           used_count, contrib_num, stream);
+                           used_count, contrib_num, 0, stream);
     if (rc) return rc;
     if (proj_xy || gs_depth) {
         // radii are not kept in the state; visibility is re-derived from the tile rectangle
@@ -240,13 +269,7 @@ int w3d_forward_stage1_raw(const w3d_view *view, int32_t P, const w3d_raw_params
                                prm ? prm->opacity : nullptr, prm ? prm->scaling : nullptr, prm ? prm->rotation : nullptr,
                                nullptr, radii, st, sc, prm ? prm->f_rest : nullptr, stream);
     if (rc) return rc;
-    rc = w3d_launch_sort_and_count(L, *view, st, sc, stream);
-    if (rc) return rc;
-    if (counts_host) {
-        W3D_HIP_CHECK(hipMemcpyAsync(counts_host, st + L.o_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        W3D_HIP_CHECK(hipStreamSynchronize(stream));
-    }
-    return W3D_OK;
+    return finish_stage1(L, *view, st, sc, counts_host, stream);
 }
 
 int w3d_backward_raw(const w3d_view *view, int32_t P, const w3d_raw_params *prm, const void *state,

@@ -175,13 +175,16 @@ gather_sorted_kernel(const uint32_t *__restrict__ sorted_ids, const uint2 *__res
     rec_mask[s] = cull ? tile_mask[g] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
 }
 
-template <int MODE, bool CULL>
+// LAYER 0: all chunks.  LAYER 1 / 2: front / back depth layer (chunk ranges in counters[4..7], see
+// layer_split_kernel); the back layer only bins into tiles that are still open after the front layer was
+// blended (tile_open), and Gaussians none of whose tiles is open never enter the serial loop.
+template <int MODE, bool CULL, int LAYER>
 __global__ void __launch_bounds__(256)
 chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_mask,
                   const uint32_t *__restrict__ counters,
                   uint32_t chunk, uint32_t C, uint32_t T, uint32_t gx, uint32_t gy, uint32_t band_rows,
                   uint16_t *__restrict__ cnt, const uint32_t *__restrict__ off, uint32_t *__restrict__ point_list,
-                  uint64_t capacity) {
+                  uint64_t capacity, const uint8_t *__restrict__ tile_open) {
     // blockIdx.y = band of tile rows this wave is responsible for: the LDS array only spans the band
     // (a few KB, so 8 waves per SIMD fit), and Gaussians whose rect misses the band are compacted
     // away BEFORE the serial loop, so the serial work per wave shrinks with the band height while
@@ -190,6 +193,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t c = blockIdx.x * 4 + wv;
     if (c >= C) return;
+    if (LAYER != 0 && (c < counters[2 + 2 * LAYER] || c >= counters[3 + 2 * LAYER])) return;
     const uint32_t y0 = blockIdx.y * band_rows, y1 = min(gy, y0 + band_rows);
     const uint32_t tb0 = y0 * gx, Tb = (y1 - y0) * gx;           // first tile / tile count of the band
     const uint32_t Tbpad = (band_rows * gx + 63u) & ~63u;
@@ -200,6 +204,10 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
     // around every access and serialise the loop on the latency of the previous list store.
     uint16_t *h16 = reinterpret_cast<uint16_t *>(smem) + (size_t)wv * Tbpad;
     uint32_t *h32 = reinterpret_cast<uint32_t *>(smem) + (size_t)wv * Tbpad;
+    // LAYER 2: one byte per tile of the band, 1 = still open (placed behind the 4 waves' counter arrays)
+    uint8_t *open8 = smem + (size_t)4 * Tbpad * (MODE == 0 ? 2 : 4) + (size_t)wv * Tbpad;
+    if (LAYER == 2)
+        for (uint32_t t = lane; t < Tb; t += 64) open8[t] = tile_open[tb0 + t];
     if (MODE == 0) {
         for (uint32_t t = lane; t < Tbpad; t += 64) h16[t] = 0;
     } else {
@@ -243,6 +251,17 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
             my_w = maxx - minx;
             my_n = my_w * (maxy - miny);
             my_magic = 65536u / max(my_w, 1u) + 1u;              // floor(k / w) == (k * magic) >> 16 for k < 64, w <= 64
+            if (LAYER == 2 && relevant && my_n <= 64u) {
+                // vectorised pre-filter: does this Gaussian reach ANY open tile of the band?
+                bool any_open = false;
+                const uint64_t m64 = (uint64_t)my_mask.x | ((uint64_t)my_mask.y << 32);
+                for (uint32_t k = 0; k < my_n && !any_open; k++) {
+                    const uint32_t ty = __umul24(k, my_magic) >> 16, row = miny + ty;
+                    if (((m64 >> k) & 1ull) && row >= y0 && row < y1)
+                        any_open = open8[__umul24(row - y0, gx) + minx + (k - __umul24(ty, my_w))] != 0;
+                }
+                relevant = any_open;
+            }
         }
         uint64_t todo = __ballot(relevant);
         while (todo) {
@@ -256,15 +275,20 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                 const uint32_t ty = __umul24(lane, mg) >> 16;
                 const uint32_t tx = lane - __umul24(ty, w);
                 const uint32_t row = miny + ty;
-                const bool hit = lane < n0 && ((mask >> lane) & 1ull) && row >= y0 && row < y1;
-                touch(hit, __umul24(row - y0, gx) + minx + tx, g);
+                bool hit = lane < n0 && ((mask >> lane) & 1ull) && row >= y0 && row < y1;
+                const uint32_t tl = __umul24(row - y0, gx) + minx + tx;
+                if (LAYER == 2 && hit) hit = open8[tl] != 0;
+                touch(hit, tl, g);
             } else {
                 // big footprint (> 64 tiles): never culled, generic division
                 for (uint32_t kb = 0; kb < n0; kb += 64) {
                     const uint32_t k = kb + lane;
                     const uint32_t ty = k / w, tx = k - ty * w;
                     const uint32_t row = miny + ty;
-                    touch(k < n0 && row >= y0 && row < y1, (row - y0) * gx + minx + tx, g);
+                    bool hit = k < n0 && row >= y0 && row < y1;
+                    const uint32_t tl = (row - y0) * gx + minx + tx;
+                    if (LAYER == 2 && hit) hit = open8[tl] != 0;
+                    touch(hit, tl, g);
                 }
             }
         }
@@ -278,24 +302,35 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
 }
 
 // ------------------------------------------------------------------------------ offset scan
+// The three scan kernels work on the chunk range [lo, hi) of one depth layer (counters[rng], counters[rng+1];
+// rng = 0xFFFFFFFF: all chunks).
+__device__ __forceinline__ void layer_range(const uint32_t *counters, uint32_t rng, uint32_t C, uint32_t &lo, uint32_t &hi) {
+    lo = 0; hi = C;
+    if (rng != 0xFFFFFFFFu) { lo = counters[rng]; hi = min(C, counters[rng + 1]); }
+}
+
 // part[sg][t] = sum over the chunks of segment sg of cnt[c][t]
 __global__ void __launch_bounds__(256)
-seg_sum_kernel(const uint16_t *__restrict__ cnt, uint32_t C, uint32_t T, uint32_t seg, uint32_t *__restrict__ part) {
+seg_sum_kernel(const uint16_t *__restrict__ cnt, uint32_t C, uint32_t T, uint32_t seg, uint32_t *__restrict__ part,
+               const uint32_t *__restrict__ counters, uint32_t rng) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, sg = blockIdx.y;
     if (t >= T) return;
-    const uint32_t c0 = sg * seg, c1 = min(C, c0 + seg);
+    uint32_t lo, hi;
+    layer_range(counters, rng, C, lo, hi);
+    const uint32_t c0 = max(sg * seg, lo), c1 = min(min(C, sg * seg + seg), hi);
     uint32_t s = 0;
     for (uint32_t c = c0; c < c1; c++) s += cnt[(size_t)c * T + t];
     part[(size_t)sg * T + t] = s;
 }
 
-// one block: totals per tile (coalesced over tiles) -> exclusive scan -> tile_start[T+1];
-// counters[1] = R.
+// one block: totals per tile (coalesced over tiles) -> exclusive scan -> tile_start[T+1] (absolute list
+// positions, starting at `base_from` ? counters[1] : 0); counters[1] = end of the lists so far.
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, uint32_t *__restrict__ tile_start,
-                 uint32_t *__restrict__ counters) {
+                 uint32_t *__restrict__ counters, int append) {
     __shared__ uint32_t wave_tot[17];
-    uint32_t carry = 0;
+    uint32_t carry = append ? counters[1] : 0u;
+    __syncthreads();
     for (uint32_t base = 0; base < T; base += 1024) {
         const uint32_t t = base + threadIdx.x;
         uint32_t v = 0;
@@ -308,6 +343,7 @@ tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, u
     }
     if (threadIdx.x == 0) {
         tile_start[T] = carry;
+        if (!append) counters[2] = carry;       // length of the front layer's lists
         counters[1] = carry;
     }
 }
@@ -315,15 +351,31 @@ tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, u
 // off[c][t] = start of chunk c's entries inside tile t's list
 __global__ void __launch_bounds__(256)
 chunk_off_kernel(const uint16_t *__restrict__ cnt, const uint32_t *__restrict__ part, const uint32_t *__restrict__ tile_start,
-                 uint32_t C, uint32_t T, uint32_t seg, uint32_t *__restrict__ off) {
+                 uint32_t C, uint32_t T, uint32_t seg, uint32_t *__restrict__ off, const uint32_t *__restrict__ counters,
+                 uint32_t rng) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, sg = blockIdx.y;
     if (t >= T) return;
-    const uint32_t c0 = sg * seg, c1 = min(C, c0 + seg);
+    uint32_t lo, hi;
+    layer_range(counters, rng, C, lo, hi);
+    const uint32_t c0 = max(sg * seg, lo), c1 = min(min(C, sg * seg + seg), hi);
     uint32_t run = tile_start[t];
     for (uint32_t s = 0; s < sg; s++) run += part[(size_t)s * T + t];
     for (uint32_t c = c0; c < c1; c++) {
         off[(size_t)c * T + t] = run;
         run += cnt[(size_t)c * T + t];
+    }
+}
+
+// Split of the depth-ordered chunks into a front layer [0, cA) and a back layer [cA, nact):
+// counters[4..5] = front range, counters[6..7] = back range.  The front layer takes `front_256`/256 of the
+// chunks that hold visible Gaussians (at least one).
+__global__ void layer_split_kernel(uint32_t *__restrict__ counters, uint32_t chunk, uint32_t front_256) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const uint32_t V = counters[0];
+        const uint32_t nact = (V + chunk - 1) / chunk;
+        uint32_t cA = (nact * front_256 + 255u) >> 8;
+        if (cA > nact) cA = nact;
+        counters[4] = 0; counters[5] = cA; counters[6] = cA; counters[7] = nact;
     }
 }
 
@@ -350,19 +402,18 @@ W3DBands w3d_pick_bands(const W3DLayout &L) {
 }
 }  // namespace
 
-int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream) {
+#define W3D_FRONT_LAYER_256 72   // front depth layer = 72/256 of the chunks that hold visible Gaussians
+
+// stable depth sort of the Gaussians + depth-ordered packed records (+ the layer split)
+int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream) {
     uint32_t *counters = reinterpret_cast<uint32_t *>(state + L.o_counters);
-    uint32_t *tile_start = reinterpret_cast<uint32_t *>(state + L.o_tile_start);
     uint32_t *keys[2] = {reinterpret_cast<uint32_t *>(scratch + L.s_keys0), reinterpret_cast<uint32_t *>(scratch + L.s_keys1)};
     uint32_t *vals[2] = {reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(scratch + L.s_vals1)};
     uint32_t *hist = reinterpret_cast<uint32_t *>(scratch + L.s_hist);
     uint32_t *rowtot = reinterpret_cast<uint32_t *>(scratch + L.s_rowtot);
-    uint16_t *cnt = reinterpret_cast<uint16_t *>(scratch + L.s_cnt);
-    uint32_t *part = reinterpret_cast<uint32_t *>(scratch + L.s_part);
-    uint32_t *off = reinterpret_cast<uint32_t *>(scratch + L.s_off);
-    const uint32_t T = (uint32_t)L.T;
     const uint32_t *sorted_ids = vals[0];
-    if (L.P > 0) {
+    if (L.P == 0) return W3D_OK;
+    {
         // ---- stable LSD radix sort of (depth bits, id), PASSES x BITS bits; culled Gaussians carry key 0xFFFFFFFF
         const uint32_t n = (uint32_t)L.P, runs = L.sort_waves, blocks = (runs + 3) / 4;
         int src = 0;
@@ -381,59 +432,68 @@ int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state
         }
         sorted_ids = vals[src];
     }
-    // ---- per-chunk per-tile counts
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3((L.P + 255) / 256), dim3(256), 0, stream, sorted_ids,
+                       reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint2 *>(state + L.o_tile_mask),
+                       counters, (uint32_t)L.P, reinterpret_cast<uint4 *>(scratch + L.s_rec),
+                       reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    hipLaunchKernelGGL(layer_split_kernel, dim3(1), dim3(64), 0, stream, counters, L.chunk, (uint32_t)W3D_FRONT_LAYER_256);
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    return W3D_OK;
+}
+
+template <int MODE, int LAYER>
+static void launch_walk(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
+                        uint64_t capacity, hipStream_t stream) {
     const W3DBands bands = w3d_pick_bands(L);
+    const dim3 grid((L.C + 3) / 4, bands.count);
+    const size_t lds = (size_t)bands.tbpad * (MODE == 0 ? 2 : 4) * 4 + (LAYER == 2 ? (size_t)bands.tbpad * 4 : 0);
+    const uint4 *rec = reinterpret_cast<const uint4 *>(scratch + L.s_rec);
+    const uint2 *rmask = reinterpret_cast<const uint2 *>(scratch + L.s_rec_mask);
+    const uint32_t *counters = reinterpret_cast<const uint32_t *>(state + L.o_counters);
+    uint16_t *cnt = reinterpret_cast<uint16_t *>(scratch + L.s_cnt);
+    const uint32_t *off = reinterpret_cast<const uint32_t *>(scratch + L.s_off);
+    const uint8_t *open = reinterpret_cast<const uint8_t *>(state + L.o_tile_open);
+    if (v.tile_cull)
+        hipLaunchKernelGGL((chunk_walk_kernel<MODE, true, LAYER>), grid, dim3(256), lds, stream, rec, rmask, counters, L.chunk, L.C,
+                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, open);
+    else
+        hipLaunchKernelGGL((chunk_walk_kernel<MODE, false, LAYER>), grid, dim3(256), lds, stream, rec, rmask, counters, L.chunk, L.C,
+                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, open);
+}
+
+// per-chunk per-tile counts of one layer (0 = all chunks, 1 = front, 2 = back/open tiles) and the list offsets
+int w3d_launch_tile_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, int layer, hipStream_t stream) {
+    uint32_t *counters = reinterpret_cast<uint32_t *>(state + L.o_counters);
+    uint32_t *tile_start = reinterpret_cast<uint32_t *>(state + (layer == 2 ? L.o_tile_startB : L.o_tile_start));
+    uint16_t *cnt = reinterpret_cast<uint16_t *>(scratch + L.s_cnt);
+    uint32_t *part = reinterpret_cast<uint32_t *>(scratch + L.s_part);
+    uint32_t *off = reinterpret_cast<uint32_t *>(scratch + L.s_off);
+    const uint32_t T = (uint32_t)L.T;
+    const uint32_t rng = layer == 0 ? 0xFFFFFFFFu : (uint32_t)(2 + 2 * layer);
     W3D_PROF("tile_count_scan", stream);
-#define WALK_ARGS(ids) reinterpret_cast<const uint4 *>(scratch + L.s_rec), reinterpret_cast<const uint2 *>(scratch + L.s_rec_mask)
-    if (L.P > 0) {
-        hipLaunchKernelGGL(gather_sorted_kernel, dim3((L.P + 255) / 256), dim3(256), 0, stream, sorted_ids,
-                           reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint2 *>(state + L.o_tile_mask),
-                           counters, (uint32_t)L.P, reinterpret_cast<uint4 *>(scratch + L.s_rec),
-                           reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);
-        W3D_LAUNCH_CHECK(v.debug, stream);
-    }
-    {
-        const dim3 grid((L.C + 3) / 4, bands.count);
-        const size_t lds = (size_t)bands.tbpad * 2 * 4;
-        if (v.tile_cull)
-            hipLaunchKernelGGL((chunk_walk_kernel<0, true>), grid, dim3(256), lds, stream, WALK_ARGS(vals[0]), counters, L.chunk,
-                               L.C, T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, (const uint32_t *)nullptr,
-                               (uint32_t *)nullptr, (uint64_t)0);
-        else
-            hipLaunchKernelGGL((chunk_walk_kernel<0, false>), grid, dim3(256), lds, stream, WALK_ARGS(vals[0]), counters, L.chunk,
-                               L.C, T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, (const uint32_t *)nullptr,
-                               (uint32_t *)nullptr, (uint64_t)0);
-    }
+    if (layer == 0) launch_walk<0, 0>(L, v, state, scratch, nullptr, 0, stream);
+    else if (layer == 1) launch_walk<0, 1>(L, v, state, scratch, nullptr, 0, stream);
+    else launch_walk<0, 2>(L, v, state, scratch, nullptr, 0, stream);
     W3D_LAUNCH_CHECK(v.debug, stream);
-    // ---- offsets
     const uint32_t tb = (T + 255) / 256;
-    hipLaunchKernelGGL(seg_sum_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, L.C, T, L.seg, part);
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, L.C, T, L.seg, part, counters, rng);
     W3D_LAUNCH_CHECK(v.debug, stream);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, part, T, (uint32_t)W3D_SCAN_SEGS, tile_start, counters);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, part, T, (uint32_t)W3D_SCAN_SEGS, tile_start, counters,
+                       layer == 2 ? 1 : 0);
     W3D_LAUNCH_CHECK(v.debug, stream);
-    hipLaunchKernelGGL(chunk_off_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, part, tile_start, L.C, T, L.seg, off);
+    hipLaunchKernelGGL(chunk_off_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, part, tile_start, L.C, T, L.seg, off,
+                       counters, rng);
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;
 }
 
 int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
-                          uint64_t list_capacity, hipStream_t stream) {
-    const uint32_t T = (uint32_t)L.T;
-    const W3DBands bands = w3d_pick_bands(L);
-    const dim3 grid((L.C + 3) / 4, bands.count);
-    const size_t lds = (size_t)bands.tbpad * 4 * 4;
+                          uint64_t list_capacity, int layer, hipStream_t stream) {
     W3D_PROF("fill_lists", stream);
-    if (v.tile_cull)
-        hipLaunchKernelGGL((chunk_walk_kernel<1, true>), grid, dim3(256), lds, stream, WALK_ARGS(ids),
-                           reinterpret_cast<const uint32_t *>(state + L.o_counters), L.chunk, L.C, T, (uint32_t)L.gx,
-                           (uint32_t)L.gy, bands.rows, (uint16_t *)nullptr,
-                           reinterpret_cast<const uint32_t *>(scratch + L.s_off), point_list, list_capacity);
-    else
-        hipLaunchKernelGGL((chunk_walk_kernel<1, false>), grid, dim3(256), lds, stream, WALK_ARGS(ids),
-                           reinterpret_cast<const uint32_t *>(state + L.o_counters), L.chunk, L.C, T, (uint32_t)L.gx,
-                           (uint32_t)L.gy, bands.rows, (uint16_t *)nullptr,
-                           reinterpret_cast<const uint32_t *>(scratch + L.s_off), point_list, list_capacity);
-#undef WALK_ARGS
+    if (layer == 0) launch_walk<1, 0>(L, v, state, scratch, point_list, list_capacity, stream);
+    else if (layer == 1) launch_walk<1, 1>(L, v, state, scratch, point_list, list_capacity, stream);
+    else launch_walk<1, 2>(L, v, state, scratch, point_list, list_capacity, stream);
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;
 }

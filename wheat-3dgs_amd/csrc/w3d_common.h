@@ -29,14 +29,17 @@ struct W3DLayout {
     uint32_t C;       // number of chunks
     uint32_t seg;     // chunks per scan segment
     // ---- state buffer (kept until backward)
-    uint64_t o_counters;   // u32[16]: [0]=num_visible [1]=num_rendered [3]=capacity of the list buffer given to stage 2
+    uint64_t o_counters;   // u32[16]: [0]=num_visible [1]=num_rendered [2]=front-layer list length
+                           //          [3]=capacity of the list buffer given to stage 2 [4..7]=layer chunk ranges
     uint64_t o_xy;         // float2[P]
     uint64_t o_conic_op;   // float4[P]
     uint64_t o_rgbd;       // float4[P]  (r,g,b,depth)
     uint64_t o_rect;       // ushort4[P] (minx,miny,maxx,maxy) tile units
     uint64_t o_clamped;    // u8[P] bit c set: SH colour channel c clamped at 0
     uint64_t o_tile_mask;  // u64[P] bit k: k-th tile of the rect (row-major) is reachable (tile_cull)
-    uint64_t o_tile_start; // u32[T+1]
+    uint64_t o_tile_start; // u32[T+1]  (front layer, or the only layer)
+    uint64_t o_tile_startB; // u32[T+1] back layer (absolute list positions)
+    uint64_t o_tile_open;  // u8[T]     1 = tile still open after the front layer
     uint64_t o_final_T;    // float[HW]
     uint64_t o_n_contrib;  // u32[HW]
     uint64_t state_bytes;
@@ -80,6 +83,8 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->o_clamped = o;    o += w3d_align_up(Pp);
     L->o_tile_mask = o;  o += w3d_align_up(Pp * 8);
     L->o_tile_start = o; o += w3d_align_up((T + 1) * 4);
+    L->o_tile_startB = o; o += w3d_align_up((T + 1) * 4);
+    L->o_tile_open = o;  o += w3d_align_up(T);
     L->o_final_T = o;    o += w3d_align_up(HW * 4);
     L->o_n_contrib = o;  o += w3d_align_up(HW * 4);
     L->state_bytes = o;
@@ -147,12 +152,13 @@ int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *me
                           const float *colors_precomp, const float *opacities, const float *scales,
                           const float *rotations, const float *cov3D_precomp, int32_t *radii, char *state,
                           char *scratch, const float *f_rest_raw, hipStream_t stream);
-int w3d_launch_sort_and_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream);
+int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream);
+int w3d_launch_tile_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, int layer, hipStream_t stream);
 int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
-                          uint64_t list_capacity, hipStream_t stream);
+                          uint64_t list_capacity, int layer, hipStream_t stream);
 int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const uint32_t *point_list, uint64_t list_capacity,
                       float *out_color, float *out_depth, float *out_alpha, const float *gt_mask, int32_t num_obj,
-                      float *used_count, int32_t *contrib_num, hipStream_t stream);
+                      float *used_count, int32_t *contrib_num, int layer, hipStream_t stream);
 int w3d_launch_flash_extras(const W3DLayout &L, const w3d_view &v, const int32_t *radii_unused, char *state,
                             float *proj_xy, float *gs_depth, hipStream_t stream);
 int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char *state, const uint32_t *point_list,

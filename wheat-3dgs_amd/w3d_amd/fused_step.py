@@ -9,6 +9,7 @@ tests/test_gpu_fused.py checks the two paths against each other.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -67,6 +68,14 @@ class ListCapacity:
 
 _capacity = ListCapacity()
 
+# Depth-layered binning (w3d_view.depth_layers = 2) in the asynchronous forward: bin and blend the front
+# ~28 % of the depth-ordered Gaussians, then only the tiles that are still open.  Identical outputs.
+# OFF by default: it only pays when the global depth order follows the per-tile order (fronto-parallel
+# views).  On the benchmark's tilted overhead cameras the depth gradient across the image is as large as
+# the slab is thick, the front layer closes only the near side of the image, and the second pass costs
+# more than it saves (measured 269 vs 319 iters/s).
+DEPTH_LAYERS = os.environ.get("W3D_DEPTH_LAYERS", "0") == "2"
+
 
 def finish(handle):
     """Wait for the counters of an asynchronous forward; True if the list capacity sufficed."""
@@ -111,6 +120,7 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True):
             R, V = int(counts[1]), int(counts[0])
             _capacity.observe(R)
         else:
+            view.c.depth_layers = 2 if DEPTH_LAYERS else 0
             check(lib.w3d_forward_stage1_raw(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(radii), ptr(state),
                                              ptr(scratch), None, stream))
             pinned = torch.empty(2, dtype=torch.int32, pin_memory=True)

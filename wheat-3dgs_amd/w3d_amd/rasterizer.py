@@ -91,6 +91,7 @@ class _View:
         v.bg, v.viewmatrix = self.bg.data_ptr(), self.vm.data_ptr()
         v.projmatrix, v.campos = self.pm.data_ptr(), self.cp.data_ptr()
         v.tile_cull = int(bool(TILE_CULL))
+        v.depth_layers = 0
         self.c = v
 
 
