@@ -1,8 +1,9 @@
 """CPU, world_size 2 over gloo: the exchange step of the view-parallel loop.
-Checks that (a) the averaged gradient bucket equals the mean of the per-view gradients,
+Checks that (a) after reduce-scatter + sharded Adam + parameter all-gather every rank holds exactly
+the parameters a single process would get from Adam on the MEAN of the per-view gradients,
 (b) the densification statistics are the SUM of per-view norms / visibility and the MAX of radii —
-not functions of the averaged gradient, (c) ranks render different cameras, (d) replicas stay
-bit-identical after densify + Adam."""
+not functions of the averaged gradient, (c) ranks render different cameras, (d) the sharded Adam
+moments are made whole before densification and the replicas stay bit-identical afterwards."""
 import os
 import socket
 import sys
@@ -22,53 +23,61 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _model(P=64):
     for p in (ROOT, os.path.join(ROOT, "wheat-3dgs_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
     from w3d_amd.synth import make_scene
-    from w3d_amd.train import Trainer
-    P = 64
     sc = make_scene(P, seed=0, scale_mean=0.05)
     m = GaussianModel(3, device="cpu")
     m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
     opt = OptimizationParams()
     m.training_setup(opt)
+    return m, opt
+
+
+def _view_grad(rank, n):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(n, generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, opt = _model()
+    from w3d_amd.train import Trainer
+    P = m.num_points
     tr = Trainer(m, list(range(10)), opt, torch.zeros(3), densify=True)
     cams = [tr.camera_for(it) for it in (1, 2, 3)]
-    # per-view quantities a rank would have after its own render + backward
-    g = torch.Generator().manual_seed(100 + rank)
-    m.flat_grad.copy_(torch.randn(m.flat_grad.shape, generator=g))
-    my_grad = m.flat_grad.clone()
-    gnorm = torch.rand(P, generator=g) * 1e-3
-    vis = torch.rand(P, generator=g) > 0.4
-    radii = (torch.rand(P, generator=g) * 30).to(torch.int32) * vis
-    nsum, vcount, rmax = tr.exchange(gnorm, vis, radii)
-    # gather everything on every rank for checking
-    def gather(t):
-        lst = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(lst, t)
-        return lst
-    grads = gather(my_grad)
-    norms, viss, rads = gather(gnorm), gather(vis.to(torch.float32)), gather(radii)
-    ok = torch.allclose(m.flat_grad, sum(grads) / world, atol=1e-7)
-    ok &= torch.allclose(nsum, sum(n * v for n, v in zip(norms, viss)), atol=1e-9)
-    ok &= torch.equal(vcount, sum(viss))
-    ok &= torch.equal(rmax, torch.stack(rads).max(0).values)
-    # lock-step: same stats -> same densify decisions and same parameters on every rank
+    ok = True
+    g = torch.Generator().manual_seed(500 + rank)
+    for step in range(3):
+        # per-view quantities a rank would have after its own render + backward
+        m.flat_grad.copy_(_view_grad(rank + 10 * step, m.flat.numel()))
+        gnorm = torch.rand(P, generator=g) * 1e-3
+        vis = torch.rand(P, generator=g) > 0.4
+        radii = (torch.rand(P, generator=g) * 30).to(torch.int32) * vis
+        nsum, vcount, rmax = tr.exchange(gnorm, vis, radii)
+
+        def gather(t):
+            lst = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(lst, t)
+            return lst
+        norms, viss, rads = gather(gnorm), gather(vis.to(torch.float32)), gather(radii)
+        ok &= torch.allclose(nsum, sum(n * v for n, v in zip(norms, viss)), atol=1e-9)
+        ok &= torch.equal(vcount, sum(viss))
+        ok &= torch.equal(rmax, torch.stack(rads).max(0).values)
+        tr.optimizer_step_and_gather(zero_grad=False, skip=())
+    # lock-step densification: whole moments first, then identical decisions on every rank
     m.xyz_gradient_accum += nsum[:, None]
     m.denom += vcount[:, None]
+    tr.gather_moments()
+    moments = m.optimizer.exp_avg.clone()
     torch.manual_seed(1234)
     m.densify_and_prune(2e-4, 0.005, 10.0, None)
-    m.optimizer.step(zero_grad=True)
-    flat = gather(m.flat.detach().clone()) if all(
-        x == m.num_points for x in [int(t) for t in gather(torch.tensor([m.num_points]))]) else None
-    ok &= flat is not None and all(torch.equal(flat[0], f) for f in flat)
-    out.put((rank, bool(ok), cams, m.num_points))
+    out.put((rank, bool(ok), cams, m.num_points, m.flat.detach().clone(), moments))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,12 +90,21 @@ def test_view_parallel_exchange_two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=180) for _ in range(world))
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(ok for _, ok, _, _ in res)
+    assert all(ok for _, ok, *_ in res)
     cams0, cams1 = res[0][2], res[1][2]
     assert all(a != b for a, b in zip(cams0, cams1))            # different view per rank in every step
     assert len(set(cams0 + cams1)) == 6                         # and no repetition within the cycle
     assert res[0][3] == res[1][3] > 64                          # replicas densified identically
+    assert torch.equal(res[0][4], res[1][4])                    # ... and hold bit-identical parameters
+    assert torch.equal(res[0][5], res[1][5])                    # ... and bit-identical (whole) Adam moments
+
+    # single-process reference: Adam on the MEAN of the per-view gradients, three steps
+    m, opt = _model()
+    for step in range(3):
+        m.flat_grad.copy_((_view_grad(0 + 10 * step, m.flat.numel()) + _view_grad(1 + 10 * step, m.flat.numel())) / world)
+        m.optimizer.step()
+    assert torch.allclose(m.optimizer.exp_avg, res[0][5], atol=1e-7)

@@ -91,8 +91,14 @@ class GaussianModel:
     def _bind(self, blocks: dict):
         """(Re)build the flat buffers from a dict name -> tensor (P, *shape)."""
         P = blocks["xyz"].shape[0]
-        self.flat = torch.empty(P * FLOATS_PER_GAUSSIAN, dtype=torch.float32, device=self.device)
-        self.flat_grad = torch.zeros_like(self.flat)
+        n = P * FLOATS_PER_GAUSSIAN
+        # storage padded to a multiple of 256 elements: any world size up to 256 can shard it evenly for the
+        # reduce-scatter / all-gather exchange (train.py) without repacking
+        n_pad = (n + 255) // 256 * 256
+        self.flat_store = torch.zeros(n_pad, dtype=torch.float32, device=self.device)
+        self.flat_grad_store = torch.zeros(n_pad, dtype=torch.float32, device=self.device)
+        self.flat = self.flat_store[:n]
+        self.flat_grad = self.flat_grad_store[:n]
         self._p = {}
         off = 0
         for name, shape in BLOCKS:

@@ -63,24 +63,32 @@ class FlatAdam:
         self.lrs.update(d["lrs"])
 
     @torch.no_grad()
-    def step(self, zero_grad=False, skip=()):
+    def step(self, zero_grad=False, skip=(), elem_range=None):
         """One Adam step on every block.  zero_grad=True clears the gradient bucket in the same
-        sweep (what `optimizer.zero_grad(set_to_none=True)` achieves at train_vanilla_3dgs.py:115)."""
+        sweep (what `optimizer.zero_grad(set_to_none=True)` achieves at train_vanilla_3dgs.py:115).
+        elem_range=(lo, hi): only that slice of the flat buffer is stepped — the shard this rank owns in
+        the view-parallel loop (the other shards arrive through the parameter all-gather)."""
         self.step_count += 1
         b1, b2 = self.betas
         bc1 = 1.0 - b1 ** self.step_count
         bc2 = 1.0 - b2 ** self.step_count
         p, g, m, v = self.model.flat, self.model.flat_grad, self.exp_avg, self.exp_avg_sq
+        slices = {}
+        for name, (a, b) in self.model.block_slices().items():
+            if elem_range is not None:
+                a, b = max(a, elem_range[0]), min(b, elem_range[1])
+            if a < b:
+                slices[name] = (a, b)
         if p.is_cuda:
             from .fused import adam_step
-            for name, (a, b) in self.model.block_slices().items():
+            for name, (a, b) in slices.items():
                 if name in skip:
                     if zero_grad:
                         g[a:b].zero_()
                     continue
                 adam_step(p[a:b], g[a:b], m[a:b], v[a:b], self.lrs[name], b1, b2, self.eps, bc1, bc2, zero_grad)
             return
-        for name, (a, b) in self.model.block_slices().items():
+        for name, (a, b) in slices.items():
             gg = g[a:b]
             if name in skip:
                 if zero_grad:

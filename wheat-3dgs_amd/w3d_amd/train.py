@@ -60,19 +60,57 @@ class Trainer:
         return self.cameras[self.perm[((iteration - 1) * self.world + self.rank) % len(self.cameras)]]
 
     # ------------------------------------------------------------------------------------------
+    def shard_range(self):
+        """[lo, hi) of the padded flat buffers this rank owns (optimizer state sharding)."""
+        n = self.model.flat_store.numel() // self.world
+        return self.rank * n, (self.rank + 1) * n
+
     def exchange(self, grad2d_norm, visible, radii):
         """The one exchange step of the view-parallel loop.  Returns the reduced
-        (sum of per-view norms, visibility count, max radii)."""
+        (sum of per-view norms, visibility count, max radii).
+
+        Gradients: reduce-scatter of the flat 59*P bucket — every rank receives the averaged gradient of
+        ITS 1/N slice only, steps Adam on that slice, and the updated parameters are all-gathered
+        (optimizer_step_and_gather).  Same bytes on the wire as an all-reduce, but the optimizer sweep
+        (the largest HBM stream of the step) shrinks N-fold per GPU."""
         m = self.model
         if self.world > 1:
             stats = torch.stack([grad2d_norm * visible, visible.to(grad2d_norm.dtype)])
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)
             r = radii.clone()
             dist.all_reduce(r, op=dist.ReduceOp.MAX)
-            dist.all_reduce(m.flat_grad, op=dist.ReduceOp.SUM)
-            m.flat_grad.div_(self.world)
+            lo, hi = self.shard_range()
+            shard = torch.empty(hi - lo, dtype=m.flat_grad_store.dtype, device=m.flat_grad_store.device)
+            dist.reduce_scatter_tensor(shard, m.flat_grad_store, op=dist.ReduceOp.SUM)
+            m.flat_grad_store[lo:hi].copy_(shard.div_(self.world))
             return stats[0], stats[1], r
         return grad2d_norm * visible, visible.to(grad2d_norm.dtype), radii
+
+    def optimizer_step_and_gather(self, zero_grad, skip):
+        """Adam on this rank's shard, then all-gather of the updated parameters (single GPU: plain step)."""
+        m = self.model
+        if self.world == 1:
+            m.optimizer.step(zero_grad=zero_grad, skip=skip)
+            return
+        lo, hi = self.shard_range()
+        m.optimizer.step(zero_grad=zero_grad, skip=skip, elem_range=(lo, hi))
+        dist.all_gather_into_tensor(m.flat_store, m.flat_store[lo:hi].clone())
+        self._moments_sharded = True
+
+    def gather_moments(self):
+        """Before anything reads or rebuilds the optimizer state (densify, checkpoint): make the
+        sharded Adam moments whole again on every rank."""
+        if self.world == 1 or not getattr(self, "_moments_sharded", False):
+            return
+        m = self.model
+        lo, hi = self.shard_range()
+        n = m.flat.numel()
+        for buf in (m.optimizer.exp_avg, m.optimizer.exp_avg_sq):
+            full = torch.zeros(m.flat_store.numel(), dtype=buf.dtype, device=buf.device)
+            full[:n].copy_(buf)
+            dist.all_gather_into_tensor(full, full[lo:hi].clone())
+            buf.copy_(full[:n])
+        self._moments_sharded = False
 
     def _post_backward(self, iteration, nsum, vcount, rmax, stats_done):
         """Densification bookkeeping + optimizer step shared by both step flavours."""
@@ -87,11 +125,13 @@ class Trainer:
                 m.denom += vcount[:, None]
             if self.densify:
                 if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+                    self.gather_moments()
                     size_threshold = 20 if iteration > opt.opacity_reset_interval else None
                     torch.manual_seed(1234 + iteration)     # identical split samples on every rank
                     m.densify_and_prune(opt.densify_grad_threshold, 0.005, self.extent, size_threshold)
                     skip = {"xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"}
                 if iteration % opt.opacity_reset_interval == 0:
+                    self.gather_moments()
                     m.reset_opacity()
                     skip.add("opacity")
         return skip
@@ -133,7 +173,7 @@ class Trainer:
             skip = self._post_backward(iteration, nsum, vcount, rmax, stats_done=single)
             if iteration < opt.iterations:
                 # the next backward overwrites the whole bucket: no zeroing pass needed
-                m.optimizer.step(zero_grad=bool(skip), skip=skip)
+                self.optimizer_step_and_gather(zero_grad=bool(skip), skip=skip)
         self.last = dict(loss=loss, image=pkg["render"], radii=pkg["radii"])
         return loss
 
@@ -155,7 +195,7 @@ class Trainer:
             nsum, vcount, rmax = self.exchange(gnorm, vis, radii)
             skip = self._post_backward(iteration, nsum, vcount, rmax, stats_done=False)
             if iteration < opt.iterations:
-                m.optimizer.step(zero_grad=True, skip=skip)
+                self.optimizer_step_and_gather(zero_grad=True, skip=skip)
         self.last = dict(loss=loss.detach(), num_rendered=None, image=image.detach())
         return loss.detach()
 
