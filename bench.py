@@ -148,8 +148,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("W3D_FORCE_DIST", "0") == "1"      # 1-rank RCCL group: exercises the exchange path
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from w3d_amd import _lib
     from w3d_amd.train import Trainer, render_views
@@ -159,7 +161,8 @@ def main():
     sc, model, opt, cams = build_scene(args, dev)
     make_ground_truth(args, cams, dev, bg)
     loss_fn = photometric_loss_torch if args.torch_loss else photometric_loss
-    trainer = Trainer(model, cams, opt, bg, densify=False, loss_fn=loss_fn, fused=False if args.autograd_path else None)
+    trainer = Trainer(model, cams, opt, bg, densify=False, loss_fn=loss_fn, fused=False if args.autograd_path else None,
+                      force_exchange=force_dist)
 
     def sync():
         if world > 1:
@@ -253,7 +256,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

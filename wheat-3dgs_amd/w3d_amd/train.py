@@ -37,7 +37,7 @@ def dist_info():
 
 class Trainer:
     def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
-                 densify=True, loss_fn=photometric_loss, fused=None):
+                 densify=True, loss_fn=photometric_loss, fused=None, force_exchange=False):
         self.model, self.cameras, self.opt = model, cameras, opt
         self.bg = background
         self.pipe = pipe or PipelineParams()
@@ -51,6 +51,9 @@ class Trainer:
                          not self.pipe.convert_SHs_python and not self.pipe.compute_cov3D_python)
         self.fused = fused
         self.rank, self.world = dist_info()
+        # force_exchange: run the multi-rank exchange path (collectives, sharded optimizer) even in a
+        # 1-rank process group — lets the RCCL code path be exercised on a single GPU
+        self.force_exchange = bool(force_exchange)
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.perm = torch.randperm(len(cameras), generator=g).tolist()
         self.last = {}
@@ -74,7 +77,7 @@ class Trainer:
         (optimizer_step_and_gather).  Same bytes on the wire as an all-reduce, but the optimizer sweep
         (the largest HBM stream of the step) shrinks N-fold per GPU."""
         m = self.model
-        if self.world > 1:
+        if self.world > 1 or self.force_exchange:
             stats = torch.stack([grad2d_norm * visible, visible.to(grad2d_norm.dtype)])
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)
             r = radii.clone()
@@ -89,7 +92,7 @@ class Trainer:
     def optimizer_step_and_gather(self, zero_grad, skip):
         """Adam on this rank's shard, then all-gather of the updated parameters (single GPU: plain step)."""
         m = self.model
-        if self.world == 1:
+        if self.world == 1 and not self.force_exchange:
             m.optimizer.step(zero_grad=zero_grad, skip=skip)
             return
         lo, hi = self.shard_range()
@@ -100,7 +103,7 @@ class Trainer:
     def gather_moments(self):
         """Before anything reads or rebuilds the optimizer state (densify, checkpoint): make the
         sharded Adam moments whole again on every rank."""
-        if self.world == 1 or not getattr(self, "_moments_sharded", False):
+        if (self.world == 1 and not self.force_exchange) or not getattr(self, "_moments_sharded", False):
             return
         m = self.model
         lo, hi = self.shard_range()
@@ -150,7 +153,7 @@ class Trainer:
         cam = self.camera_for(iteration)
         with torch.no_grad():
             tracking = iteration < opt.densify_until_iter
-            single = self.world == 1
+            single = self.world == 1 and not self.force_exchange
             # statistics are updated inside the backward kernel only when the list-capacity guess is known to
             # hold (synchronous forward); with the speculative forward they are applied after finish()
             fused_stats = False
