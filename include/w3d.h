@@ -76,6 +76,16 @@ typedef struct w3d_view {
                               * outputs; since saturated tiles are the norm in dense scenes most of the binning
                               * work disappears.  Needs the asynchronous forward (counts_host == NULL): the total
                               * list length is only known after the front layer has been blended. */
+    /* Speculative per-tile list truncation for training loops that revisit cameras.  tile_depth_cut (device,
+     * one float per tile, nullable): instances deeper than their tile's cut are not binned — the kept
+     * entries are a PREFIX of the tile's depth-ordered list, so outputs are unchanged as long as every pixel
+     * of the tile saturates inside it.  tile_depth_cut_out (device, nullable) receives the cuts for the next
+     * visit of this camera: depth of the last entry the tile walked + a margin, or +inf for tiles that did
+     * not saturate.  A tile that had a finite cut and did NOT saturate may have lost contributors: it is
+     * counted in the third counter of the state (uint32 at byte 32, see w3d_forward_stage1); the caller
+     * must then repeat the view without cuts.  Single-pass mode only (depth_layers <= 1). */
+    const float *tile_depth_cut;
+    float *tile_depth_cut_out;
 } w3d_view;
 
 int w3d_version(void);

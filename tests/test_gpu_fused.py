@@ -211,7 +211,10 @@ def test_depth_layered_forward_is_bit_identical_and_backward_matches():
             gref = m.flat_grad.clone()
             fused_step._capacity.known = ref["handle"]["num_rendered"]   # generous guess -> async + layered
             fused_step.DEPTH_LAYERS = True
-            lay = render_raw(cam, m, bg, sync=False)
+            try:
+                lay = render_raw(cam, m, bg, sync=False)
+            finally:
+                fused_step.DEPTH_LAYERS = False
             assert lay["handle"]["view"].c.depth_layers == 2
             backward_raw(m, lay["handle"], dimg)
             assert finish(lay["handle"])
@@ -222,3 +225,36 @@ def test_depth_layered_forward_is_bit_identical_and_backward_matches():
             assert lay["handle"]["num_rendered"] <= ref["handle"]["num_rendered"]
             err = float((glay - gref).abs().max() / gref.abs().max())
             assert err <= 1e-4, err
+
+
+def test_depth_cuts_are_exact_or_repeated():
+    """Speculative per-tile list truncation (w3d_view.tile_depth_cut): with cuts from an earlier visit the
+    outputs are bit-identical to the uncut render; a cut that is too shallow is detected (suspect tiles)."""
+    from w3d_amd import fused_step
+    from w3d_amd.fused_step import render_raw, finish
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    dev = torch.device("cuda:0")
+    P, W, H = 400_000, 480, 360
+    cam = make_cameras(3, W, H)[1].to(dev)
+    sc = make_scene(P, seed=7, scale_mean=0.012)
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    m.active_sh_degree = 3
+    m.training_setup(OptimizationParams())
+    bg = torch.zeros(3, device=dev)
+    fused_step.DEPTH_LAYERS = False
+    ref = render_raw(cam, m, bg, sync=True)
+    fused_step._capacity.known = ref["handle"]["num_rendered"]
+    first = render_raw(cam, m, bg, sync=False, want_cut=True)
+    assert finish(first["handle"])
+    cuts = first["handle"]["depth_cut_out"]
+    assert torch.isfinite(cuts).float().mean() > 0.5            # most tiles saturate in this dense scene
+    second = render_raw(cam, m, bg, sync=False, depth_cut=cuts, want_cut=True)
+    assert finish(second["handle"]) and second["handle"]["suspect_tiles"] == 0
+    assert second["handle"]["num_rendered"] < 0.99 * first["handle"]["num_rendered"]    # lists really were truncated
+    for k in ("render", "depth", "alpha", "radii"):
+        assert torch.equal(ref[k], second[k]), k
+    # cuts that are far too shallow must be reported, not silently rendered
+    bad = render_raw(cam, m, bg, sync=False, depth_cut=torch.full_like(cuts, 0.5))
+    assert not finish(bad["handle"]) and bad["handle"]["suspect_tiles"] > 0

@@ -165,13 +165,14 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
 // which re-read their chunk once per band and per pass — stream them coalesced instead of gathering.
 __global__ void __launch_bounds__(256)
 gather_sorted_kernel(const uint32_t *__restrict__ sorted_ids, const uint2 *__restrict__ rect,
-                     const uint2 *__restrict__ tile_mask, const uint32_t *__restrict__ counters, uint32_t P,
+                     const uint2 *__restrict__ tile_mask, const float4 *__restrict__ rgbd,
+                     const uint32_t *__restrict__ counters, uint32_t P,
                      uint4 *__restrict__ rec, uint2 *__restrict__ rec_mask, int cull) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= P || s >= counters[0]) return;
     const uint32_t g = sorted_ids[s];
     const uint2 rc = rect[g];
-    rec[s] = make_uint4(g, rc.x, rc.y, 0u);
+    rec[s] = make_uint4(g, rc.x, rc.y, __float_as_uint(rgbd[g].w));     // .w = view depth (for the depth cuts)
     rec_mask[s] = cull ? tile_mask[g] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
 }
 
@@ -184,7 +185,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                   const uint32_t *__restrict__ counters,
                   uint32_t chunk, uint32_t C, uint32_t T, uint32_t gx, uint32_t gy, uint32_t band_rows,
                   uint16_t *__restrict__ cnt, const uint32_t *__restrict__ off, uint32_t *__restrict__ point_list,
-                  uint64_t capacity, const uint8_t *__restrict__ tile_open) {
+                  uint64_t capacity, const uint8_t *__restrict__ tile_open, const float *__restrict__ depth_cut) {
     // blockIdx.y = band of tile rows this wave is responsible for: the LDS array only spans the band
     // (a few KB, so 8 waves per SIMD fit), and Gaussians whose rect misses the band are compacted
     // away BEFORE the serial loop, so the serial work per wave shrinks with the band height while
@@ -208,6 +209,12 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
     uint8_t *open8 = smem + (size_t)4 * Tbpad * (MODE == 0 ? 2 : 4) + (size_t)wv * Tbpad;
     if (LAYER == 2)
         for (uint32_t t = lane; t < Tb; t += 64) open8[t] = tile_open[tb0 + t];
+    // per-tile depth cuts (speculative list truncation, see w3d_view.tile_depth_cut): an instance deeper than
+    // its tile's cut is not binned.  One private copy per wave keeps the walk free of workgroup barriers.
+    float *cut32 = reinterpret_cast<float *>(smem + (size_t)4 * Tbpad * ((MODE == 0 ? 2 : 4) + (LAYER == 2 ? 1 : 0))) + (size_t)wv * Tbpad;
+    const bool has_cut = depth_cut != nullptr;
+    if (has_cut)
+        for (uint32_t t = lane; t < Tb; t += 64) cut32[t] = depth_cut[tb0 + t];
     if (MODE == 0) {
         for (uint32_t t = lane; t < Tbpad; t += 64) h16[t] = 0;
     } else {
@@ -240,9 +247,11 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         if (base + 64 + lane < s_end) { nx_rec = rec[base + 64 + lane]; nx_mask = rec_mask[base + 64 + lane]; }
         uint32_t my_g = 0, my_minx = 0, my_miny = 0, my_w = 1, my_n = 0, my_magic = 0;
         uint2 my_mask = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        float my_depth = 0.f;
         bool relevant = false;
         if (lane < nb) {
             my_g = cur_rec.x;
+            my_depth = __uint_as_float(cur_rec.w);
             const uint2 rc = make_uint2(cur_rec.y, cur_rec.z);
             const uint32_t minx = rc.x & 0xFFFFu, miny = rc.x >> 16, maxx = rc.y & 0xFFFFu, maxy = rc.y >> 16;
             relevant = miny < y1 && maxy > y0;                   // rect reaches into this band
@@ -262,6 +271,17 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                 }
                 relevant = any_open;
             }
+            if (has_cut && relevant && my_n <= 64u) {
+                // vectorised pre-filter: is this Gaussian in front of the cut of ANY of its tiles in the band?
+                bool any_front = false;
+                const uint64_t m64 = (uint64_t)my_mask.x | ((uint64_t)my_mask.y << 32);
+                for (uint32_t k = 0; k < my_n && !any_front; k++) {
+                    const uint32_t ty = __umul24(k, my_magic) >> 16, row = miny + ty;
+                    if (((m64 >> k) & 1ull) && row >= y0 && row < y1)
+                        any_front = my_depth <= cut32[__umul24(row - y0, gx) + minx + (k - __umul24(ty, my_w))];
+                }
+                relevant = any_front;
+            }
         }
         uint64_t todo = __ballot(relevant);
         while (todo) {
@@ -269,6 +289,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
             todo &= todo - 1;
             const uint32_t n0 = RL(my_n, j);
             const uint32_t g = RL(my_g, j), w = RL(my_w, j), minx = RL(my_minx, j), miny = RL(my_miny, j);
+            const float gdepth = __uint_as_float(RL(__float_as_uint(my_depth), j));
             if (n0 <= 64u) {
                 const uint32_t mg = RL(my_magic, j);
                 const uint64_t mask = CULL ? ((uint64_t)RL(my_mask.x, j) | ((uint64_t)RL(my_mask.y, j) << 32)) : ~0ull;
@@ -278,6 +299,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                 bool hit = lane < n0 && ((mask >> lane) & 1ull) && row >= y0 && row < y1;
                 const uint32_t tl = __umul24(row - y0, gx) + minx + tx;
                 if (LAYER == 2 && hit) hit = open8[tl] != 0;
+                if (has_cut && hit) hit = gdepth <= cut32[tl];
                 touch(hit, tl, g);
             } else {
                 // big footprint (> 64 tiles): never culled, generic division
@@ -288,6 +310,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                     bool hit = k < n0 && row >= y0 && row < y1;
                     const uint32_t tl = (row - y0) * gx + minx + tx;
                     if (LAYER == 2 && hit) hit = open8[tl] != 0;
+                    if (has_cut && hit) hit = gdepth <= cut32[tl];
                     touch(hit, tl, g);
                 }
             }
@@ -376,6 +399,7 @@ __global__ void layer_split_kernel(uint32_t *__restrict__ counters, uint32_t chu
         uint32_t cA = (nact * front_256 + 255u) >> 8;
         if (cA > nact) cA = nact;
         counters[4] = 0; counters[5] = cA; counters[6] = cA; counters[7] = nact;
+        counters[8] = 0;      // tiles whose truncated list ended unsaturated (render_fwd, depth cuts)
     }
 }
 
@@ -434,7 +458,8 @@ int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, ch
     }
     hipLaunchKernelGGL(gather_sorted_kernel, dim3((L.P + 255) / 256), dim3(256), 0, stream, sorted_ids,
                        reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint2 *>(state + L.o_tile_mask),
-                       counters, (uint32_t)L.P, reinterpret_cast<uint4 *>(scratch + L.s_rec),
+                       reinterpret_cast<const float4 *>(state + L.o_rgbd), counters, (uint32_t)L.P,
+                       reinterpret_cast<uint4 *>(scratch + L.s_rec),
                        reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);
     W3D_LAUNCH_CHECK(v.debug, stream);
     hipLaunchKernelGGL(layer_split_kernel, dim3(1), dim3(64), 0, stream, counters, L.chunk, (uint32_t)W3D_FRONT_LAYER_256);
@@ -447,7 +472,9 @@ static void launch_walk(const W3DLayout &L, const w3d_view &v, char *state, char
                         uint64_t capacity, hipStream_t stream) {
     const W3DBands bands = w3d_pick_bands(L);
     const dim3 grid((L.C + 3) / 4, bands.count);
-    const size_t lds = (size_t)bands.tbpad * (MODE == 0 ? 2 : 4) * 4 + (LAYER == 2 ? (size_t)bands.tbpad * 4 : 0);
+    const float *cut = (LAYER == 0) ? v.tile_depth_cut : nullptr;      // depth cuts only in the single-pass mode
+    const size_t lds = (size_t)bands.tbpad * (MODE == 0 ? 2 : 4) * 4 + (LAYER == 2 ? (size_t)bands.tbpad * 4 : 0) +
+                       (cut ? (size_t)bands.tbpad * 4 * 4 : 0);
     const uint4 *rec = reinterpret_cast<const uint4 *>(scratch + L.s_rec);
     const uint2 *rmask = reinterpret_cast<const uint2 *>(scratch + L.s_rec_mask);
     const uint32_t *counters = reinterpret_cast<const uint32_t *>(state + L.o_counters);
@@ -456,10 +483,10 @@ static void launch_walk(const W3DLayout &L, const w3d_view &v, char *state, char
     const uint8_t *open = reinterpret_cast<const uint8_t *>(state + L.o_tile_open);
     if (v.tile_cull)
         hipLaunchKernelGGL((chunk_walk_kernel<MODE, true, LAYER>), grid, dim3(256), lds, stream, rec, rmask, counters, L.chunk, L.C,
-                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, open);
+                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, open, cut);
     else
         hipLaunchKernelGGL((chunk_walk_kernel<MODE, false, LAYER>), grid, dim3(256), lds, stream, rec, rmask, counters, L.chunk, L.C,
-                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, open);
+                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, open, cut);
 }
 
 // per-chunk per-tile counts of one layer (0 = all chunks, 1 = front, 2 = back/open tiles) and the list offsets

@@ -31,6 +31,7 @@ struct W3DLayout {
     // ---- state buffer (kept until backward)
     uint64_t o_counters;   // u32[16]: [0]=num_visible [1]=num_rendered [2]=front-layer list length
                            //          [3]=capacity of the list buffer given to stage 2 [4..7]=layer chunk ranges
+                           //          [8]=tiles whose depth-cut list ended unsaturated
     uint64_t o_xy;         // float2[P]
     uint64_t o_conic_op;   // float4[P]
     uint64_t o_rgbd;       // float4[P]  (r,g,b,depth)

@@ -95,7 +95,8 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                   const float *__restrict__ gt_mask, int num_obj, int P, float *__restrict__ used_count,
                   int32_t *__restrict__ contrib_num, uint32_t list_cap, uint32_t *__restrict__ counters,
-                  const uint32_t *__restrict__ tile_startA, uint8_t *__restrict__ tile_open) {
+                  const uint32_t *__restrict__ tile_startA, uint8_t *__restrict__ tile_open,
+                  const float *__restrict__ cut_in, float *__restrict__ cut_out) {
     __shared__ StagedLDS lds[4];
     __shared__ int s_labels[4][FLASH ? 256 : 1];
     uint32_t tile;
@@ -157,6 +158,8 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     const uint32_t start = min(tile_start[tile], list_cap), end = min(tile_start[tile + 1], list_cap);
     // contributor numbers continue across layers: the back list follows the tile's front list
     const uint32_t first = (LAYER == 2) ? (tile_startA[tile + 1] - tile_startA[tile]) : 0u;
+    uint32_t deepest = 0;        // 1-based position of the deepest entry that changed any pixel's state
+    const bool track_cut = (cut_in != nullptr) || (cut_out != nullptr);
     for (uint32_t base = start; base < end; base += 64) {
         if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
         const uint32_t n = min(64u, end - base);
@@ -183,6 +186,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 Tr[k] = apply ? test_T : Tr[k];
                 last[k] = apply ? contributor : last[k];
                 done[k] = done[k] || stop;
+                if (LAYER == 0 && track_cut && __ballot(apply || stop) != 0ull) deepest = contributor;
                 if (FLASH) { wk[k] = w; napplied[k] += apply ? 1 : 0; any_applied = any_applied || apply; }
             }
             if (FLASH && gt_mask && used_count) {
@@ -203,6 +207,22 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     }
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t HW = (size_t)H * W;
+    if (LAYER == 0 && (cut_in || cut_out)) {
+        // speculative list truncation (w3d_view.tile_depth_cut): verify this visit, prepare the next one
+        const bool saturated = __ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull;
+        if (lane == 0) {
+            if (cut_out) {
+                float c = __builtin_inff();
+                if (saturated && deepest > 0) {
+                    const float d = rgbd[point_list[start + deepest - 1]].w;
+                    c = d + fmaxf(0.03f * d, 1e-3f);
+                }
+                cut_out[tile] = c;
+            }
+            // a truncated list that ended before every pixel saturated may have lost contributors
+            if (cut_in && !saturated && cut_in[tile] < __builtin_inff()) atomicAdd(&counters[8], 1u);
+        }
+    }
     if (LAYER == 1) {
         const bool open = __ballot(!(done[0] && done[1] && done[2] && done[3])) != 0ull;
         if (lane == 0) tile_open[tile] = open ? 1 : 0;
@@ -445,7 +465,8 @@ int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const 
         reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg, out_color, out_depth, out_alpha,                    \
         reinterpret_cast<float *>(state + L.o_final_T), reinterpret_cast<uint32_t *>(state + L.o_n_contrib), gt_mask, \
         num_obj, L.P, used_count, contrib_num, (uint32_t)(list_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : list_capacity),      \
-        reinterpret_cast<uint32_t *>(state + L.o_counters), tsA, reinterpret_cast<uint8_t *>(state + L.o_tile_open)
+        reinterpret_cast<uint32_t *>(state + L.o_counters), tsA, reinterpret_cast<uint8_t *>(state + L.o_tile_open), \
+        (layer == 0 ? v.tile_depth_cut : nullptr), (layer == 0 ? v.tile_depth_cut_out : nullptr)
     {
         W3D_PROF("render_fwd", stream);
         if (flash) hipLaunchKernelGGL((render_fwd_kernel<true, 0>), dim3(blocks), dim3(256), 0, stream, ARGS);

@@ -85,15 +85,22 @@ def finish(handle):
     pinned, ev = pend
     ev.synchronize()
     handle["num_visible"], handle["num_rendered"] = int(pinned[0]), int(pinned[1])
+    handle["suspect_tiles"] = int(pinned[8])      # tiles whose depth-cut list ended before they saturated
     handle["pending"] = None
-    _capacity.observe(handle["num_rendered"])
-    return handle["num_rendered"] <= handle["capacity"]
+    if handle["suspect_tiles"] == 0 or handle["depth_cut"] is None:
+        _capacity.observe(handle["num_rendered"])
+    return handle["num_rendered"] <= handle["capacity"] and handle["suspect_tiles"] == 0
 
 
-def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True):
+def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, depth_cut=None, want_cut=False):
     """Forward on the raw parameters.  Returns the dict of render() (minus viewspace_points) plus a
     `handle` for backward_raw().  sync=False: no host synchronisation (see ListCapacity); the caller
-    must call finish(handle) before trusting the outputs."""
+    must call finish(handle) before trusting the outputs.
+
+    depth_cut (T,) float tensor from an earlier visit of this camera: per-tile depth beyond which
+    nothing is binned (w3d_view.tile_depth_cut) — finish() is False when a tile turned out to need more
+    (repeat the view with depth_cut=None).  want_cut: handle["depth_cut_out"] receives the cuts for the
+    next visit."""
     dev = model.flat.device
     if not model.flat.is_cuda:
         raise RuntimeError("the fused step needs the model on the GPU; there is no CPU path")
@@ -103,6 +110,16 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True):
                                       scaling_modifier, cam.world_view_transform, cam.full_proj_transform,
                                       model.active_sh_degree, cam.camera_center, False, False)
     view = _View(s, (model.max_sh_degree + 1) ** 2, dev)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    cut_out = None
+    if depth_cut is not None:
+        if sync:
+            raise ValueError("depth cuts need the asynchronous forward (sync=False)")
+        assert depth_cut.numel() == T and depth_cut.dtype == torch.float32 and depth_cut.is_cuda
+        view.c.tile_depth_cut = depth_cut.data_ptr()
+    if want_cut:
+        cut_out = torch.empty(T, dtype=torch.float32, device=dev)
+        view.c.tile_depth_cut_out = cut_out.data_ptr()
     prm = _raw_params(model)
     with torch.cuda.device(dev):
         stream = stream_ptr(dev)
@@ -123,11 +140,6 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True):
             view.c.depth_layers = 2 if DEPTH_LAYERS else 0
             check(lib.w3d_forward_stage1_raw(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(radii), ptr(state),
                                              ptr(scratch), None, stream))
-            pinned = torch.empty(2, dtype=torch.int32, pin_memory=True)
-            pinned.copy_(state[:8].view(torch.int32), non_blocking=True)     # counters sit at offset 0 of the state
-            ev = torch.cuda.Event()
-            ev.record()
-            pending = (pinned, ev)
             R, V = guess, -1
         plist = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
@@ -135,8 +147,16 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True):
         alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
         check(lib.w3d_forward_stage2(ctypes.byref(view.c), P, ptr(state), ptr(scratch), ptr(plist), ctypes.c_uint64(R),
                                      ptr(color), ptr(depth), ptr(alpha), None, 0, None, None, None, None, stream))
+        if guess != 0:
+            # counters (offset 0 of the state) travel to pinned memory AFTER the blend so that the depth-cut
+            # verdict is included; finish() waits on the event
+            pinned = torch.empty(16, dtype=torch.int32, pin_memory=True)
+            pinned.copy_(state[:64].view(torch.int32), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            pending = (pinned, ev)
     handle = dict(view=view, P=P, state=state, point_list=plist, radii=radii, num_rendered=R, num_visible=V,
-                  capacity=R, pending=pending)
+                  capacity=R, pending=pending, depth_cut=depth_cut, depth_cut_out=cut_out, suspect_tiles=0)
     return {"render": color, "radii": radii, "depth": depth, "alpha": alpha, "handle": handle}
 
 

@@ -15,6 +15,8 @@ same step; then
   * densify/prune then run identically on every rank (same statistics, same RNG seed for the
     split samples) so the replicas stay in lock-step without a parameter broadcast.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -54,6 +56,14 @@ class Trainer:
         # force_exchange: run the multi-rank exchange path (collectives, sharded optimizer) even in a
         # 1-rank process group — lets the RCCL code path be exercised on a single GPU
         self.force_exchange = bool(force_exchange)
+        # speculative per-tile list truncation from the previous visit of each camera (fused step only).
+        # OFF by default: exact (verified, view repeated on a miss) but measured slower on the benchmark —
+        # with the banded walk only ~12 Gaussians per 64-batch reach the serial loop, so the per-lane
+        # pre-filter over each Gaussian's tiles costs as much as it saves, and the fast-changing synthetic
+        # scene misses its cuts on ~60 % of the revisits.
+        self.use_depth_cuts = os.environ.get("W3D_DEPTH_CUTS", "0") == "1"
+        self.depth_cuts = {}
+        self.cut_misses = 0
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.perm = torch.randperm(len(cameras), generator=g).tolist()
         self.last = {}
@@ -157,12 +167,20 @@ class Trainer:
             # statistics are updated inside the backward kernel only when the list-capacity guess is known to
             # hold (synchronous forward); with the speculative forward they are applied after finish()
             fused_stats = False
+            # per-camera depth cuts from the previous visit (speculative list truncation, verified by finish())
+            key = id(cam)
+            cut = self.depth_cuts.get(key) if self.use_depth_cuts else None
             while True:
-                pkg = render_raw(cam, m, self.bg, sync=False)
+                pkg = render_raw(cam, m, self.bg, sync=False, depth_cut=cut, want_cut=self.use_depth_cuts)
                 loss, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
                 gnorm, _ = backward_raw(m, pkg["handle"], dimg, update_stats=fused_stats, want_norm=True)
                 if finish(pkg["handle"]):        # the only host wait of the step, with the backward already queued
                     break
+                if pkg["handle"]["suspect_tiles"]:
+                    cut = None                   # some tile needed more than its cut allowed: repeat without cuts
+                    self.cut_misses += 1
+            if self.use_depth_cuts and pkg["handle"]["depth_cut_out"] is not None:
+                self.depth_cuts[key] = pkg["handle"]["depth_cut_out"]
             if single and tracking:
                 vis = pkg["radii"] > 0
                 m.xyz_gradient_accum += gnorm[:, None]          # gnorm is 0 on culled Gaussians
