@@ -210,6 +210,25 @@ def main():
         dist.all_reduce(r_el, op=dist.ReduceOp.MAX)
     mpix = world * n_r * args.width * args.height / 1e6 / float(r_el)
 
+    # config C4: FlashSplat per-mask contribution render (run_3d_seg.py's inner call), binary mask, same scene
+    from w3d_amd.gaussian_renderer import flashsplat_render
+    from w3d_amd.train import PipelineParams
+    yy, xx = torch.meshgrid(torch.arange(args.height, device=dev), torch.arange(args.width, device=dev), indexing="ij")
+    mask = (((xx - args.width // 2) ** 2 + (yy - args.height // 2) ** 2) < (args.height // 3) ** 2).float()
+    n_f = 8
+    with torch.no_grad():
+        flashsplat_render(cams[0], model, PipelineParams(), bg, gt_mask=mask, obj_num=1)
+        sync()
+        f0 = time.perf_counter()
+        counts = None
+        for i in range(n_f):
+            uc = flashsplat_render(cams[i % len(cams)], model, PipelineParams(), bg, gt_mask=mask, obj_num=1)["used_count"]
+            counts = uc if counts is None else counts + uc
+        sync()
+        f1 = time.perf_counter()
+    flash_vps = world * n_f / (f1 - f0)
+    del counts
+
     if rank == 0:
         ws = [workload_stats(model, cams[i], bg, dev) for i in (0, len(cams) // 2)]
         V = sum(w["V"] for w in ws) / len(ws)
@@ -240,7 +259,7 @@ def main():
             "value": round(world * args.steps / elapsed, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "render_mpix_per_s": round(mpix, 1),
+            "render_mpix_per_s": round(mpix, 1), "flashsplat_views_per_s": round(flash_vps, 1),
             "config": {"workload": f"C3: plot-shaped synthetic scene, {P} Gaussians, SH degree 3, "
                                    f"{args.width}x{args.height}, {args.views} overhead cameras, depth+alpha channels",
                        "points": P, "image": [args.width, args.height], "views_per_step": world,

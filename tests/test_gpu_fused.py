@@ -258,3 +258,44 @@ def test_depth_cuts_are_exact_or_repeated():
     # cuts that are far too shallow must be reported, not silently rendered
     bad = render_raw(cam, m, bg, sync=False, depth_cut=torch.full_like(cuts, 0.5))
     assert not finish(bad["handle"]) and bad["handle"]["suspect_tiles"] > 0
+
+
+def test_training_with_densification_prune_and_opacity_reset():
+    """The whole step incl. the episodic host logic (rows A10-A11): clone / split / prune rebuild the flat
+    buffers and the Adam moments, opacity reset clears its moments; the kernels keep running on the new P."""
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.train import Trainer, render_views
+    dev = torch.device("cuda:0")
+    W, H = 160, 120
+    cams = [c.to(dev) for c in make_cameras(6, W, H)]
+    bg = torch.zeros(3, device=dev)
+    target = make_scene(3000, seed=15, scale_mean=0.04)
+    tm = GaussianModel(3, device=dev)
+    tm.create_from_tensors(target.xyz, target.features_dc, target.features_rest, target.scaling, target.rotation, target.opacity)
+    tm.active_sh_degree = 3
+    for cam, img in zip(cams, render_views(tm, cams, bg)):
+        cam.original_image = img.clamp(0, 1)
+    sc = make_scene(1500, seed=16, scale_mean=0.04)
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    m.active_sh_degree = 3
+
+    class Opt(OptimizationParams):
+        densify_from_iter = 10
+        densification_interval = 10
+        opacity_reset_interval = 45
+        densify_until_iter = 70
+        densify_grad_threshold = 0.00005
+    opt = Opt()
+    m.training_setup(opt)
+    tr = Trainer(m, cams, opt, bg, densify=True, cameras_extent=2.0)
+    sizes, losses = [], []
+    for it in range(1, 91):
+        losses.append(float(tr.step(it)))
+        sizes.append(m.num_points)
+    assert len(set(sizes)) > 3                       # P changed several times (clone/split/prune)
+    assert m.flat.numel() == 59 * m.num_points and m.optimizer.exp_avg.numel() == m.flat.numel()
+    assert m.xyz_gradient_accum.shape[0] == m.num_points and m.max_radii2D.shape[0] == m.num_points
+    assert torch.isfinite(m.flat).all() and all(np.isfinite(losses))
+    assert min(losses[30:44]) < np.mean(losses[:5])        # learning happens between the opacity resets (45, 90)

@@ -209,3 +209,27 @@ def test_variant_validation_messages():
         _check_variants(t, None, None, None, None)
     _check_variants(t, None, t, t, None)
     _check_variants(None, t, None, None, t)
+
+
+def test_ply_roundtrip_and_layout(tmp_path):
+    """PLY snapshot (row N4): attribute order and channel-major SH layout of the reference
+    (scene/gaussian_model.py:196-232), read back by name."""
+    m, sc = _model(P=17, seed=9)
+    m._which_object[:, 0] = torch.arange(17, dtype=torch.int)
+    path = os.path.join(tmp_path, "point_cloud", "iteration_7", "point_cloud.ply")
+    m.save_ply(path)
+    raw = open(path, "rb").read()
+    head = raw[: raw.index(b"end_header\n")].decode()
+    props = [ln.split()[-1] for ln in head.split("\n") if ln.startswith("property")]
+    assert props[:9] == ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"]
+    assert props[9] == "f_rest_0" and props[53] == "f_rest_44" and props[54:] == \
+        ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3", "which_object"]
+    assert "element vertex 17" in head and len(props) == 63
+    data = np.frombuffer(raw, dtype="<f4", offset=raw.index(b"end_header\n") + 11).reshape(17, 63)
+    # channel-major: f_rest_0..14 are the 15 coefficients of channel 0
+    assert np.allclose(data[:, 9:24], sc.features_rest[:, :, 0].numpy())
+    assert np.allclose(data[:, 6:9], sc.features_dc[:, 0, :].numpy())
+    m2 = GaussianModel(3, device="cpu")
+    m2.load_ply(path)
+    assert torch.equal(m2.flat, m.flat) and torch.equal(m2._which_object, m._which_object)
+    assert m2.active_sh_degree == 3

@@ -306,6 +306,62 @@ class GaussianModel:
             self._p["opacity"].copy_(new)
         self.optimizer.zero_moments("opacity")
 
+    # ------------------------------------------------------------------ PLY snapshots (gaussian_model.py:196-293)
+    def _ply_attributes(self):
+        names = ["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(3)]
+        names += [f"f_rest_{i}" for i in range(self._features_rest.shape[1] * 3)]
+        names += ["opacity"] + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)] + ["which_object"]
+        return names
+
+    def save_ply(self, path):
+        """Binary little-endian PLY with the reference's attribute order and layout: all float32;
+        f_dc / f_rest stored CHANNEL-major (transpose(1,2).flatten) as scene/gaussian_model.py:217-218 does."""
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+        P = self.num_points
+        cols = [self._xyz.detach(), torch.zeros(P, 3, device=self.device),
+                self._features_dc.detach().transpose(1, 2).flatten(start_dim=1),
+                self._features_rest.detach().transpose(1, 2).flatten(start_dim=1),
+                self._opacity.detach(), self._scaling.detach(), self._rotation.detach(),
+                self._which_object.to(torch.float32).reshape(P, 1)]
+        data = torch.cat([c.reshape(P, -1).float() for c in cols], dim=1).contiguous().cpu().numpy().astype("<f4")
+        names = self._ply_attributes()
+        assert data.shape[1] == len(names)
+        header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % P
+        header += "".join("property float %s\n" % n for n in names) + "end_header\n"
+        with open(path, "wb") as f:
+            f.write(header.encode("ascii"))
+            f.write(data.tobytes())
+
+    def load_ply(self, path):
+        """Inverse of save_ply (reference load_ply, gaussian_model.py:239-293): attribute lookup by NAME, so
+        files written by the reference load as well."""
+        with open(path, "rb") as f:
+            raw = f.read()
+        end = raw.index(b"end_header\n") + len(b"end_header\n")
+        lines = raw[:end].decode("ascii").split("\n")
+        assert "binary_little_endian" in lines[1], "only binary little-endian PLY is supported"
+        P = int([ln for ln in lines if ln.startswith("element vertex")][0].split()[-1])
+        props = [ln.split()[-1] for ln in lines if ln.startswith("property")]
+        assert all(ln.split()[1] == "float" for ln in lines if ln.startswith("property")), "expected float32 properties"
+        data = np.frombuffer(raw, dtype="<f4", count=P * len(props), offset=end).reshape(P, len(props))
+        col = {n: i for i, n in enumerate(props)}
+
+        def take(prefix):
+            names = sorted((n for n in props if n.startswith(prefix)), key=lambda n: int(n.split("_")[-1]))
+            return torch.tensor(np.stack([data[:, col[n]] for n in names], axis=1))
+        xyz = torch.tensor(np.stack([data[:, col[k]] for k in ("x", "y", "z")], axis=1))
+        n_rest = len([n for n in props if n.startswith("f_rest_")])
+        assert n_rest == 3 * ((self.max_sh_degree + 1) ** 2 - 1)
+        f_dc = take("f_dc_").reshape(P, 3, 1).transpose(1, 2).contiguous()
+        f_rest = take("f_rest_").reshape(P, 3, n_rest // 3).transpose(1, 2).contiguous()
+        self._bind(dict(xyz=xyz, f_dc=f_dc, f_rest=f_rest, opacity=torch.tensor(data[:, col["opacity"]].copy())[:, None],
+                        scaling=take("scale_"), rotation=take("rot_")))
+        wo = data[:, col["which_object"]] if "which_object" in col else np.zeros(P, np.float32)
+        self._which_object = torch.tensor(wo.copy()).to(torch.int)[:, None].to(self.device)
+        self._reset_stats()
+        self.active_sh_degree = self.max_sh_degree
+
     # ------------------------------------------------------------------ checkpoint (gaussian_model.py:63-99)
     def capture(self):
         return (self.active_sh_degree, self._xyz.detach().clone(), self._features_dc.detach().clone(),
