@@ -93,14 +93,14 @@ def test_training_step_decreases_loss_and_tracks_stats():
     assert torch.isfinite(m.flat).all()
 
 
-def test_fused_raw_step_equals_autograd_step():
+@pytest.mark.parametrize("deg,W,H", [(2, 200, 152), (0, 176, 144), (1, 203, 149), (3, 160, 128)])
+def test_fused_raw_step_equals_autograd_step(deg, W, H):
     """The fused raw-parameter path and the drop-in render()+autograd path are the same arithmetic:
     same image, same gradient bucket, same densification statistics, same parameters after Adam."""
     from w3d_amd.synth import make_scene, make_cameras
     from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
     from w3d_amd.train import Trainer
     dev = torch.device("cuda:0")
-    W, H = 200, 152
     cams = [c.to(dev) for c in make_cameras(4, W, H)]
     g = torch.Generator().manual_seed(0)
     for cam in cams:
@@ -111,7 +111,7 @@ def test_fused_raw_step_equals_autograd_step():
     for fused in (False, True):
         m = GaussianModel(3, device=dev)
         m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
-        m.active_sh_degree = 2
+        m.active_sh_degree = deg
         opt = OptimizationParams()
         m.training_setup(opt)
         tr = Trainer(m, cams, opt, bg, densify=False, fused=fused)
