@@ -19,6 +19,7 @@
 namespace {
 
 #define LOG2E 1.4426950408889634f
+#define W3D_ACC_STRIDE 12      // floats per entry in the backward's LDS accumulator (10 used; 48 B keeps float4 alignment)
 
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_mov(float src) {
@@ -276,6 +277,19 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
     for (int i = 0; i < N; i++) v[i] += dpp_mov<0x143, 0xC>(v[i]);
 }
 
+// first four DPP stages only: every lane ends up with the sum over its 16-lane row
+template <int N>
+__device__ __forceinline__ void row_sum_n(float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += dpp_mov<0xB1>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += dpp_mov<0x4E>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += dpp_mov<0x141>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += dpp_mov<0x140>(v[i]);
+}
+
 struct Staged { float4 a, b, c; };
 __device__ __forceinline__ Staged gather_entry(uint32_t g, const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
                                                const float4 *__restrict__ rgbd) {
@@ -300,10 +314,13 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   const float *__restrict__ dL_dalpha_px, float *__restrict__ grad2d,
                   const uint32_t *__restrict__ counters, const uint32_t *__restrict__ tile_startB) {
     __shared__ StagedLDS lds[4];
+    __shared__ __align__(16) float acc_all[4][64 * W3D_ACC_STRIDE];   // per-entry sums of the current batch
+    constexpr int NV = HAS_DA ? 10 : 9;
     uint32_t tile;
     if (!wave_to_tile(T, tile)) return;
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     StagedLDS &s = lds[wv];
+    float *acc = acc_all[wv];
     const uint32_t tx0 = (tile % gx) * W3D_TILE, ty0 = (tile / gx) * W3D_TILE;
     const uint32_t lx = lane & 7, ly = lane >> 3;
     const size_t HW = (size_t)H * W;
@@ -360,6 +377,11 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     for (int b = nb - 1; b >= 0; b--) {
         const uint32_t n = min(64u, maxc - (uint32_t)b * 64u);
         s.a[lane] = nxt.a; s.b[lane] = nxt.b; s.c[lane] = nxt.c;
+        {
+            float4 *z = reinterpret_cast<float4 *>(&acc[lane * W3D_ACC_STRIDE]);
+            z[0] = make_float4(0.f, 0.f, 0.f, 0.f); z[1] = z[0]; z[2] = z[0];
+        }
+        uint64_t touched = 0ull;
         __builtin_amdgcn_wave_barrier();
         if (b > 0) {
             nxt = (ids != 0xFFFFFFFFu) ? gather_entry(ids, xy, conic_op, rgbd) : Staged{};
@@ -414,21 +436,37 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 v[6] += dch * dp0[k]; v[7] += dch * dp1[k]; v[8] += dch * dp2[k];
             }
             if (__ballot(any) == 0ull) continue;
-            // one wave reduction per tile instance, then one 36/40-B record update
-            wave_sum_n(v);
-            float tot[HAS_DA ? 10 : 9];
+            // reduce within the 16-lane rows in registers (4 DPP stages), then one lane per row adds the row sums
+            // into this entry's LDS accumulator (4 lanes on one address per ds_add_f32); the batch is flushed
+            // below with 4 records per atomic instruction
+            row_sum_n(v);
+            touched |= 1ull << j;
+            if ((lane & 15u) == 0u) {
 #pragma unroll
-            for (int i = 0; i < (HAS_DA ? 10 : 9); i++) tot[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i]), 63));
-            // record: [0] dL/dmean2D.x [1] .y [2] dL/dconic.x [3] .y (half) [4] .z [5] opacity [6..8] rgb [9] depth
-            float val = -(eb.x * tot[0] + eb.y * tot[1]) * ddelx_dx;
-            val = lane == 1u ? -(eb.z * tot[1] + eb.y * tot[0]) * ddely_dy : val;
-            val = lane == 2u ? -0.5f * tot[2] : val;
-            val = lane == 3u ? -0.5f * tot[3] : val;
-            val = lane == 4u ? -0.5f * tot[4] : val;
-#pragma unroll
-            for (int i = 5; i < (HAS_DA ? 10 : 9); i++) val = (lane == (uint32_t)i) ? tot[i] : val;
-            const uint32_t g = __float_as_uint(ea.w);
-            if (lane < (HAS_DA ? 10u : 9u)) atomicAdd(&grad2d[(size_t)g * W3D_G2D_STRIDE + lane], val);
+                for (int i = 0; i < NV; i++) atomicAdd(&acc[j * W3D_ACC_STRIDE + i], v[i]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // flush: lane -> (entry e = 4*pass + lane/16, value k = lane%16); the five moments become
+        // dL/dmean2D and dL/dconic here.  record: [0] dL/dmean2D.x [1] .y [2] dL/dconic.x [3] .y (half) [4] .z
+        // [5] opacity [6..8] rgb [9] depth
+        {
+            const uint32_t k = lane & 15u, sub = lane >> 4;
+#pragma unroll 4
+            for (uint32_t pass = 0; pass < 16; pass++) {
+                const uint32_t e = pass * 4u + sub;
+                if (((touched >> e) & 1ull) && k < (uint32_t)NV) {
+                    const float *a = &acc[e * W3D_ACC_STRIDE];
+                    const float4 co = s.b[e];
+                    float val;
+                    if (k == 0u) val = -(co.x * a[0] + co.y * a[1]) * ddelx_dx;
+                    else if (k == 1u) val = -(co.z * a[1] + co.y * a[0]) * ddely_dy;
+                    else if (k < 5u) val = -0.5f * a[k];
+                    else val = a[k];
+                    const uint32_t g = __float_as_uint(s.a[e].w);
+                    atomicAdd(&grad2d[(size_t)g * W3D_G2D_STRIDE + k], val);
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
