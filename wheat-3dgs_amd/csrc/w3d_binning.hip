@@ -342,7 +342,8 @@ seg_sum_kernel(const uint16_t *__restrict__ cnt, uint32_t C, uint32_t T, uint32_
     layer_range(counters, rng, C, lo, hi);
     const uint32_t c0 = max(sg * seg, lo), c1 = min(min(C, sg * seg + seg), hi);
     uint32_t s = 0;
-    for (uint32_t c = c0; c < c1; c++) s += cnt[(size_t)c * T + t];
+#pragma unroll 16
+    for (uint32_t c = c0; c < c1; c++) s += cnt[(size_t)c * T + t];      // independent loads: keep many in flight
     part[(size_t)sg * T + t] = s;
 }
 
@@ -357,8 +358,10 @@ tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, u
     for (uint32_t base = 0; base < T; base += 1024) {
         const uint32_t t = base + threadIdx.x;
         uint32_t v = 0;
-        if (t < T)
+        if (t < T) {
+#pragma unroll 16
             for (uint32_t s = 0; s < nseg; s++) v += part[(size_t)s * T + t];
+        }
         uint32_t tot;
         const uint32_t ex = block_exclusive_scan(v, wave_tot, tot);
         if (t < T) tile_start[t] = carry + ex;
@@ -383,7 +386,15 @@ chunk_off_kernel(const uint16_t *__restrict__ cnt, const uint32_t *__restrict__ 
     const uint32_t c0 = max(sg * seg, lo), c1 = min(min(C, sg * seg + seg), hi);
     uint32_t run = tile_start[t];
     for (uint32_t s = 0; s < sg; s++) run += part[(size_t)s * T + t];
-    for (uint32_t c = c0; c < c1; c++) {
+    uint32_t c = c0;
+    for (; c + 8 <= c1; c += 8) {         // 8 count loads in flight per step of the running sum
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = cnt[(size_t)(c + i) * T + t];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { off[(size_t)(c + i) * T + t] = run; run += v[i]; }
+    }
+    for (; c < c1; c++) {
         off[(size_t)c * T + t] = run;
         run += cnt[(size_t)c * T + t];
     }
