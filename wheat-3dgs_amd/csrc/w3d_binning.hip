@@ -36,6 +36,7 @@ radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items,
     __builtin_amdgcn_wave_barrier();
     if (run < n_runs) {
         const uint32_t beg = run * items, end = min(n, beg + items);
+#pragma unroll 8
         for (uint32_t i = beg + lane; i < end; i += 64) {
             const uint32_t d = (keys[i] >> shift) & (W3D_RADIX_BINS - 1u);
             atomicAdd(const_cast<uint32_t *>(&h_all[wv][d]), 1u);
@@ -127,11 +128,14 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
     __builtin_amdgcn_wave_barrier();
     const uint32_t beg = run * items, end = min(n, beg + items);
     const uint64_t lt = lanemask_lt();
+    // software pipeline: the next 64 (key, id) pairs are in flight while the current ones are ranked
+    uint32_t nkey = (beg + lane < end) ? keys_in[beg + lane] : 0u;
+    uint32_t nval = (beg + lane < end) ? vals_in[beg + lane] : 0u;
     for (uint32_t base = beg; base < end; base += 64) {
         const uint32_t i = base + lane;
         const bool valid = i < end;
-        const uint32_t key = valid ? keys_in[i] : 0u;
-        const uint32_t val = valid ? vals_in[i] : 0u;
+        const uint32_t key = nkey, val = nval;
+        if (i + 64 < end) { nkey = keys_in[i + 64]; nval = vals_in[i + 64]; }
         const uint32_t d = (key >> shift) & (W3D_RADIX_BINS - 1u);
         // lanes holding the same digit (stable rank = number of such lanes below me)
         uint64_t peers = __ballot(valid);
