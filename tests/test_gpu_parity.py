@@ -364,3 +364,32 @@ def test_determinism_and_linearity_full_size():
         assert float((b - 2 * a).abs().max() / a.abs().max()) < 2e-3
     # culled Gaussians receive exactly zero gradient
     assert float(t1["shs"].grad[~vis].abs().max()) == 0 and float(g1[~vis].abs().max()) == 0
+
+
+@pytest.mark.parametrize("P,W,H,scale", [(1, 33, 17, 0.05), (20_000, 3840, 2160, 0.004), (150_000, 97, 61, 0.02),
+                                         (70_000, 16, 16, 0.01)])
+def test_extreme_shapes_against_oracle(P, W, H, scale):
+    """Sizes around the design limits: a single Gaussian, a 4K frame (32 400 tiles, many bands), far more
+    Gaussians than pixels (long per-tile lists, every tile saturated), one single tile holding everything."""
+    sc = make_scene(P, seed=P % 97, scale_mean=scale)
+    if P == 1:
+        sc.xyz[0] = torch.tensor([0.0, 0.0, 0.3])
+    cam = make_cameras(3, W, H)[1]
+    bg = (0.05, 0.1, 0.15)
+    d = view_inputs(sc, cam)
+    rng = np.random.RandomState(1)
+    gc = rng.randn(3, H, W).astype(np.float32)
+    o = make_oracle(cam, bg, nthreads=8)
+    ref = o.forward(**np_inputs(d))
+    gref = o.backward(gc, None, None)
+    vis = ref["radii"] > 0
+    for cull in (False, True):
+        out, g = run_hip(d, cam, bg, grads=(gc, None, None), tile_cull=cull)
+        if not cull:
+            check_integers(out, o, ref)
+        else:
+            np.testing.assert_array_equal(out["radii"], ref["radii"])
+        check_images(out, ref, f"[{P} {W}x{H} cull={cull}] ")
+        if vis.any():
+            check_grads(g, gref, vis, f"[{P} {W}x{H} cull={cull}] ", tol=2e-4)
+    o.free()
