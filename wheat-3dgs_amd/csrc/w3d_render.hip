@@ -58,9 +58,11 @@ __device__ __forceinline__ uint32_t wave_to_tile(uint32_t T, uint32_t &tile) {
 }
 
 struct StagedLDS {
-    float4 a[64];  // x, y, pmin (power below which alpha < 1/255 for sure), id bits
-    float4 b[64];  // conic.x, conic.y, conic.z, opacity
+    float4 a[64];  // x, y, pmin2 (log2-domain power below which alpha < 1/255 for sure), id bits
+    float4 b[64];  // conic.x, conic.y, conic.z, opacity            (only the backward's flush reads it)
     float4 c[64];  // r, g, b, depth
+    float4 d[64];  // -0.5*log2e*conic.x, -log2e*conic.y, -0.5*log2e*conic.z, opacity: the exponent in the
+                   // log2 domain is dx*(d.x*dx + d.y*dy) + d.z*dy*dy — 5 VALU instead of 7 + 1 for the exp2 scale
 };
 
 __device__ __forceinline__ void stage_entries(StagedLDS &s, uint32_t lane, uint32_t n, const uint32_t *__restrict__ list,
@@ -74,9 +76,10 @@ __device__ __forceinline__ void stage_entries(StagedLDS &s, uint32_t lane, uint3
         // alpha = min(0.99, o*exp(power)) >= 1/255 needs power >= -log(255 o); 1e-4 slack covers
         // the rounding of the fast exp, so skipping below pmin never changes a result.
         const float pmin = (co.w > 0.f) ? (-__logf(255.0f * co.w) - 1e-4f) : 1.0f;
-        s.a[lane] = make_float4(p.x, p.y, pmin, __uint_as_float(g));
+        s.a[lane] = make_float4(p.x, p.y, pmin * LOG2E, __uint_as_float(g));
         s.b[lane] = co;
         s.c[lane] = cd;
+        s.d[lane] = make_float4(-0.5f * LOG2E * co.x, -LOG2E * co.y, -0.5f * LOG2E * co.z, co.w);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -166,17 +169,17 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         const uint32_t n = min(64u, end - base);
         stage_entries(s, lane, n, point_list + base, xy, conic_op, rgbd);
         for (uint32_t j = 0; j < n; j++) {
-            const float4 ea = s.a[j], eb = s.b[j], ec = s.c[j];
+            const float4 ea = s.a[j], ed = s.d[j], ec = s.c[j];
             const uint32_t contributor = first + base - start + j + 1;
             float wk[4] = {0.f, 0.f, 0.f, 0.f};
             bool any_applied = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const float dx = ea.x - pxf[k], dy = ea.y - pyf[k];
-                const float power = -0.5f * (eb.x * dx * dx + eb.z * dy * dy) - eb.y * dx * dy;
+                const float power = fmaf(ed.z * dy, dy, fmaf(ed.y, dy, ed.x * dx) * dx);      // log2 domain
                 const bool cand = !done[k] && power <= 0.f && power >= ea.z;
                 if (__ballot(cand) == 0ull) continue;   // whole quadrant untouched by this Gaussian
-                const float alpha = fminf(0.99f, eb.w * __builtin_amdgcn_exp2f(power * LOG2E));
+                const float alpha = fminf(0.99f, ed.w * __builtin_amdgcn_exp2f(power));
                 const float test_T = Tr[k] * (1.f - alpha);
                 const bool ok = cand && alpha >= (1.0f / 255.0f);
                 const bool stop = ok && test_T < 0.0001f;
@@ -297,7 +300,7 @@ __device__ __forceinline__ Staged gather_entry(uint32_t g, const float2 *__restr
     const float4 co = conic_op[g];
     Staged s;
     const float pmin = (co.w > 0.f) ? (-__logf(255.0f * co.w) - 1e-4f) : 1.0f;
-    s.a = make_float4(p.x, p.y, pmin, __uint_as_float(g));
+    s.a = make_float4(p.x, p.y, pmin * LOG2E, __uint_as_float(g));
     s.b = co;
     s.c = rgbd[g];
     return s;
@@ -377,6 +380,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     for (int b = nb - 1; b >= 0; b--) {
         const uint32_t n = min(64u, maxc - (uint32_t)b * 64u);
         s.a[lane] = nxt.a; s.b[lane] = nxt.b; s.c[lane] = nxt.c;
+        s.d[lane] = make_float4(-0.5f * LOG2E * nxt.b.x, -LOG2E * nxt.b.y, -0.5f * LOG2E * nxt.b.z, nxt.b.w);
         {
             float4 *z = reinterpret_cast<float4 *>(&acc[lane * W3D_ACC_STRIDE]);
             z[0] = make_float4(0.f, 0.f, 0.f, 0.f); z[1] = z[0]; z[2] = z[0];
@@ -388,7 +392,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             ids = batch_id(b - 2);
         }
         for (int j = (int)n - 1; j >= 0; j--) {
-            const float4 ea = s.a[j], eb = s.b[j], ec = s.c[j];
+            const float4 ea = s.a[j], ed = s.d[j], ec = s.c[j];
             const uint32_t idx0 = (uint32_t)b * 64u + (uint32_t)j;   // 0-based position in the tile list
             // per-lane partial sums of this tile instance.  Geometry enters through the five moments of
             // m = dL/dG * G:  S1 = sum m dx, S2 = sum m dy, Sxx = sum m dx^2, Sxy = sum m dx dy, Syy = sum m dy^2;
@@ -401,11 +405,11 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const float dx = ea.x - (pxb + (float)((k & 1) * 8)), dy = ea.y - (pyb + (float)((k >> 1) * 8));
-                const float power = -0.5f * (eb.x * dx * dx + eb.z * dy * dy) - eb.y * dx * dy;
+                const float power = fmaf(ed.z * dy, dy, fmaf(ed.y, dy, ed.x * dx) * dx);      // log2 domain
                 const bool cand = idx0 < last[k] && power <= 0.f && power >= ea.z;
                 if (__ballot(cand) == 0ull) continue;
-                const float Graw = __builtin_amdgcn_exp2f(power * LOG2E);
-                const float araw = fminf(0.99f, eb.w * Graw);
+                const float Graw = __builtin_amdgcn_exp2f(power);
+                const float araw = fminf(0.99f, ed.w * Graw);
                 const bool ok = cand && araw >= (1.0f / 255.0f);
                 if (__ballot(ok) == 0ull) continue;
                 any = any || ok;
@@ -428,7 +432,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 Tr[k] = Tn;
                 dL_dalpha *= Tn;
                 if (has_bg) dL_dalpha -= (Tfin[k] * inv) * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);
-                const float m = eb.w * dL_dalpha * G;      // dL/dG * G
+                const float m = ed.w * dL_dalpha * G;      // dL/dG * G
                 const float mx = m * dx, my = m * dy;
                 v[0] += mx; v[1] += my;
                 v[2] += mx * dx; v[3] += mx * dy; v[4] += my * dy;
