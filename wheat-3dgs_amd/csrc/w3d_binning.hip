@@ -182,18 +182,30 @@ gather_sorted_kernel(const uint32_t *__restrict__ sorted_ids, const uint2 *__res
 
 // LAYER 0: all chunks.  LAYER 1 / 2: front / back depth layer (chunk ranges in counters[4..7], see
 // layer_split_kernel); the back layer only bins into tiles that are still open after the front layer was
-// blended (tile_open), and Gaussians none of whose tiles is open never enter the serial loop.
+// blended (tile_open).
+//
+// One wave per (chunk, band of tile rows).  The wave streams the chunk's depth-ordered records, keeps the
+// ones whose rect reaches into its band (about one in eight) in a 128-entry LDS ring, and whenever 64 are
+// queued it bins all 64 AT ONCE, one record per lane:
+//   count (MODE 0): every lane walks the set bits of ITS record's tile mask and adds 1 to the tile's packed
+//                   u16 LDS counter (ds_add_u32 — counting needs no order);
+//   fill  (MODE 1): phase A: every lane ORs its lane bit into a 64-bit LDS bitmap per tile (ds_or_b64);
+//                   phase B: it walks its tiles again, position = cursor[tile] + popcount(bitmap below my bit),
+//                            and writes the list entry — ring slots are in depth order, so the rank within the
+//                            batch IS the depth rank and the counting sort stays stable without any serial walk;
+//                   phase C: lanes <-> tiles of the band: cursor += popcount(bitmap), bitmap = 0.
+// Records with more than W3D_WALK_SMALL tiles in the band are binned by the whole wave (lanes <-> the tiles
+// of that record) in the same three phases, so one big footprint does not stall 63 lanes.
+#define W3D_WALK_SMALL 12
+#define W3D_WALK_QUEUE 128
 template <int MODE, bool CULL, int LAYER>
 __global__ void __launch_bounds__(256)
 chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_mask,
                   const uint32_t *__restrict__ counters,
                   uint32_t chunk, uint32_t C, uint32_t T, uint32_t gx, uint32_t gy, uint32_t band_rows,
                   uint16_t *__restrict__ cnt, const uint32_t *__restrict__ off, uint32_t *__restrict__ point_list,
-                  uint64_t capacity, const uint8_t *__restrict__ tile_open, const float *__restrict__ depth_cut) {
-    // blockIdx.y = band of tile rows this wave is responsible for: the LDS array only spans the band
-    // (a few KB, so 8 waves per SIMD fit), and Gaussians whose rect misses the band are compacted
-    // away BEFORE the serial loop, so the serial work per wave shrinks with the band height while
-    // the number of independent waves grows by the number of bands.
+                  uint64_t capacity, const uint8_t *__restrict__ tile_open, const float *__restrict__ depth_cut,
+                  uint32_t wave_bytes) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t c = blockIdx.x * 4 + wv;
@@ -204,43 +216,106 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
     const uint32_t Tbpad = (band_rows * gx + 63u) & ~63u;
     const uint32_t V = counters[0];
     (void)T;
-    // plain (non-volatile) LDS accesses: a wave's LDS operations complete in issue order, and the compiler
-    // keeps may-alias loads/stores in program order; `volatile` would make the backend drain vmcnt/lgkmcnt
-    // around every access and serialise the loop on the latency of the previous list store.
-    uint16_t *h16 = reinterpret_cast<uint16_t *>(smem) + (size_t)wv * Tbpad;
-    uint32_t *h32 = reinterpret_cast<uint32_t *>(smem) + (size_t)wv * Tbpad;
-    // LAYER 2: one byte per tile of the band, 1 = still open (placed behind the 4 waves' counter arrays)
-    uint8_t *open8 = smem + (size_t)4 * Tbpad * (MODE == 0 ? 2 : 4) + (size_t)wv * Tbpad;
+    // per-wave LDS: [ring 2 x 128 x 16 B][MODE 1: bitmap 8 B x Tbpad][counters / cursors][open bytes][depth cuts]
+    unsigned char *base_w = smem + (size_t)wv * wave_bytes;
+    uint4 *qa = reinterpret_cast<uint4 *>(base_w);
+    uint4 *qb = qa + W3D_WALK_QUEUE;
+    unsigned char *p = base_w + 2 * W3D_WALK_QUEUE * sizeof(uint4);
+    unsigned long long *bm = reinterpret_cast<unsigned long long *>(p);
+    if (MODE == 1) p += (size_t)Tbpad * 8;
+    uint32_t *h32 = reinterpret_cast<uint32_t *>(p);             // MODE 0: Tbpad/2 words of two u16 counters; MODE 1: cursors
+    p += (size_t)Tbpad * (MODE == 0 ? 2 : 4);
+    uint8_t *open8 = p;
+    if (LAYER == 2) p += Tbpad;
+    float *cut32 = reinterpret_cast<float *>(p);
+    const bool has_cut = depth_cut != nullptr;
     if (LAYER == 2)
         for (uint32_t t = lane; t < Tb; t += 64) open8[t] = tile_open[tb0 + t];
-    // per-tile depth cuts (speculative list truncation, see w3d_view.tile_depth_cut): an instance deeper than
-    // its tile's cut is not binned.  One private copy per wave keeps the walk free of workgroup barriers.
-    float *cut32 = reinterpret_cast<float *>(smem + (size_t)4 * Tbpad * ((MODE == 0 ? 2 : 4) + (LAYER == 2 ? 1 : 0))) + (size_t)wv * Tbpad;
-    const bool has_cut = depth_cut != nullptr;
     if (has_cut)
         for (uint32_t t = lane; t < Tb; t += 64) cut32[t] = depth_cut[tb0 + t];
     if (MODE == 0) {
-        for (uint32_t t = lane; t < Tbpad; t += 64) h16[t] = 0;
+        for (uint32_t t = lane; t < Tbpad / 2; t += 64) h32[t] = 0;
     } else {
         const uint32_t *row = off + (size_t)c * T + tb0;
         for (uint32_t t = lane; t < Tb; t += 64) h32[t] = row[t];
+        for (uint32_t t = lane; t < Tbpad; t += 64) bm[t] = 0ull;
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t s_beg = min(V, c * chunk), s_end = min(V, s_beg + chunk);
 #define RL(x, i) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (int)(i)))
-    auto touch = [&](bool hit, uint32_t t, uint32_t g) {
-        if (hit) {
-            if (MODE == 0) {
-                h16[t] = (uint16_t)(h16[t] + 1);
-            } else {
-                const uint32_t pos = h32[t];
-                h32[t] = pos + 1;
-                if (pos < capacity) point_list[pos] = g;
+    uint32_t q_head = 0, q_len = 0;                               // wave-uniform ring state
+
+    // bins the first nq (<= 64) queued records
+    auto process = [&](uint32_t nq) {
+        const uint32_t slot = (q_head + lane) & (W3D_WALK_QUEUE - 1u);
+        uint4 ea = make_uint4(0u, 0u, 1u, 0u), eb = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < nq) { ea = qa[slot]; eb = qb[slot]; }
+        const uint32_t g = ea.x, minx = ea.y & 0xFFFFu, miny = ea.y >> 16, w = ea.z & 0x7Fu, magic = ea.z >> 7;
+        const uint32_t kind = ea.w;                               // 0 = lane-parallel, 1 = whole wave (<= 64 tiles), 2 = whole wave (big rect)
+        const uint64_t rm = (uint64_t)eb.x | ((uint64_t)eb.y << 32);
+        const float depth = __uint_as_float(eb.z);
+        const uint64_t coop = __ballot(lane < nq && kind != 0u);
+        auto tile_ok = [&](uint32_t tl, float d) -> bool {
+            bool ok = true;
+            if (LAYER == 2) ok = open8[tl] != 0;
+            if (has_cut) ok = ok && d <= cut32[tl];
+            return ok;
+        };
+        // visits every (record, tile) instance of the batch: op(tile index in band, record's ring position, id)
+        auto traverse = [&](auto op) {
+            uint64_t m = (lane < nq && kind == 0u) ? rm : 0ull;
+            while (__ballot(m != 0ull)) {
+                if (m != 0ull) {
+                    const uint32_t k = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+                    m &= m - 1ull;
+                    const uint32_t ty = __umul24(k, magic) >> 16;
+                    const uint32_t tl = __umul24(miny + ty - y0, gx) + minx + (k - __umul24(ty, w));
+                    if (tile_ok(tl, depth)) op(tl, lane, g);
+                }
+            }
+            uint64_t todo = coop;
+            while (todo) {
+                const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+                todo &= todo - 1ull;
+                const uint32_t jg = RL(g, j), jw = RL(w, j), jminx = RL(minx, j), jminy = RL(miny, j);
+                const float jd = __uint_as_float(RL(eb.z, j));
+                if (RL(kind, j) == 1u) {
+                    const uint64_t jm = (uint64_t)RL(eb.x, j) | ((uint64_t)RL(eb.y, j) << 32);
+                    const uint32_t ty = __umul24(lane, RL(magic, j)) >> 16;
+                    const uint32_t tl = __umul24(jminy + ty - y0, gx) + jminx + (lane - __umul24(ty, jw));
+                    if (((jm >> lane) & 1ull) && tile_ok(tl, jd)) op(tl, j, jg);
+                } else {
+                    // rect of more than 64 tiles (never culled): rows of the band only, generic division
+                    const uint32_t hi = RL(eb.w, j), jmaxx = hi & 0xFFFFu, jmaxy = hi >> 16;
+                    const uint32_t r0 = max(jminy, y0), r1 = min(jmaxy, y1), ww = jmaxx - jminx;
+                    const uint32_t n = (r1 - r0) * ww;
+                    for (uint32_t kb = 0; kb < n; kb += 64) {
+                        const uint32_t k = kb + lane;
+                        const uint32_t ty = k / ww, tl = (r0 + ty - y0) * gx + jminx + (k - ty * ww);
+                        if (k < n && tile_ok(tl, jd)) op(tl, j, jg);
+                    }
+                }
+            }
+        };
+        if (MODE == 0) {
+            traverse([&](uint32_t tl, uint32_t, uint32_t) { atomicAdd(&h32[tl >> 1], 1u << ((tl & 1u) * 16u)); });
+        } else {
+            traverse([&](uint32_t tl, uint32_t src, uint32_t) { atomicOr(&bm[tl], 1ull << src); });
+            __builtin_amdgcn_wave_barrier();
+            traverse([&](uint32_t tl, uint32_t src, uint32_t id) {
+                const uint32_t pos = h32[tl] + (uint32_t)__popcll(bm[tl] & ((1ull << src) - 1ull));
+                if (pos < capacity) point_list[pos] = id;
+            });
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t t = lane; t < Tb; t += 64) {
+                const unsigned long long b = bm[t];
+                if (b) { h32[t] += (uint32_t)__popcll(b); bm[t] = 0ull; }
             }
         }
         __builtin_amdgcn_wave_barrier();
     };
-    // software pipeline: the records of batch b+1 are in flight while batch b is walked
+
+    // software pipeline: the records of batch b+1 are in flight while batch b is examined
     uint4 nx_rec = make_uint4(0u, 0u, 0u, 0u);
     uint2 nx_mask = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     if (s_beg + lane < s_end) { nx_rec = rec[s_beg + lane]; nx_mask = rec_mask[s_beg + lane]; }
@@ -249,81 +324,47 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         const uint4 cur_rec = nx_rec;
         const uint2 cur_mask = nx_mask;
         if (base + 64 + lane < s_end) { nx_rec = rec[base + 64 + lane]; nx_mask = rec_mask[base + 64 + lane]; }
-        uint32_t my_g = 0, my_minx = 0, my_miny = 0, my_w = 1, my_n = 0, my_magic = 0;
-        uint2 my_mask = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        float my_depth = 0.f;
         bool relevant = false;
+        uint4 ea, eb;
         if (lane < nb) {
-            my_g = cur_rec.x;
-            my_depth = __uint_as_float(cur_rec.w);
-            const uint2 rc = make_uint2(cur_rec.y, cur_rec.z);
-            const uint32_t minx = rc.x & 0xFFFFu, miny = rc.x >> 16, maxx = rc.y & 0xFFFFu, maxy = rc.y >> 16;
+            const uint32_t minx = cur_rec.y & 0xFFFFu, miny = cur_rec.y >> 16, maxx = cur_rec.z & 0xFFFFu, maxy = cur_rec.z >> 16;
             relevant = miny < y1 && maxy > y0;                   // rect reaches into this band
-            if (CULL) my_mask = cur_mask;                        // bit k: k-th tile of the rect (row-major) can be reached
-            my_minx = minx; my_miny = miny;
-            my_w = maxx - minx;
-            my_n = my_w * (maxy - miny);
-            my_magic = 65536u / max(my_w, 1u) + 1u;              // floor(k / w) == (k * magic) >> 16 for k < 64, w <= 64
-            if (LAYER == 2 && relevant && my_n <= 64u) {
-                // vectorised pre-filter: does this Gaussian reach ANY open tile of the band?
-                bool any_open = false;
-                const uint64_t m64 = (uint64_t)my_mask.x | ((uint64_t)my_mask.y << 32);
-                for (uint32_t k = 0; k < my_n && !any_open; k++) {
-                    const uint32_t ty = __umul24(k, my_magic) >> 16, row = miny + ty;
-                    if (((m64 >> k) & 1ull) && row >= y0 && row < y1)
-                        any_open = open8[__umul24(row - y0, gx) + minx + (k - __umul24(ty, my_w))] != 0;
-                }
-                relevant = any_open;
+            const uint32_t w = maxx - minx, n = w * (maxy - miny);
+            uint64_t rm = ~0ull;
+            uint32_t kind = 2u;
+            if (relevant && n <= 64u) {
+                // bit k: k-th tile of the rect (row-major) can be reached — restricted to the rows of this band
+                const uint32_t k_lo = (max(miny, y0) - miny) * w, k_hi = (min(maxy, y1) - miny) * w;
+                rm = (k_hi >= 64u ? ~0ull : ((1ull << k_hi) - 1ull)) & ~((1ull << k_lo) - 1ull);
+                if (CULL) rm &= (uint64_t)cur_mask.x | ((uint64_t)cur_mask.y << 32);
+                relevant = relevant && rm != 0ull;
+                kind = __popcll(rm) > W3D_WALK_SMALL ? 1u : 0u;
             }
-            if (has_cut && relevant && my_n <= 64u) {
-                // vectorised pre-filter: is this Gaussian in front of the cut of ANY of its tiles in the band?
-                bool any_front = false;
-                const uint64_t m64 = (uint64_t)my_mask.x | ((uint64_t)my_mask.y << 32);
-                for (uint32_t k = 0; k < my_n && !any_front; k++) {
-                    const uint32_t ty = __umul24(k, my_magic) >> 16, row = miny + ty;
-                    if (((m64 >> k) & 1ull) && row >= y0 && row < y1)
-                        any_front = my_depth <= cut32[__umul24(row - y0, gx) + minx + (k - __umul24(ty, my_w))];
-                }
-                relevant = any_front;
-            }
+            const uint32_t magic = 65536u / max(w, 1u) + 1u;     // floor(k / w) == (k * magic) >> 16 for k < 64, w <= 64
+            ea = make_uint4(cur_rec.x, cur_rec.y, (magic << 7) | min(w, 127u), kind);
+            eb = make_uint4((uint32_t)rm, (uint32_t)(rm >> 32), cur_rec.w, cur_rec.z);
         }
-        uint64_t todo = __ballot(relevant);
-        while (todo) {
-            const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
-            todo &= todo - 1;
-            const uint32_t n0 = RL(my_n, j);
-            const uint32_t g = RL(my_g, j), w = RL(my_w, j), minx = RL(my_minx, j), miny = RL(my_miny, j);
-            const float gdepth = __uint_as_float(RL(__float_as_uint(my_depth), j));
-            if (n0 <= 64u) {
-                const uint32_t mg = RL(my_magic, j);
-                const uint64_t mask = CULL ? ((uint64_t)RL(my_mask.x, j) | ((uint64_t)RL(my_mask.y, j) << 32)) : ~0ull;
-                const uint32_t ty = __umul24(lane, mg) >> 16;
-                const uint32_t tx = lane - __umul24(ty, w);
-                const uint32_t row = miny + ty;
-                bool hit = lane < n0 && ((mask >> lane) & 1ull) && row >= y0 && row < y1;
-                const uint32_t tl = __umul24(row - y0, gx) + minx + tx;
-                if (LAYER == 2 && hit) hit = open8[tl] != 0;
-                if (has_cut && hit) hit = gdepth <= cut32[tl];
-                touch(hit, tl, g);
-            } else {
-                // big footprint (> 64 tiles): never culled, generic division
-                for (uint32_t kb = 0; kb < n0; kb += 64) {
-                    const uint32_t k = kb + lane;
-                    const uint32_t ty = k / w, tx = k - ty * w;
-                    const uint32_t row = miny + ty;
-                    bool hit = k < n0 && row >= y0 && row < y1;
-                    const uint32_t tl = (row - y0) * gx + minx + tx;
-                    if (LAYER == 2 && hit) hit = open8[tl] != 0;
-                    if (has_cut && hit) hit = gdepth <= cut32[tl];
-                    touch(hit, tl, g);
-                }
+        const uint64_t bal = __ballot(relevant);
+        if (bal) {
+            if (relevant) {
+                const uint32_t slot = (q_head + q_len + (uint32_t)__popcll(bal & lanemask_lt())) & (W3D_WALK_QUEUE - 1u);
+                qa[slot] = ea; qb[slot] = eb;
+            }
+            q_len += (uint32_t)__popcll(bal);
+            __builtin_amdgcn_wave_barrier();
+            if (q_len >= 64u) {
+                process(64u);
+                q_head = (q_head + 64u) & (W3D_WALK_QUEUE - 1u);
+                q_len -= 64u;
             }
         }
     }
+    if (q_len) process(q_len);
 #undef RL
     if (MODE == 0) {
         __builtin_amdgcn_wave_barrier();
         uint16_t *row = cnt + (size_t)c * T + tb0;
+        const uint16_t *h16 = reinterpret_cast<const uint16_t *>(h32);
         for (uint32_t t = lane; t < Tb; t += 64) row[t] = h16[t];
     }
 }
@@ -427,10 +468,11 @@ __global__ void copy_ranges_kernel(const uint32_t *__restrict__ tile_start, uint
 // serial work per wave and its LDS footprint (4 waves x Tband x 4 B per workgroup); every band adds a
 // redundant pass over the chunk's 20-B Gaussian records.  Keep the LDS of a workgroup <= 16 KB.
 struct W3DBands { uint32_t rows, count, tbpad; };
-W3DBands w3d_pick_bands(const W3DLayout &L) {
+W3DBands w3d_pick_bands(const W3DLayout &L, int mode) {
     W3DBands b;
-    uint32_t band_tiles = 1024u;                     // ~1024 tiles per band
-    if (const char *e = getenv("W3D_TUNE_BAND_TILES")) band_tiles = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : band_tiles;
+    uint32_t band_tiles = mode == 0 ? 1024u : 512u;  // tiles per band (the fill pass holds 12 B of LDS per tile, the count pass 2 B)
+    if (const char *e = getenv(mode == 0 ? "W3D_TUNE_BAND_TILES" : "W3D_TUNE_BAND_TILES_FILL"))
+        band_tiles = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : band_tiles;
     uint32_t rows = band_tiles / (uint32_t)L.gx;
     if (rows < 1) rows = 1;
     if (rows > (uint32_t)L.gy) rows = (uint32_t)L.gy;
@@ -485,11 +527,12 @@ int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, ch
 template <int MODE, int LAYER>
 static void launch_walk(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
                         uint64_t capacity, hipStream_t stream) {
-    const W3DBands bands = w3d_pick_bands(L);
+    const W3DBands bands = w3d_pick_bands(L, MODE);
     const dim3 grid((L.C + 3) / 4, bands.count);
     const float *cut = (LAYER == 0) ? v.tile_depth_cut : nullptr;      // depth cuts only in the single-pass mode
-    const size_t lds = (size_t)bands.tbpad * (MODE == 0 ? 2 : 4) * 4 + (LAYER == 2 ? (size_t)bands.tbpad * 4 : 0) +
-                       (cut ? (size_t)bands.tbpad * 4 * 4 : 0);
+    const uint32_t wave_bytes = 2u * W3D_WALK_QUEUE * 16u + bands.tbpad * (MODE == 0 ? 2u : 12u) +
+                                (LAYER == 2 ? bands.tbpad : 0u) + (cut ? bands.tbpad * 4u : 0u);
+    const size_t lds = (size_t)wave_bytes * 4;
     const uint4 *rec = reinterpret_cast<const uint4 *>(scratch + L.s_rec);
     const uint2 *rmask = reinterpret_cast<const uint2 *>(scratch + L.s_rec_mask);
     const uint32_t *counters = reinterpret_cast<const uint32_t *>(state + L.o_counters);
@@ -498,10 +541,10 @@ static void launch_walk(const W3DLayout &L, const w3d_view &v, char *state, char
     const uint8_t *open = reinterpret_cast<const uint8_t *>(state + L.o_tile_open);
     if (v.tile_cull)
         hipLaunchKernelGGL((chunk_walk_kernel<MODE, true, LAYER>), grid, dim3(256), lds, stream, rec, rmask, counters, L.chunk, L.C,
-                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, open, cut);
+                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, open, cut, wave_bytes);
     else
         hipLaunchKernelGGL((chunk_walk_kernel<MODE, false, LAYER>), grid, dim3(256), lds, stream, rec, rmask, counters, L.chunk, L.C,
-                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, open, cut);
+                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, open, cut, wave_bytes);
 }
 
 // per-chunk per-tile counts of one layer (0 = all chunks, 1 = front, 2 = back/open tiles) and the list offsets
