@@ -196,7 +196,9 @@ gather_sorted_kernel(const uint32_t *__restrict__ sorted_ids, const uint2 *__res
 //                   phase C: lanes <-> tiles of the band: cursor += popcount(bitmap), bitmap = 0.
 // Records with more than W3D_WALK_SMALL tiles in the band are binned by the whole wave (lanes <-> the tiles
 // of that record) in the same three phases, so one big footprint does not stall 63 lanes.
-#define W3D_WALK_SMALL 12
+#ifndef W3D_WALK_SMALL
+#define W3D_WALK_SMALL 16
+#endif
 #define W3D_WALK_QUEUE 128
 template <int MODE, bool CULL, int LAYER>
 __global__ void __launch_bounds__(256)
@@ -208,10 +210,13 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                   uint32_t wave_bytes) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t c = blockIdx.x * 4 + wv;
-    if (c >= C) return;
+    // the 4 waves of a workgroup walk the SAME chunk for 4 neighbouring bands: they stream the same records at
+    // about the same time, so three of the four reads hit the CU's vector L1
+    const uint32_t c = blockIdx.x;
+    const uint32_t band = blockIdx.y * 4 + wv;
+    if (c >= C || band * band_rows >= gy) return;
     if (LAYER != 0 && (c < counters[2 + 2 * LAYER] || c >= counters[3 + 2 * LAYER])) return;
-    const uint32_t y0 = blockIdx.y * band_rows, y1 = min(gy, y0 + band_rows);
+    const uint32_t y0 = band * band_rows, y1 = min(gy, y0 + band_rows);
     const uint32_t tb0 = y0 * gx, Tb = (y1 - y0) * gx;           // first tile / tile count of the band
     const uint32_t Tbpad = (band_rows * gx + 63u) & ~63u;
     const uint32_t V = counters[0];
@@ -233,15 +238,34 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         for (uint32_t t = lane; t < Tb; t += 64) open8[t] = tile_open[tb0 + t];
     if (has_cut)
         for (uint32_t t = lane; t < Tb; t += 64) cut32[t] = depth_cut[tb0 + t];
+    const uint32_t s_beg = min(V, c * chunk), s_end = min(V, s_beg + chunk);
+    // the first records are requested before the LDS set-up below, which hides their latency; NB 64-record
+    // batches are kept in flight (rotating registers, so the loop body — and process() — exists once)
+    constexpr int NB = 4;
+    uint4 nx_rec[NB];
+    uint2 nx_mask[NB];
+    auto fetch_one = [&](uint32_t from, uint4 &r, uint2 &mk) {
+        const uint32_t s = from + lane;
+        r = make_uint4(0u, 0u, 0u, 0u);
+        mk = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (s < s_end) { r = rec[s]; if (CULL) mk = rec_mask[s]; }
+    };
+#pragma unroll
+    for (int i = 0; i < NB; i++) fetch_one(s_beg + (uint32_t)i * 64u, nx_rec[i], nx_mask[i]);
     if (MODE == 0) {
         for (uint32_t t = lane; t < Tbpad / 2; t += 64) h32[t] = 0;
     } else {
         const uint32_t *row = off + (size_t)c * T + tb0;
-        for (uint32_t t = lane; t < Tb; t += 64) h32[t] = row[t];
+        for (uint32_t t0 = 0; t0 < Tb; t0 += 512) {              // 8 independent loads in flight per lane
+            uint32_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const uint32_t t = t0 + (uint32_t)i * 64u + lane; v[i] = t < Tb ? row[t] : 0u; }
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const uint32_t t = t0 + (uint32_t)i * 64u + lane; if (t < Tb) h32[t] = v[i]; }
+        }
         for (uint32_t t = lane; t < Tbpad; t += 64) bm[t] = 0ull;
     }
     __builtin_amdgcn_wave_barrier();
-    const uint32_t s_beg = min(V, c * chunk), s_end = min(V, s_beg + chunk);
 #define RL(x, i) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (int)(i)))
     uint32_t q_head = 0, q_len = 0;                               // wave-uniform ring state
 
@@ -261,18 +285,25 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
             if (has_cut) ok = ok && d <= cut32[tl];
             return ok;
         };
-        // visits every (record, tile) instance of the batch: op(tile index in band, record's ring position, id)
-        auto traverse = [&](auto op) {
+        // lane-parallel part: the (at most W3D_WALK_SMALL) tiles of this lane's record, derived once and kept in registers
+        constexpr uint32_t NONE = 0xFFFFFFFFu;
+        uint32_t tls[W3D_WALK_SMALL];
+        uint32_t kmax = 0;                                         // wave-uniform: slots [0, kmax) hold a tile for some lane
+        {
             uint64_t m = (lane < nq && kind == 0u) ? rm : 0ull;
-            while (__ballot(m != 0ull)) {
-                if (m != 0ull) {
-                    const uint32_t k = (uint32_t)__ffsll((unsigned long long)m) - 1u;
-                    m &= m - 1ull;
-                    const uint32_t ty = __umul24(k, magic) >> 16;
-                    const uint32_t tl = __umul24(miny + ty - y0, gx) + minx + (k - __umul24(ty, w));
-                    if (tile_ok(tl, depth)) op(tl, lane, g);
-                }
+#pragma unroll
+            for (int i = 0; i < W3D_WALK_SMALL; i++) {
+                const bool v = m != 0ull;
+                if (__ballot(v) != 0ull) kmax = (uint32_t)i + 1u;
+                const uint32_t k = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+                m &= m - 1ull;
+                const uint32_t ty = __umul24(k, magic) >> 16;
+                const uint32_t tl = __umul24(miny + ty - y0, gx) + minx + (k - __umul24(ty, w));
+                tls[i] = (v && tile_ok(v ? tl : 0u, depth)) ? tl : NONE;
             }
+        }
+        // whole-wave part: records with many tiles, one at a time, lanes <-> tiles.  op(tile index in band, ring position, id)
+        auto traverse_coop = [&](auto op) {
             uint64_t todo = coop;
             while (todo) {
                 const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
@@ -298,32 +329,64 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
             }
         };
         if (MODE == 0) {
-            traverse([&](uint32_t tl, uint32_t, uint32_t) { atomicAdd(&h32[tl >> 1], 1u << ((tl & 1u) * 16u)); });
+#pragma unroll
+            for (int i = 0; i < W3D_WALK_SMALL; i++) {
+                if ((uint32_t)i >= kmax) break;
+                if (tls[i] != NONE) atomicAdd(&h32[tls[i] >> 1], 1u << ((tls[i] & 1u) * 16u));
+            }
+            traverse_coop([&](uint32_t tl, uint32_t, uint32_t) { atomicAdd(&h32[tl >> 1], 1u << ((tl & 1u) * 16u)); });
         } else {
-            traverse([&](uint32_t tl, uint32_t src, uint32_t) { atomicOr(&bm[tl], 1ull << src); });
+            const unsigned long long mybit = 1ull << lane;
+#pragma unroll
+            for (int i = 0; i < W3D_WALK_SMALL; i++) {
+                if ((uint32_t)i >= kmax) break;
+                if (tls[i] != NONE) atomicOr(&bm[tls[i]], mybit);
+            }
+            traverse_coop([&](uint32_t tl, uint32_t src, uint32_t) { atomicOr(&bm[tl], 1ull << src); });
             __builtin_amdgcn_wave_barrier();
-            traverse([&](uint32_t tl, uint32_t src, uint32_t id) {
+            // all cursor / bitmap reads of the batch are issued back to back, then the list entries are written
+#pragma unroll
+            for (int i0 = 0; i0 < W3D_WALK_SMALL; i0 += 8) {
+                if ((uint32_t)i0 >= kmax) break;
+                uint32_t hh[8];
+                unsigned long long bb[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    hh[i] = 0u; bb[i] = 0ull;
+                    if (tls[i0 + i] != NONE) { hh[i] = h32[tls[i0 + i]]; bb[i] = bm[tls[i0 + i]]; }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t pos = hh[i] + (uint32_t)__popcll(bb[i] & (mybit - 1ull));
+                    if (tls[i0 + i] != NONE && pos < capacity) point_list[pos] = g;
+                }
+            }
+            traverse_coop([&](uint32_t tl, uint32_t src, uint32_t id) {
                 const uint32_t pos = h32[tl] + (uint32_t)__popcll(bm[tl] & ((1ull << src) - 1ull));
                 if (pos < capacity) point_list[pos] = id;
             });
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t t = lane; t < Tb; t += 64) {
-                const unsigned long long b = bm[t];
-                if (b) { h32[t] += (uint32_t)__popcll(b); bm[t] = 0ull; }
+            for (uint32_t t0 = 0; t0 < Tb; t0 += 512) {          // cursors advance by the batch's hits; 8 reads in flight
+                unsigned long long b8[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const uint32_t t = t0 + (uint32_t)i * 64u + lane; b8[i] = t < Tb ? bm[t] : 0ull; }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t t = t0 + (uint32_t)i * 64u + lane;
+                    if (b8[i]) { h32[t] += (uint32_t)__popcll(b8[i]); bm[t] = 0ull; }
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
     };
 
-    // software pipeline: the records of batch b+1 are in flight while batch b is examined
-    uint4 nx_rec = make_uint4(0u, 0u, 0u, 0u);
-    uint2 nx_mask = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (s_beg + lane < s_end) { nx_rec = rec[s_beg + lane]; nx_mask = rec_mask[s_beg + lane]; }
-    for (uint32_t base = s_beg; base < s_end; base += 64) {
+    for (uint32_t base = s_beg; base < s_end; base += 64u) {
         const uint32_t nb = min(64u, s_end - base);
-        const uint4 cur_rec = nx_rec;
-        const uint2 cur_mask = nx_mask;
-        if (base + 64 + lane < s_end) { nx_rec = rec[base + 64 + lane]; nx_mask = rec_mask[base + 64 + lane]; }
+        const uint4 cur_rec = nx_rec[0];
+        const uint2 cur_mask = nx_mask[0];
+#pragma unroll
+        for (int i = 0; i + 1 < NB; i++) { nx_rec[i] = nx_rec[i + 1]; nx_mask[i] = nx_mask[i + 1]; }
+        fetch_one(base + 64u * NB, nx_rec[NB - 1], nx_mask[NB - 1]);
         bool relevant = false;
         uint4 ea, eb;
         if (lane < nb) {
@@ -337,10 +400,12 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                 const uint32_t k_lo = (max(miny, y0) - miny) * w, k_hi = (min(maxy, y1) - miny) * w;
                 rm = (k_hi >= 64u ? ~0ull : ((1ull << k_hi) - 1ull)) & ~((1ull << k_lo) - 1ull);
                 if (CULL) rm &= (uint64_t)cur_mask.x | ((uint64_t)cur_mask.y << 32);
-                relevant = relevant && rm != 0ull;
+                relevant = rm != 0ull;
                 kind = __popcll(rm) > W3D_WALK_SMALL ? 1u : 0u;
             }
-            const uint32_t magic = 65536u / max(w, 1u) + 1u;     // floor(k / w) == (k * magic) >> 16 for k < 64, w <= 64
+            // floor(k / w) == (k * magic) >> 16 for k < 64, w <= 64 with magic = floor(65536 / w) + 1; through the float
+            // reciprocal (65536 / w is either an integer, where rcp is exact enough, or >= 1/64 away from one)
+            const uint32_t magic = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)max(w, 1u)) + 0.004f) + 1u;
             ea = make_uint4(cur_rec.x, cur_rec.y, (magic << 7) | min(w, 127u), kind);
             eb = make_uint4((uint32_t)rm, (uint32_t)(rm >> 32), cur_rec.w, cur_rec.z);
         }
@@ -352,14 +417,16 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
             }
             q_len += (uint32_t)__popcll(bal);
             __builtin_amdgcn_wave_barrier();
-            if (q_len >= 64u) {
-                process(64u);
-                q_head = (q_head + 64u) & (W3D_WALK_QUEUE - 1u);
-                q_len -= 64u;
-            }
+        }
+        // bin 64 queued records — or, after the last batch, whatever is left (the same code, so process() is instantiated once)
+        const bool last = base + 64u >= s_end;
+        while (q_len >= 64u || (last && q_len)) {
+            const uint32_t nq = min(q_len, 64u);
+            process(nq);
+            q_head = (q_head + nq) & (W3D_WALK_QUEUE - 1u);
+            q_len -= nq;
         }
     }
-    if (q_len) process(q_len);
 #undef RL
     if (MODE == 0) {
         __builtin_amdgcn_wave_barrier();
@@ -528,7 +595,7 @@ template <int MODE, int LAYER>
 static void launch_walk(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
                         uint64_t capacity, hipStream_t stream) {
     const W3DBands bands = w3d_pick_bands(L, MODE);
-    const dim3 grid((L.C + 3) / 4, bands.count);
+    const dim3 grid(L.C, (bands.count + 3) / 4);
     const float *cut = (LAYER == 0) ? v.tile_depth_cut : nullptr;      // depth cuts only in the single-pass mode
     const uint32_t wave_bytes = 2u * W3D_WALK_QUEUE * 16u + bands.tbpad * (MODE == 0 ? 2u : 12u) +
                                 (LAYER == 2 ? bands.tbpad : 0u) + (cut ? bands.tbpad * 4u : 0u);
