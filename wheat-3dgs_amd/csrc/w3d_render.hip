@@ -63,11 +63,42 @@ struct StagedLDS {
     float4 c[64];  // r, g, b, depth
     float4 d[64];  // -0.5*log2e*conic.x, -log2e*conic.y, -0.5*log2e*conic.z, opacity: the exponent in the
                    // log2 domain is dx*(d.x*dx + d.y*dy) + d.z*dy*dy — 5 VALU instead of 7 + 1 for the exp2 scale
+    uint32_t q[64]; // bit k: the Gaussian can reach alpha >= 1/255 somewhere in the 8x8 pixel quadrant k of the tile
 };
+
+// Which of the tile's four 8x8 quadrants can this Gaussian touch?  The minimum of q(d) = 0.5 d^T Conic d over
+// the quadrant's pixel rectangle is compared with tau = log(255 o) + ~1e-3 (exactly the per-tile test of the
+// binning stage, w3d_preprocess.hip footprint_hits_tile, on a quarter tile): the minimum sits at the centre if
+// that is inside, otherwise on one of the four edges, where it is a clamped 1-D parabola minimum.  Evaluated
+// once per list entry by the staging lane; the blend loops then skip a quadrant on a scalar bit test instead
+// of evaluating the exponent for 64 pixels.  Conservative by the 1e-3 margin, so no result changes.
+__device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, float B, float C, float pmin,
+                                                  float tx0, float ty0) {
+    if (!(A > 0.f && C > 0.f)) return pmin <= 0.f ? 0xFu : 0u;
+    const float tau = -pmin + 9e-4f;                 // pmin = -log(255 o) - 1e-4
+    const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float x0 = tx0 + (float)((k & 1) * 8), y0 = ty0 + (float)((k >> 1) * 8);
+        const float dxl = mx - (x0 + 7.f), dxh = mx - x0, dyl = my - (y0 + 7.f), dyh = my - y0;
+        const bool inside = dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f;
+        float dy = fminf(fmaxf(-B * dxl * iC, dyl), dyh);
+        float best = 0.5f * (A * dxl * dxl + C * dy * dy) + B * dxl * dy;
+        dy = fminf(fmaxf(-B * dxh * iC, dyl), dyh);
+        best = fminf(best, 0.5f * (A * dxh * dxh + C * dy * dy) + B * dxh * dy);
+        float dx = fminf(fmaxf(-B * dyl * iA, dxl), dxh);
+        best = fminf(best, 0.5f * (A * dx * dx + C * dyl * dyl) + B * dx * dyl);
+        dx = fminf(fmaxf(-B * dyh * iA, dxl), dxh);
+        best = fminf(best, 0.5f * (A * dx * dx + C * dyh * dyh) + B * dx * dyh);
+        if (inside || !(best > tau)) m |= 1u << k;
+    }
+    return m;
+}
 
 __device__ __forceinline__ void stage_entries(StagedLDS &s, uint32_t lane, uint32_t n, const uint32_t *__restrict__ list,
                                               const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
-                                              const float4 *__restrict__ rgbd) {
+                                              const float4 *__restrict__ rgbd, float tx0, float ty0) {
     if (lane < n) {
         const uint32_t g = list[lane];
         const float2 p = xy[g];
@@ -80,6 +111,7 @@ __device__ __forceinline__ void stage_entries(StagedLDS &s, uint32_t lane, uint3
         s.b[lane] = co;
         s.c[lane] = cd;
         s.d[lane] = make_float4(-0.5f * LOG2E * co.x, -LOG2E * co.y, -0.5f * LOG2E * co.z, co.w);
+        s.q[lane] = quadrant_mask(p.x, p.y, co.x, co.y, co.z, pmin, tx0, ty0);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -167,14 +199,17 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     for (uint32_t base = start; base < end; base += 64) {
         if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
         const uint32_t n = min(64u, end - base);
-        stage_entries(s, lane, n, point_list + base, xy, conic_op, rgbd);
+        stage_entries(s, lane, n, point_list + base, xy, conic_op, rgbd, (float)tx0, (float)ty0);
         for (uint32_t j = 0; j < n; j++) {
+            const uint32_t qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.q[j]);
+            if (qm == 0u) continue;
             const float4 ea = s.a[j], ed = s.d[j], ec = s.c[j];
             const uint32_t contributor = first + base - start + j + 1;
             float wk[4] = {0.f, 0.f, 0.f, 0.f};
             bool any_applied = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
+                if (!(qm & (1u << k))) continue;
                 const float dx = ea.x - pxf[k], dy = ea.y - pyf[k];
                 const float power = fmaf(ed.z * dy, dy, fmaf(ed.y, dy, ed.x * dx) * dx);      // log2 domain
                 const bool cand = !done[k] && power <= 0.f && power >= ea.z;
@@ -381,6 +416,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         const uint32_t n = min(64u, maxc - (uint32_t)b * 64u);
         s.a[lane] = nxt.a; s.b[lane] = nxt.b; s.c[lane] = nxt.c;
         s.d[lane] = make_float4(-0.5f * LOG2E * nxt.b.x, -LOG2E * nxt.b.y, -0.5f * LOG2E * nxt.b.z, nxt.b.w);
+        s.q[lane] = quadrant_mask(nxt.a.x, nxt.a.y, nxt.b.x, nxt.b.y, nxt.b.z, nxt.a.z * (1.0f / LOG2E), (float)tx0, (float)ty0);
         {
             float4 *z = reinterpret_cast<float4 *>(&acc[lane * W3D_ACC_STRIDE]);
             z[0] = make_float4(0.f, 0.f, 0.f, 0.f); z[1] = z[0]; z[2] = z[0];
@@ -392,6 +428,8 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             ids = batch_id(b - 2);
         }
         for (int j = (int)n - 1; j >= 0; j--) {
+            const uint32_t qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.q[j]);
+            if (qm == 0u) continue;
             const float4 ea = s.a[j], ed = s.d[j], ec = s.c[j];
             const uint32_t idx0 = (uint32_t)b * 64u + (uint32_t)j;   // 0-based position in the tile list
             // per-lane partial sums of this tile instance.  Geometry enters through the five moments of
@@ -404,6 +442,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
+                if (!(qm & (1u << k))) continue;
                 const float dx = ea.x - (pxb + (float)((k & 1) * 8)), dy = ea.y - (pyb + (float)((k >> 1) * 8));
                 const float power = fmaf(ed.z * dy, dy, fmaf(ed.y, dy, ed.x * dx) * dx);      // log2 domain
                 const bool cand = idx0 < last[k] && power <= 0.f && power >= ea.z;
