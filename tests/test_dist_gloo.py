@@ -55,11 +55,13 @@ def _worker(rank, world, port, out):
     g = torch.Generator().manual_seed(500 + rank)
     for step in range(3):
         # per-view quantities a rank would have after its own render + backward
-        m.flat_grad.copy_(_view_grad(rank + 10 * step, m.flat.numel()))
+        # (exchange()'s contract: the bucket holds the view's gradient already scaled by 1/world)
+        m.flat_grad.copy_(_view_grad(rank + 10 * step, m.flat.numel()) / world)
         gnorm = torch.rand(P, generator=g) * 1e-3
         vis = torch.rand(P, generator=g) > 0.4
         radii = (torch.rand(P, generator=g) * 30).to(torch.int32) * vis
         nsum, vcount, rmax = tr.exchange(gnorm, vis, radii)
+        tr.wait_stats()
 
         def gather(t):
             lst = [torch.zeros_like(t) for _ in range(world)]

@@ -78,26 +78,47 @@ class Trainer:
         n = self.model.flat_store.numel() // self.world
         return self.rank * n, (self.rank + 1) * n
 
-    def exchange(self, grad2d_norm, visible, radii):
+    def exchange(self, grad2d_norm, visible, radii, tracking=True):
         """The one exchange step of the view-parallel loop.  Returns the reduced
-        (sum of per-view norms, visibility count, max radii).
+        (sum of per-view norms, visibility count, max radii) — None each once densification is over.
 
-        Gradients: reduce-scatter of the flat 59*P bucket — every rank receives the averaged gradient of
+        Contract: the flat gradient bucket holds THIS view's gradient already scaled by 1/world (the step
+        scales dL/dimage, a 3xHxW pass, instead of dividing the 59*P bucket afterwards; exact for power-of-two
+        worlds), and `grad2d_norm` is the norm of the unscaled 2-D gradient.
+
+        Gradients: reduce-scatter (SUM) of the flat 59*P bucket — every rank receives the averaged gradient of
         ITS 1/N slice only, steps Adam on that slice, and the updated parameters are all-gathered
         (optimizer_step_and_gather).  Same bytes on the wire as an all-reduce, but the optimizer sweep
-        (the largest HBM stream of the step) shrinks N-fold per GPU."""
+        (the largest HBM stream of the step) shrinks N-fold per GPU.  On RCCL both collectives run in place
+        (recv = send + rank*count), so no staging copy of the 472 MB bucket exists; the reduce-scatter is
+        issued first and asynchronously, the small statistics all-reduces queue behind it and overlap Adam."""
         m = self.model
         if self.world > 1 or self.force_exchange:
-            stats = torch.stack([grad2d_norm * visible, visible.to(grad2d_norm.dtype)])
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-            r = radii.clone()
-            dist.all_reduce(r, op=dist.ReduceOp.MAX)
             lo, hi = self.shard_range()
-            shard = torch.empty(hi - lo, dtype=m.flat_grad_store.dtype, device=m.flat_grad_store.device)
-            dist.reduce_scatter_tensor(shard, m.flat_grad_store, op=dist.ReduceOp.SUM)
-            m.flat_grad_store[lo:hi].copy_(shard.div_(self.world))
+            inplace = dist.get_backend() == "nccl"
+            if inplace:
+                self._rs_work = dist.reduce_scatter_tensor(m.flat_grad_store[lo:hi], m.flat_grad_store,
+                                                           op=dist.ReduceOp.SUM, async_op=True)
+            else:
+                shard = torch.empty(hi - lo, dtype=m.flat_grad_store.dtype, device=m.flat_grad_store.device)
+                dist.reduce_scatter_tensor(shard, m.flat_grad_store, op=dist.ReduceOp.SUM)
+                m.flat_grad_store[lo:hi].copy_(shard)
+                self._rs_work = None
+            if not tracking:
+                return None, None, None
+            stats = torch.stack([grad2d_norm * visible, visible.to(grad2d_norm.dtype)])
+            w1 = dist.all_reduce(stats, op=dist.ReduceOp.SUM, async_op=True)
+            r = radii.clone()
+            w2 = dist.all_reduce(r, op=dist.ReduceOp.MAX, async_op=True)
+            self._stat_work = (w1, w2)
             return stats[0], stats[1], r
         return grad2d_norm * visible, visible.to(grad2d_norm.dtype), radii
+
+    def wait_stats(self):
+        """Make the current stream wait for the statistics all-reduces of exchange()."""
+        for w in getattr(self, "_stat_work", None) or ():
+            w.wait()
+        self._stat_work = None
 
     def optimizer_step_and_gather(self, zero_grad, skip):
         """Adam on this rank's shard, then all-gather of the updated parameters (single GPU: plain step)."""
@@ -106,8 +127,14 @@ class Trainer:
             m.optimizer.step(zero_grad=zero_grad, skip=skip)
             return
         lo, hi = self.shard_range()
+        if getattr(self, "_rs_work", None) is not None:
+            self._rs_work.wait()
+            self._rs_work = None
         m.optimizer.step(zero_grad=zero_grad, skip=skip, elem_range=(lo, hi))
-        dist.all_gather_into_tensor(m.flat_store, m.flat_store[lo:hi].clone())
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(m.flat_store, m.flat_store[lo:hi])
+        else:
+            dist.all_gather_into_tensor(m.flat_store, m.flat_store[lo:hi].clone())
         self._moments_sharded = True
 
     def gather_moments(self):
@@ -173,6 +200,8 @@ class Trainer:
             while True:
                 pkg = render_raw(cam, m, self.bg, sync=False, depth_cut=cut, want_cut=self.use_depth_cuts)
                 loss, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
+                if not single and self.world > 1:
+                    dimg.mul_(1.0 / self.world)      # the bucket then holds grad/world: reduce-scatter(SUM) = mean
                 gnorm, _ = backward_raw(m, pkg["handle"], dimg, update_stats=fused_stats, want_norm=True)
                 if finish(pkg["handle"]):        # the only host wait of the step, with the backward already queued
                     break
@@ -188,7 +217,10 @@ class Trainer:
                 m.max_radii2D = torch.max(m.max_radii2D, pkg["radii"].to(m.max_radii2D.dtype))
             if not single:
                 vis = pkg["radii"] > 0
-                nsum, vcount, rmax = self.exchange(gnorm, vis, pkg["radii"])
+                if self.world > 1:
+                    gnorm = gnorm * float(self.world)           # statistics use the unscaled per-view norm
+                nsum, vcount, rmax = self.exchange(gnorm, vis, pkg["radii"], tracking=tracking)
+                self.wait_stats()
             else:
                 nsum = vcount = rmax = None
             skip = self._post_backward(iteration, nsum, vcount, rmax, stats_done=single)
@@ -209,11 +241,13 @@ class Trainer:
         pkg = render(cam, m, self.pipe, self.bg)
         image = pkg["render"]
         loss = self.loss_fn(image, cam.original_image, opt.lambda_dssim)
-        loss.backward()
+        (loss / self.world if self.world > 1 else loss).backward()
         with torch.no_grad():
             vis, radii = pkg["visibility_filter"], pkg["radii"]
-            gnorm = pkg["viewspace_points"].grad[:, :2].norm(dim=-1)
-            nsum, vcount, rmax = self.exchange(gnorm, vis, radii)
+            gnorm = pkg["viewspace_points"].grad[:, :2].norm(dim=-1) * float(self.world)
+            tracking = iteration < opt.densify_until_iter
+            nsum, vcount, rmax = self.exchange(gnorm, vis, radii, tracking=tracking)
+            self.wait_stats()
             skip = self._post_backward(iteration, nsum, vcount, rmax, stats_done=False)
             if iteration < opt.iterations:
                 self.optimizer_step_and_gather(zero_grad=True, skip=skip)
