@@ -17,6 +17,8 @@
  *        <- simple_knn._C.distCUDA2            reference scene/gaussian_model.py:20,148
  *   w3d_l1_ssim_fwd_bwd (next-row N1)
  *        <- utils/loss_utils.py:17-63 (l1_loss, ssim) as used at train_vanilla_3dgs.py:77-80
+ *   w3d_densify_compact (next-row N3)
+ *        <- scene/gaussian_model.py:332-397,441-455 (optimizer-state surgery of densify / prune)
  *   w3d_adam_step (next-row N2)
  *        <- torch.optim.Adam over the 6 parameter groups, scene/gaussian_model.py:172-182,
  *           stepped at train_vanilla_3dgs.py:113-115
@@ -184,6 +186,20 @@ int w3d_l1_ssim_fwd_bwd(int32_t C, int32_t H, int32_t W, const float *image, con
 int w3d_adam_step(uint64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, float lr,
                   float beta1, float beta2, float eps, float bias_correction1, float bias_correction2,
                   int32_t zero_grad, w3d_stream_t stream);
+
+/* Next-row N3: one-pass row compaction of the flat parameter buffer and both Adam moments for densify / prune
+ * <- scene/gaussian_model.py:332-397 (_prune_optimizer, cat_tensors_to_optimizer, densification_postfix,
+ *    prune_points), called three to four times per densify_and_prune :441-455.
+ * The flat buffers are block-wise: block b holds P rows of block_dims_host[b] floats, blocks back to back.
+ * Output row r takes source row src_rows[r] (< P_old).  Rows [0, n_keep) keep their Adam moments; rows
+ * [n_keep, P_new) are new (clones, then split children from n_child0 on) and get zero moments; split children
+ * take their xyz_block / scaling_block rows from child_xyz / child_scaling ((P_new - n_child0, 3) each).
+ * exp_avg_* may all be NULL (no optimizer state).  block_dims_host is a HOST array. */
+int w3d_densify_compact(int32_t n_blocks, const int32_t *block_dims_host, int32_t xyz_block, int32_t scaling_block,
+                        uint64_t P_old, uint64_t P_new, uint64_t n_keep, uint64_t n_child0, const int32_t *src_rows,
+                        const float *param_old, const float *exp_avg_old, const float *exp_avg_sq_old,
+                        float *param_new, float *exp_avg_new, float *exp_avg_sq_new, const float *child_xyz,
+                        const float *child_scaling, w3d_stream_t stream);
 
 /* Diagnostics for bench.py's roofline leg: time the launches whose stage name contains
  * `kernel_substr` ("*" = all, NULL/"" = off) with HIP events on their launch stream;

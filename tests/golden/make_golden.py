@@ -213,3 +213,58 @@ gaussian_renderer.flashsplat_render(cam, gm, Pipe(), bg, used_mask=used)
 json.dump({"captured": captured, "render_keys": keys_render, "flashsplat_keys": sorted(out2.keys())},
           open(os.path.join(OUT, "render_marshalling.json"), "w"), indent=1, default=str)
 print("golden fixtures written to", OUT)
+
+# (8) densify_and_prune on the reference's own GaussianModel (scene/gaussian_model.py:399-455) with its torch.optim.Adam
+#     state surgery (:318-374): pre-state -> post-state, CPU random stream (torch.manual_seed) for the split samples.
+from types import SimpleNamespace  # noqa: E402
+torch.cuda.empty_cache = lambda: None
+
+
+def _densify_case(seed, P, max_screen_size, tag, out):
+    gg = torch.Generator().manual_seed(seed)
+    gm = GaussianModel(3)
+    gm.spatial_lr_scale = 1.0
+    gm._xyz = torch.nn.Parameter(torch.randn(P, 3, generator=gg))
+    gm._features_dc = torch.nn.Parameter(torch.randn(P, 1, 3, generator=gg))
+    gm._features_rest = torch.nn.Parameter(torch.randn(P, 15, 3, generator=gg) * 0.1)
+    gm._scaling = torch.nn.Parameter(torch.log(torch.rand(P, 3, generator=gg) * 0.06 + 1e-3))   # around percent_dense * extent = 0.02
+    gm._scaling.data[::17] = torch.log(torch.tensor(0.5))                                       # some beyond 0.1 * extent
+    gm._rotation = torch.nn.Parameter(torch.randn(P, 4, generator=gg))
+    gm._opacity = torch.nn.Parameter(torch.randn(P, 1, generator=gg) * 3.0 - 2.0)               # some below min_opacity
+    gm._which_object = torch.arange(P, dtype=torch.int32).reshape(P, 1)
+    gm.max_radii2D = torch.rand(P, generator=gg) * 40
+    args = SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016,
+                           position_lr_delay_mult=0.01, position_lr_max_steps=30000, feature_lr=0.0025, opacity_lr=0.05,
+                           scaling_lr=0.005, rotation_lr=0.001)
+    gm.training_setup(args)
+    for _ in range(2):
+        for grp in gm.optimizer.param_groups:
+            p = grp["params"][0]
+            p.grad = torch.randn(p.shape, generator=gg) * 1e-2
+        gm.optimizer.step()
+    gm.xyz_gradient_accum = torch.rand(P, 1, generator=gg) * 6e-4
+    gm.denom = (torch.rand(P, 1, generator=gg) > 0.1).float()          # zeros give 0/0 -> NaN -> 0 (:443)
+
+    def snap(prefix):
+        for grp in gm.optimizer.param_groups:
+            p = grp["params"][0]
+            st = gm.optimizer.state[p]
+            out[f"{tag}_{prefix}_{grp['name']}"] = p.detach().numpy().copy()
+            out[f"{tag}_{prefix}_m_{grp['name']}"] = st["exp_avg"].numpy().copy()
+            out[f"{tag}_{prefix}_v_{grp['name']}"] = st["exp_avg_sq"].numpy().copy()
+        out[f"{tag}_{prefix}_accum"] = gm.xyz_gradient_accum.numpy().copy()
+        out[f"{tag}_{prefix}_denom"] = gm.denom.numpy().copy()
+        out[f"{tag}_{prefix}_max_radii2D"] = gm.max_radii2D.numpy().copy()
+        out[f"{tag}_{prefix}_which_object"] = gm._which_object.numpy().copy()
+    snap("pre")
+    torch.manual_seed(1000 + seed)
+    gm.densify_and_prune(0.0002, 0.005, 2.0, max_screen_size)
+    snap("post")
+    out[f"{tag}_args"] = np.array([0.0002, 0.005, 2.0, -1.0 if max_screen_size is None else float(max_screen_size), 1000 + seed])
+
+
+dens = {}
+_densify_case(3, 300, 20, "a", dens)
+_densify_case(4, 257, None, "b", dens)
+np.savez_compressed(os.path.join(OUT, "densify.npz"), **dens)
+print("densify fixture:", {k: v.shape for k, v in dens.items() if k.endswith("_xyz")})

@@ -305,3 +305,50 @@ def test_training_with_densification_prune_and_opacity_reset():
     assert m.xyz_gradient_accum.shape[0] == m.num_points and m.max_radii2D.shape[0] == m.num_points
     assert torch.isfinite(m.flat).all() and all(np.isfinite(losses))
     assert min(losses[30:44]) < np.mean(losses[:5])        # learning happens between the opacity resets (45, 90)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_densify_compaction_kernel_matches_reference_golden(tag, monkeypatch):
+    """csrc/w3d_densify.hip against tests/golden/densify.npz (the reference's own densify_and_prune, CPU): the random
+    split samples are taken from the CPU stream the fixture was made with, everything else runs on the GPU.  Rows, order,
+    Adam moments, which_object and statistics must match bit for bit; the split children's positions (a bmm on the GPU)
+    to 1e-6."""
+    import os
+    from test_host_logic import _model_from_golden, G
+    z = np.load(os.path.join(G, "densify.npz"))
+    m = _model_from_golden(z, tag, device="cuda:0")
+    max_grad, min_opacity, extent, mss, seed = [float(x) for x in z[f"{tag}_args"]]
+    real_normal = torch.normal
+
+    def cpu_stream_normal(mean, std, **kw):
+        return real_normal(mean=mean.cpu(), std=std.cpu(), **kw).to(std.device)
+    monkeypatch.setattr(torch, "normal", cpu_stream_normal)
+    torch.manual_seed(int(seed))
+    P0 = m.num_points
+    m.densify_and_prune(max_grad, min_opacity, extent, None if mss < 0 else mss)
+    assert m.num_points == z[f"{tag}_post_xyz"].shape[0] != P0
+    mom = m.optimizer.moments()
+    for n in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"):
+        got, ref = m._p[n].detach().cpu().numpy(), z[f"{tag}_post_{n}"]
+        if n == "xyz":
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
+            assert (got != ref).mean() < 0.2          # only split children may differ at all
+        elif n == "scaling":
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)     # log() of the children's scales on the GPU
+        else:
+            assert np.array_equal(got, ref), n
+        assert np.array_equal(mom[n][0].cpu().numpy(), z[f"{tag}_post_m_{n}"]), n
+        assert np.array_equal(mom[n][1].cpu().numpy(), z[f"{tag}_post_v_{n}"]), n
+    assert np.array_equal(m._which_object.cpu().numpy(), z[f"{tag}_post_which_object"])
+    assert float(m.xyz_gradient_accum.abs().max()) == 0 and float(m.max_radii2D.abs().max()) == 0
+    # prune_points keeps the survivors' statistics and moments
+    m.max_radii2D = torch.arange(m.num_points, device="cuda:0", dtype=torch.float32)
+    before = m.flat.clone()
+    sl = m.block_slices()["f_rest"]
+    mask = torch.zeros(m.num_points, dtype=torch.bool, device="cuda:0")
+    mask[1::3] = True
+    Pb = m.num_points
+    m.prune_points(mask)
+    keep = (~mask).nonzero().squeeze(1)
+    assert torch.equal(m.max_radii2D, keep.float())
+    assert torch.equal(m._p["f_rest"].detach().reshape(-1, 45), before[sl[0]:sl[1]].view(Pb, 45)[keep])

@@ -233,3 +233,63 @@ def test_ply_roundtrip_and_layout(tmp_path):
     m2.load_ply(path)
     assert torch.equal(m2.flat, m.flat) and torch.equal(m2._which_object, m._which_object)
     assert m2.active_sh_degree == 3
+
+
+def _model_from_golden(z, tag, device="cpu"):
+    """GaussianModel + FlatAdam holding the pre-densification state of fixture case `tag`."""
+    names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+    t = {n: torch.tensor(z[f"{tag}_pre_{n}"]) for n in names}
+    m = GaussianModel(3, device=device)
+    m.create_from_tensors(t["xyz"], t["f_dc"], t["f_rest"], t["scaling"], t["rotation"], t["opacity"])
+    m.training_setup(OptimizationParams())
+    mom = m.optimizer.moments()
+    for n in names:
+        mom[n][0].copy_(torch.tensor(z[f"{tag}_pre_m_{n}"]).to(device))
+        mom[n][1].copy_(torch.tensor(z[f"{tag}_pre_v_{n}"]).to(device))
+    m.optimizer.step_count = 2
+    m.xyz_gradient_accum = torch.tensor(z[f"{tag}_pre_accum"]).to(device)
+    m.denom = torch.tensor(z[f"{tag}_pre_denom"]).to(device)
+    m.max_radii2D = torch.tensor(z[f"{tag}_pre_max_radii2D"]).to(device)
+    m._which_object = torch.tensor(z[f"{tag}_pre_which_object"]).to(device)
+    return m
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_densify_and_prune_matches_reference_golden(tag):
+    """tests/golden/densify.npz was produced by the reference's own GaussianModel.densify_and_prune (with its
+    torch.optim.Adam state surgery) on the CPU: the one-pass compaction must give the same rows in the same order,
+    the same Adam moments, and the same statistics, bit for bit (same torch CPU random stream for the split samples)."""
+    z = np.load(os.path.join(G, "densify.npz"))
+    m = _model_from_golden(z, tag)
+    max_grad, min_opacity, extent, mss, seed = [float(x) for x in z[f"{tag}_args"]]
+    torch.manual_seed(int(seed))
+    m.densify_and_prune(max_grad, min_opacity, extent, None if mss < 0 else mss)
+    assert m.num_points == z[f"{tag}_post_xyz"].shape[0]
+    mom = m.optimizer.moments()
+    for n in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"):
+        assert np.array_equal(m._p[n].detach().numpy(), z[f"{tag}_post_{n}"]), n
+        assert np.array_equal(mom[n][0].numpy(), z[f"{tag}_post_m_{n}"]), n
+        assert np.array_equal(mom[n][1].numpy(), z[f"{tag}_post_v_{n}"]), n
+    assert np.array_equal(m._which_object.numpy(), z[f"{tag}_post_which_object"])
+    assert np.array_equal(m.xyz_gradient_accum.numpy(), z[f"{tag}_post_accum"])
+    assert np.array_equal(m.denom.numpy(), z[f"{tag}_post_denom"])
+    assert np.array_equal(m.max_radii2D.numpy(), z[f"{tag}_post_max_radii2D"])
+    assert m.optimizer.step_count == 2 and m.flat_store.numel() % 256 == 0
+
+
+def test_stepwise_densify_equals_one_pass():
+    """clone -> split -> prune as three separate compactions (the reference's own sequence) == the folded single pass."""
+    z = np.load(os.path.join(G, "densify.npz"))
+    a, b = _model_from_golden(z, "a"), _model_from_golden(z, "a")
+    torch.manual_seed(5)
+    a.densify_and_prune(2e-4, 0.005, 2.0, 20)
+    torch.manual_seed(5)
+    grads = b.xyz_gradient_accum / b.denom
+    grads[grads.isnan()] = 0.0
+    b.densify_and_clone(grads, 2e-4, 2.0)
+    b.densify_and_split(grads, 2e-4, 2.0)
+    prune = (b.get_opacity < 0.005).squeeze() | (b.max_radii2D > 20) | (b.get_scaling.max(dim=1).values > 0.1 * 2.0)
+    b.prune_points(prune)
+    assert a.num_points == b.num_points
+    assert torch.equal(a.flat, b.flat) and torch.equal(a.optimizer.exp_avg, b.optimizer.exp_avg)
+    assert torch.equal(a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq) and torch.equal(a._which_object, b._which_object)

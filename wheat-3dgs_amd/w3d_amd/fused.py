@@ -12,6 +12,8 @@ lib.w3d_l1_ssim_fwd_bwd.argtypes = [_i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _v
 lib.w3d_l1_ssim_fwd_bwd.restype = ctypes.c_int
 lib.w3d_adam_step.argtypes = [_u64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _i32, _vp]
 lib.w3d_adam_step.restype = ctypes.c_int
+lib.w3d_densify_compact.argtypes = [_i32, ctypes.POINTER(_i32), _i32, _i32, _u64, _u64, _u64, _u64] + [_vp] * 10
+lib.w3d_densify_compact.restype = ctypes.c_int
 
 
 def l1_ssim_fwd_bwd(image, gt, lambda_dssim=0.2):
@@ -43,3 +45,21 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, bc1, bc2, zero_grad=False):
     with torch.cuda.device(p.device):
         check(lib.w3d_adam_step(n, ptr(p), ptr(g), ptr(m), ptr(v), float(lr), float(beta1), float(beta2), float(eps),
                                 float(bc1), float(bc2), int(bool(zero_grad)), stream_ptr(p.device)))
+
+
+def densify_compact(block_dims, xyz_block, scaling_block, P_old, src_rows, n_keep, n_child0, param_old, m_old, v_old,
+                    param_new, m_new, v_new, child_xyz=None, child_scaling=None):
+    """One-pass row compaction of the flat parameter buffer and the Adam moments (csrc/w3d_densify.hip).
+    src_rows: int32 (P_new,) source row of every output row; rows >= n_keep get zero moments; rows >= n_child0
+    take their xyz / scaling from child_xyz / child_scaling."""
+    if not param_old.is_cuda:
+        raise RuntimeError("densify_compact needs GPU tensors")
+    P_new = int(src_rows.numel())
+    dims = (_i32 * len(block_dims))(*[int(d) for d in block_dims])
+    src = src_rows.to(torch.int32).contiguous()
+    cx = None if child_xyz is None else child_xyz.float().contiguous()
+    cs = None if child_scaling is None else child_scaling.float().contiguous()
+    with torch.cuda.device(param_old.device):
+        check(lib.w3d_densify_compact(len(block_dims), dims, int(xyz_block), int(scaling_block), int(P_old), P_new,
+                                      int(n_keep), int(n_child0), ptr(src), ptr(param_old), ptr(m_old), ptr(v_old),
+                                      ptr(param_new), ptr(m_new), ptr(v_new), ptr(cx), ptr(cs), stream_ptr(param_old.device)))

@@ -42,7 +42,10 @@ def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, ma
 
 def quat_to_rotmat(q):
     """(N,4) quaternion (normalised here, as reference utils/general_utils.py:78-99) -> (N,3,3)."""
-    q = q / q.norm(dim=1, keepdim=True)
+    # the norm as an explicit left-to-right sum of squares: torch's vectorised .norm() rounds differently in the last
+    # bit, and the split children's positions are compared bit for bit with the reference's (tests/golden/densify.npz)
+    n = torch.sqrt(q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1] + q[:, 2] * q[:, 2] + q[:, 3] * q[:, 3])
+    q = q / n[:, None]
     r, x, y, z = q.unbind(1)
     return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
@@ -97,6 +100,7 @@ class GaussianModel:
         n_pad = (n + 255) // 256 * 256
         self.flat_store = torch.zeros(n_pad, dtype=torch.float32, device=self.device)
         self.flat_grad_store = torch.zeros(n_pad, dtype=torch.float32, device=self.device)
+        self._full, self._spare = {}, {}
         self.flat = self.flat_store[:n]
         self.flat_grad = self.flat_grad_store[:n]
         self._p = {}
@@ -230,75 +234,155 @@ class GaussianModel:
         self.xyz_gradient_accum[update_filter] += torch.norm(g[update_filter, :2], dim=-1, keepdim=True)
         self.denom[update_filter] += 1
 
-    def _rebuild(self, keep, extra=None):
-        """Single resize path: keep rows where `keep` is True, then append `extra` rows.
-        Parameters, both Adam moments and the bookkeeping vectors move together."""
-        cur = {n: self._p[n].detach() for n, _ in BLOCKS}
-        mom = self.optimizer.moments() if self.optimizer is not None else None
-        new, new_m, new_v = {}, {}, {}
-        for n, _ in BLOCKS:
-            parts = [cur[n][keep]]
-            if extra is not None:
-                parts.append(extra[n])
-            new[n] = torch.cat(parts, 0)
-            if mom is not None:
-                m, v = mom[n]
-                pad = [] if extra is None else [torch.zeros_like(extra[n])]
-                new_m[n] = torch.cat([m[keep]] + pad, 0)
-                new_v[n] = torch.cat([v[keep]] + pad, 0)
-        n_extra = 0 if extra is None else extra["xyz"].shape[0]
-        wo = self._which_object[keep]
-        if extra is not None:
-            wo = torch.cat([wo, extra["which_object"]], 0)
-        stats = (self.xyz_gradient_accum[keep], self.denom[keep], self.max_radii2D[keep])
-        steps = self.optimizer.step_count if self.optimizer is not None else 0
-        self._bind(new)
-        self._which_object = wo
-        if self.optimizer is not None:
-            self.training_setup(self._train_args, moments=(new_m, new_v, steps))
-        if n_extra:
-            self._reset_stats()      # reference zeroes the statistics after every growth (densification_postfix)
+    def _bind_store(self, flat_store, flat_grad_store, P):
+        """Adopt already-filled flat buffers (layout of _bind) without copying."""
+        n = P * FLOATS_PER_GAUSSIAN
+        self.flat_store, self.flat_grad_store = flat_store, flat_grad_store
+        self.flat, self.flat_grad = flat_store[:n], flat_grad_store[:n]
+        self._p = {}
+        off = 0
+        for name, shape in BLOCKS:
+            k = P * int(np.prod(shape))
+            p = nn.Parameter(self.flat[off:off + k].view(P, *shape), requires_grad=True)
+            p.grad = self.flat_grad[off:off + k].view(P, *shape)
+            self._p[name] = p
+            off += k
+
+    def _compact(self, src, n_keep, n_child0=None, child_xyz=None, child_scaling=None, reset_stats=True):
+        """The single resize path.  New row r = old row src[r]; rows >= n_keep are new points
+        (zero Adam moments, reference cat_tensors_to_optimizer :356-374), rows >= n_child0 are split children whose
+        xyz / scaling come from child_xyz / child_scaling.  Parameters and both moments move in ONE pass of
+        csrc/w3d_densify.hip on the GPU (torch index_select on the CPU, for the host-logic tests)."""
+        P_old, P_new = self.num_points, int(src.numel())
+        n_child0 = P_new if n_child0 is None else int(n_child0)
+        n = P_new * FLOATS_PER_GAUSSIAN
+        n_pad = (n + 255) // 256 * 256
+        opt = self.optimizer
+        # Buffers come from a two-generation pool with 25 % head room: a fresh multi-GB hipMalloc costs 100+ ms,
+        # the compaction itself ~5 ms at 5 M Gaussians, and P changes at every densification.
+        spare, self._spare = getattr(self, "_spare", {}), {}
+        cur = getattr(self, "_full", {})
+
+        def take(key):
+            buf = spare.pop(key, None)
+            if buf is None or buf.numel() < n_pad or buf.device != self.flat.device:
+                buf = torch.empty((int(n_pad * 1.25) + 255) // 256 * 256, dtype=torch.float32, device=self.flat.device)
+            return buf
+        full = {"store": take("store")}
+        new_store = full["store"][:n_pad]
+        new_store[n:].zero_()
+        g_full = cur.get("grad")
+        full["grad"] = g_full if g_full is not None and g_full.numel() >= n_pad else take("grad")
+        new_grad = full["grad"][:n_pad]
+        new_grad.zero_()
+        m_new = v_new = None
+        if opt is not None:
+            full["m"], full["v"] = take("m"), take("v")
+            m_new, v_new = full["m"][:n], full["v"][:n]
+        dims = [int(np.prod(shape)) for _, shape in BLOCKS]
+        names = [name for name, _ in BLOCKS]
+        if self.flat.is_cuda:
+            from .fused import densify_compact
+            densify_compact(dims, names.index("xyz"), names.index("scaling"), P_old, src, n_keep, n_child0, self.flat,
+                            None if opt is None else opt.exp_avg, None if opt is None else opt.exp_avg_sq,
+                            new_store, m_new, v_new, child_xyz, child_scaling)
+        else:
+            src64 = src.to(torch.int64)
+            off_o = off_n = 0
+            for name, d in zip(names, dims):
+                def rows(buf):
+                    return buf[off_o:off_o + P_old * d].view(P_old, d).index_select(0, src64)
+                blk = rows(self.flat.detach())
+                if n_child0 < P_new and name == "xyz":
+                    blk[n_child0:] = child_xyz
+                if n_child0 < P_new and name == "scaling":
+                    blk[n_child0:] = child_scaling
+                new_store[off_n:off_n + P_new * d] = blk.reshape(-1)
+                if opt is not None:
+                    for old, new_ in ((opt.exp_avg, m_new), (opt.exp_avg_sq, v_new)):
+                        mb = rows(old)
+                        mb[n_keep:] = 0
+                        new_[off_n:off_n + P_new * d] = mb.reshape(-1)
+                off_o += P_old * d
+                off_n += P_new * d
+        src64 = src.to(torch.int64)
+        self._which_object = self._which_object.index_select(0, src64)
+        stats = None if reset_stats else (self.xyz_gradient_accum.index_select(0, src64), self.denom.index_select(0, src64),
+                                          self.max_radii2D.index_select(0, src64))
+        steps = opt.step_count if opt is not None else 0
+        # the buffers just vacated serve the next compaction
+        self._spare = {"store": cur.get("store", self.flat_store)}
+        if opt is not None:
+            self._spare["m"], self._spare["v"] = cur.get("m", opt.exp_avg), cur.get("v", opt.exp_avg_sq)
+        self._bind_store(new_store, new_grad, P_new)
+        self._full = full
+        if opt is not None:
+            self.training_setup(self._train_args, moments=(m_new, v_new, steps))
+        if reset_stats:
+            self._reset_stats()      # reference zeroes the statistics after every growth (densification_postfix :395-397)
         else:
             self.xyz_gradient_accum, self.denom, self.max_radii2D = stats
 
     def prune_points(self, mask):
-        self._rebuild(~mask)
+        """reference :340-354 — drops the rows where mask is True, keeps the statistics of the survivors."""
+        src = (~mask).nonzero().squeeze(1)
+        self._compact(src, n_keep=src.numel(), reset_stats=False)
 
-    def _select(self, sel, repeat=1):
-        d = {n: self._p[n].detach()[sel].repeat(repeat, *([1] * (self._p[n].dim() - 1))) for n, _ in BLOCKS}
-        d["which_object"] = self._which_object[sel].repeat(repeat, 1)
-        return d
+    def _split_children(self, sel_idx, N):
+        """xyz and (raw) scaling of the N children of every selected Gaussian, reference :407-414 (same torch.normal
+        call on the same stds, so the same random stream is consumed)."""
+        stds = self.get_scaling.detach()[sel_idx].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
+        rots = quat_to_rotmat(self._p["rotation"].detach()[sel_idx]).repeat(N, 1, 1)
+        child_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self._p["xyz"].detach()[sel_idx].repeat(N, 1)
+        return child_xyz, torch.log(stds / (0.8 * N))
+
+    def _selection(self, grads, grad_threshold, scene_extent):
+        hot = torch.norm(grads, dim=-1) >= grad_threshold
+        smax = self.get_scaling.detach().max(dim=1).values
+        return hot & (smax <= self.percent_dense * scene_extent), hot & (smax > self.percent_dense * scene_extent), smax
 
     def densify_and_clone(self, grads, grad_threshold, scene_extent):
-        sel = (torch.norm(grads, dim=-1) >= grad_threshold) & \
-              (self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent)
-        self._rebuild(torch.ones(self.num_points, dtype=torch.bool, device=self.device), self._select(sel))
+        """reference :425-439"""
+        P = self.num_points
+        clone, _, _ = self._selection(grads, grad_threshold, scene_extent)
+        src = torch.cat([torch.arange(P, device=self.device), clone.nonzero().squeeze(1)])
+        self._compact(src, n_keep=P)
 
     def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
+        """reference :399-423 (grads shorter than P are zero-padded, as there)"""
         P = self.num_points
-        padded = torch.zeros(P, device=self.device)
-        padded[:grads.shape[0]] = grads.squeeze()
-        sel = (padded >= grad_threshold) & (self.get_scaling.max(dim=1).values > self.percent_dense * scene_extent)
-        new = self._select(sel, N)
-        stds = self.get_scaling.detach()[sel].repeat(N, 1)
-        samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
-        rots = quat_to_rotmat(self._p["rotation"].detach()[sel]).repeat(N, 1, 1)
-        new["xyz"] = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + new["xyz"]
-        new["scaling"] = torch.log(stds / (0.8 * N))
-        keep = torch.ones(P, dtype=torch.bool, device=self.device)
-        self._rebuild(keep, new)
-        drop = torch.cat((sel, torch.zeros(N * int(sel.sum()), dtype=torch.bool, device=self.device)))
-        self.prune_points(drop)
+        padded = torch.zeros(P, 1, device=self.device)
+        padded[:grads.shape[0]] = grads.reshape(-1, 1)
+        _, split, _ = self._selection(padded, grad_threshold, scene_extent)
+        sel_idx = split.nonzero().squeeze(1)
+        child_xyz, child_scaling = self._split_children(sel_idx, N)
+        keep = (~split).nonzero().squeeze(1)
+        self._compact(torch.cat([keep, sel_idx.repeat(N)]), n_keep=keep.numel(), n_child0=keep.numel(),
+                      child_xyz=child_xyz, child_scaling=child_scaling)
 
-    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, N=2):
+        """reference :441-455, with clone -> split -> prune folded into ONE compaction of the buffers.  The surviving rows
+        and their order are those of the reference's three steps: originals that are neither split nor pruned, then
+        the clones, then the children (all first samples, then all second samples).  Quirk kept: densification_postfix
+        zeroes max_radii2D before the screen-size test :449, so that test can never fire; only opacity and the
+        world-size test prune."""
         grads = self.xyz_gradient_accum / self.denom
         grads[grads.isnan()] = 0.0
-        self.densify_and_clone(grads, max_grad, extent)
-        self.densify_and_split(grads, max_grad, extent)
-        prune = (self.get_opacity < min_opacity).squeeze()
+        clone, split, smax = self._selection(grads, max_grad, extent)
+        low = (self.get_opacity.detach() < min_opacity).squeeze(-1)
+        prune_parent = (low | (smax > 0.1 * extent)) if max_screen_size else low
+        sel_idx = split.nonzero().squeeze(1)
+        child_xyz, child_scaling = self._split_children(sel_idx, N)
+        child_prune = low[sel_idx].repeat(N)
         if max_screen_size:
-            prune = prune | (self.max_radii2D > max_screen_size) | (self.get_scaling.max(dim=1).values > 0.1 * extent)
-        self.prune_points(prune)
+            child_prune = child_prune | (torch.exp(child_scaling).max(dim=1).values > 0.1 * extent)
+        idx_keep = (~split & ~prune_parent).nonzero().squeeze(1)
+        idx_clone = (clone & ~prune_parent).nonzero().squeeze(1)
+        ck = ~child_prune
+        src = torch.cat([idx_keep, idx_clone, sel_idx.repeat(N)[ck]])
+        self._compact(src, n_keep=idx_keep.numel(), n_child0=idx_keep.numel() + idx_clone.numel(),
+                      child_xyz=child_xyz[ck], child_scaling=child_scaling[ck])
 
     def reset_opacity(self):
         new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))

@@ -19,6 +19,11 @@ class FlatAdam:
         self.betas = betas
         self.eps = eps
         self.step_count = 0
+        if moments is not None and isinstance(moments[0], torch.Tensor):
+            # flat moments with the layout of model.flat, adopted as they are (densification's compaction kernel wrote them)
+            self.exp_avg, self.exp_avg_sq, self.step_count = moments[0], moments[1], int(moments[2])
+            assert self.exp_avg.shape == model.flat.shape and self.exp_avg_sq.shape == model.flat.shape
+            return
         self.exp_avg = torch.zeros_like(model.flat)
         self.exp_avg_sq = torch.zeros_like(model.flat)
         if moments is not None:
