@@ -17,6 +17,8 @@
  *        <- simple_knn._C.distCUDA2            reference scene/gaussian_model.py:20,148
  *   w3d_l1_ssim_fwd_bwd (next-row N1)
  *        <- utils/loss_utils.py:17-63 (l1_loss, ssim) as used at train_vanilla_3dgs.py:77-80
+ *   w3d_backward_raw_adam (next-row N2, single GPU)
+ *        <- train_vanilla_3dgs.py:80 loss.backward() + :113-115 optimizer.step() / zero_grad()
  *   w3d_densify_compact (next-row N3)
  *        <- scene/gaussian_model.py:332-397,441-455 (optimizer-state surgery of densify / prune)
  *   w3d_adam_step (next-row N2)
@@ -169,6 +171,28 @@ int w3d_backward_raw(const w3d_view *view, int32_t P, const w3d_raw_params *para
                      const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth,
                      const float *dL_dalpha, const w3d_raw_grads *grads, const w3d_densify_stats *stats,
                      void *scratch, w3d_stream_t stream);
+
+/* Single-GPU fusion of the optimizer into the backward pass (next-row N2): the per-Gaussian stage of the backward has
+ * the complete gradient of its Gaussian in registers / LDS, so it applies torch.optim.Adam's update
+ * (scene/gaussian_model.py:172-182, stepped at train_vanilla_3dgs.py:113-115) to the 59 parameters and their moments
+ * right there — the 472 MB gradient bucket is neither written nor read back.  `params` are updated IN PLACE.
+ * lr[i] / skip[i] in block order xyz, f_dc, f_rest, opacity, scaling, rotation; a skipped block keeps parameters and
+ * moments untouched (the reference's replaced nn.Parameters have .grad None in that step).  If the forward's speculative
+ * list buffer was too small (counters on the device say so) NOTHING is updated, so the caller can repeat the view.
+ * Needs sh_coeffs == 16.  The gradient norms / statistics of `stats` are produced as in w3d_backward_raw. */
+typedef struct w3d_raw_blocks {
+    float *xyz, *f_dc, *f_rest, *opacity, *scaling, *rotation;
+} w3d_raw_blocks;
+typedef struct w3d_adam_fused {
+    w3d_raw_blocks exp_avg, exp_avg_sq;
+    float lr[6];
+    int32_t skip[6];
+    float beta1, beta2, eps, bias_correction1, bias_correction2;
+} w3d_adam_fused;
+int w3d_backward_raw_adam(const w3d_view *view, int32_t P, const w3d_raw_blocks *params, const void *state,
+                          const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth,
+                          const float *dL_dalpha, const w3d_adam_fused *adam, const w3d_densify_stats *stats,
+                          void *scratch, w3d_stream_t stream);
 
 /* mean squared distance to the 3 nearest other points; points (N,3) -> out (N,) */
 int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream);

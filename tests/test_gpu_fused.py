@@ -115,6 +115,7 @@ def test_fused_raw_step_equals_autograd_step(deg, W, H):
         opt = OptimizationParams()
         m.training_setup(opt)
         tr = Trainer(m, cams, opt, bg, densify=False, fused=fused)
+        tr.fused_adam = False            # the gradient bucket is compared below: keep the optimizer a separate sweep
         assert tr.fused == fused
         # peek at the gradient bucket of the first step before Adam consumes it
         orig = m.optimizer.step
@@ -147,8 +148,10 @@ def test_fused_raw_step_equals_autograd_step(deg, W, H):
     assert float((ma.denom != mb.denom).float().mean()) <= 1e-2
 
 
-def test_speculative_list_capacity_overflow_is_repeated():
-    """The fused forward sizes the per-tile list buffer from previous views and never syncs with the host;
+@pytest.mark.parametrize("fused_adam", [False, True])
+def test_speculative_list_capacity_overflow_is_repeated(fused_adam):
+    """(fused_adam: the backward kernel that applies the optimizer must update NOTHING when the lists overflowed.)
+    The fused forward sizes the per-tile list buffer from previous views and never syncs with the host;
     when the guess is too small the view must be repeated, with the same result as a run whose guess held."""
     from w3d_amd import fused_step
     from w3d_amd.synth import make_scene, make_cameras
@@ -170,6 +173,7 @@ def test_speculative_list_capacity_overflow_is_repeated():
         opt = OptimizationParams()
         m.training_setup(opt)
         tr = Trainer(m, cams, opt, bg, densify=False)
+        tr.fused_adam = fused_adam
         calls = {"n": 0}
         orig = fused_step.render_raw
 
@@ -352,3 +356,56 @@ def test_densify_compaction_kernel_matches_reference_golden(tag, monkeypatch):
     keep = (~mask).nonzero().squeeze(1)
     assert torch.equal(m.max_radii2D, keep.float())
     assert torch.equal(m._p["f_rest"].detach().reshape(-1, 45), before[sl[0]:sl[1]].view(Pb, 45)[keep])
+
+
+def test_fused_adam_backward_equals_separate_adam_sweep():
+    """w3d_backward_raw_adam (optimizer applied by the backward kernel, no gradient bucket) against w3d_backward_raw +
+    w3d_adam_step: same parameters and moments after one step (up to float-atomic ordering noise in the gradients), same
+    statistics, step counter advanced, and the gradient bucket never written."""
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    W, H = 208, 160
+    cams = [c.to(dev) for c in make_cameras(4, W, H)]
+    g = torch.Generator().manual_seed(2)
+    for cam in cams:
+        cam.original_image = torch.rand(3, H, W, generator=g).to(dev)
+    bg = torch.tensor([0.0, 0.1, 0.2], device=dev)
+    sc = make_scene(7000, seed=11, scale_mean=0.02)
+    out = []
+    for fused_adam in (False, True):
+        m = GaussianModel(3, device=dev)
+        m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+        m.active_sh_degree = 3
+        opt = OptimizationParams()
+        m.training_setup(opt)
+        m.flat_grad.fill_(123.0)
+        tr = Trainer(m, cams, opt, bg, densify=False)
+        tr.fused_adam = fused_adam
+        p0 = m.flat.clone()
+        tr.step(1)
+        one = (m.flat.clone(), m.optimizer.exp_avg.clone(), m.optimizer.exp_avg_sq.clone(), m.xyz_gradient_accum.clone(),
+               m.denom.clone(), m.max_radii2D.clone())
+        if fused_adam:
+            assert float((m.flat_grad - 123.0).abs().max()) == 0          # bucket untouched
+        for it in range(2, 5):
+            tr.step(it)
+        assert m.optimizer.step_count == 4
+        out.append((one, m.flat.clone(), p0))
+    (a1, a4, p0), (b1, b4, _) = out
+    # moments after one step are (1-b1) g and (1-b2) g^2: compare them like gradients
+    for k, tol in ((1, 2e-4), (2, 4e-4)):
+        for name, (lo, hi) in m.block_slices().items():
+            ref = a1[k][lo:hi]
+            err = float((b1[k][lo:hi] - ref).abs().max() / (ref.abs().max() + 1e-30))
+            assert err <= tol, f"moment {k} of {name}: rel err {err:.2e}"
+    # the first Adam step moves every parameter with a non-zero gradient by ~lr: both flavours moved the same way
+    moved = (a1[0] - p0).abs() > 0
+    assert float(moved.float().mean()) > 0.3
+    d1 = (a1[0] - b1[0]).abs()
+    assert float((d1 > 1e-6).float().mean()) <= 2e-3 and float(d1.max()) <= 0.11
+    assert torch.equal(a1[4], b1[4]) and torch.equal(a1[5], b1[5])
+    assert float((a1[3] - b1[3]).abs().max() / a1[3].abs().max()) <= 2e-4
+    d4 = (a4 - b4).abs()
+    assert float((d4 > 1e-4).float().mean()) <= 2e-3 and float(d4.max()) <= 0.25

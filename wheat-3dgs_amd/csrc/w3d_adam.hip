@@ -8,10 +8,7 @@ namespace {
 
 __device__ __forceinline__ void adam1(float &p, float &g, float &m, float &v, float step_size, float b1, float b2,
                                       float eps, float inv_sqrt_bc2) {
-    m = b1 * m + (1.f - b1) * g;
-    v = b2 * v + (1.f - b2) * g * g;
-    const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
-    p = p - step_size * (m / denom);
+    w3d_adam1(p, g, m, v, step_size, b1, b2, eps, inv_sqrt_bc2);
 }
 
 // NT (bit 0 loads, bit 1 stores): nontemporal accesses — the sweep touches 3.3 GB once per step, caching any of it

@@ -306,6 +306,38 @@ int w3d_backward_raw(const w3d_view *view, int32_t P, const w3d_raw_params *prm,
                                           grads->opacity, grads->scaling, grads->rotation, nullptr, &ra, stream);
 }
 
+int w3d_backward_raw_adam(const w3d_view *view, int32_t P, const w3d_raw_blocks *prm, const void *state,
+                          const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                          const w3d_adam_fused *adam, const w3d_densify_stats *stats, void *scratch, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    int rc = check_view(view);
+    if (rc) return rc;
+    W3DLayout L;
+    rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
+    if (rc) { w3d_set_error("bad sizes"); return rc; }
+    if (P == 0) return W3D_OK;
+    if (!state || !scratch || !dL_dcolor || !prm || !adam) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
+    if (!(adam->bias_correction1 > 0.f) || !(adam->bias_correction2 > 0.f)) {
+        w3d_set_error("fused Adam: bias corrections must be positive (step >= 1)");
+        return W3D_ERR_INVALID;
+    }
+    if (stats && stats->xyz_gradient_accum) {
+        w3d_set_error("fused Adam: statistics are applied by the caller once the view is known to be final");
+        return W3D_ERR_INVALID;
+    }
+    const char *st = static_cast<const char *>(state);
+    float *grad2d = static_cast<float *>(scratch);
+    rc = w3d_launch_render_backward(L, *view, st, point_list, dL_dcolor, dL_ddepth, dL_dalpha, grad2d, stream);
+    if (rc) return rc;
+    W3DRawBwdArgs ra = {};
+    ra.f_rest = prm->f_rest; ra.opacity_logit = prm->opacity;
+    ra.adam = adam; ra.params_rw = prm;
+    if (stats) { ra.gnorm_out = stats->grad2d_norm; ra.radii = stats->radii; }
+    return w3d_launch_preprocess_backward(L, *view, prm->xyz, prm->f_dc, nullptr, prm->scaling, prm->rotation, nullptr, st,
+                                          grad2d, nullptr, stats ? stats->dL_dmeans2D : nullptr, nullptr, nullptr, nullptr,
+                                          nullptr, nullptr, nullptr, &ra, stream);
+}
+
 int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream_) {
     if (N < 0 || (N > 0 && (!points || !out))) { w3d_set_error("bad knn arguments"); return W3D_ERR_INVALID; }
     return w3d_launch_knn(N, points, out, reinterpret_cast<hipStream_t>(stream_));

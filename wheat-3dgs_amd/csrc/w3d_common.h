@@ -146,7 +146,20 @@ struct W3DRawBwdArgs {
     float *dL_df_rest, *gnorm_out;
     const int32_t *radii;
     float *accum, *denom, *max_radii;
+    const w3d_adam_fused *adam;       // non-NULL: apply Adam in place instead of writing gradients
+    const w3d_raw_blocks *params_rw;  // ... to these parameter blocks
 };
+
+// torch.optim.Adam's element update (no weight decay / amsgrad), shared by the sweep kernel and the fused backward;
+// contraction off so that both compile to the same roundings
+__device__ __forceinline__ void w3d_adam1(float &p, float g, float &m, float &v, float step_size, float b1, float b2,
+                                          float eps, float inv_sqrt_bc2) {
+#pragma clang fp contract(off)
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+    p = p - step_size * (m / denom);
+}
 
 // kernels' host launchers (one per .hip file)
 int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,

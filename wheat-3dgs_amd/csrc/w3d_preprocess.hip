@@ -378,7 +378,59 @@ struct RawBwd {
     float *gnorm_out;          // (P,) ||dL/dmean2D.xy|| (0 for culled), nullable
     const int32_t *radii;      // (P,) for the fused statistics, nullable
     float *accum, *denom, *max_radii;   // densification statistics updated in place, nullable
+    // fused optimizer (ADAM instantiation): blocks in the order xyz, f_dc, f_rest, opacity, scaling, rotation
+    float *pw[6], *m[6], *v[6];
+    float step_size[6];                 // lr / bias_correction1 per block
+    uint32_t skip_mask;                 // bit i: leave block i untouched
+    float b1, b2, eps, inv_sqrt_bc2;
+    const uint32_t *counters;           // forward counters: [1] = list length needed, [3] = list capacity used
 };
+
+// Adam on the `rows` x DIM contiguous floats a workgroup owns in parameter block b, gradients taken from an LDS stage
+// (row stride rstride, column offset coff).  16-B nontemporal accesses when the span is aligned (U groups of 3 loads in
+// flight per thread), dword accesses otherwise and for the tail.
+template <int DIM, int U>
+__device__ __forceinline__ void coop_adam(const RawBwd &raw, int b, size_t g0, int rows, const float *stage, int rstride, int coff) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    float *pb = raw.pw[b] + g0 * DIM, *mb = raw.m[b] + g0 * DIM, *vb = raw.v[b] + g0 * DIM;
+    const float step = raw.step_size[b];
+    const int n = rows * DIM;
+    const bool vec = (((uintptr_t)pb | (uintptr_t)mb | (uintptr_t)vb) & 15) == 0;
+    const int nv = vec ? n / 4 : 0;
+    for (int q0 = threadIdx.x; q0 < nv; q0 += 256 * U) {
+        f4 pp[U], mm[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int q = q0 + u * 256;
+            if (q < nv) {
+                pp[u] = __builtin_nontemporal_load(reinterpret_cast<f4 *>(pb) + q);
+                mm[u] = __builtin_nontemporal_load(reinterpret_cast<f4 *>(mb) + q);
+                vv[u] = __builtin_nontemporal_load(reinterpret_cast<f4 *>(vb) + q);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int q = q0 + u * 256;
+            if (q < nv) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int e = 4 * q + c;
+                    float a = pp[u][c], cm = mm[u][c], cv = vv[u][c];
+                    w3d_adam1(a, stage[(e / DIM) * rstride + coff + e % DIM], cm, cv, step, raw.b1, raw.b2, raw.eps, raw.inv_sqrt_bc2);
+                    pp[u][c] = a; mm[u][c] = cm; vv[u][c] = cv;
+                }
+                __builtin_nontemporal_store(pp[u], reinterpret_cast<f4 *>(pb) + q);
+                __builtin_nontemporal_store(mm[u], reinterpret_cast<f4 *>(mb) + q);
+                __builtin_nontemporal_store(vv[u], reinterpret_cast<f4 *>(vb) + q);
+            }
+        }
+    }
+    for (int e = 4 * nv + threadIdx.x; e < n; e += 256) {
+        float pp = pb[e], mm = mb[e], vv = vb[e];
+        w3d_adam1(pp, stage[(e / DIM) * rstride + coff + e % DIM], mm, vv, step, raw.b1, raw.b2, raw.eps, raw.inv_sqrt_bc2);
+        pb[e] = pp; mb[e] = mm; vb[e] = vv;
+    }
+}
 
 // RAW: shs/dL_dshs are the f_dc blocks, scales/rotations/opacity are pre-activation and the
 // gradients are chained through exp / normalize / sigmoid before being written.
@@ -386,7 +438,10 @@ struct RawBwd {
 // 256 Gaussians are staged in LDS (row stride 49 floats: conflict-free) and written out as one
 // contiguous, fully coalesced span instead of 45-48 dword stores per lane at a 180/192-B stride.
 #define W3D_SHROW 49
-template <bool HAS_SH, bool HAS_SCALE_ROT, bool RAW, bool FAST16>
+// ADAM (with RAW and FAST16): instead of writing the gradients, apply the optimizer update to the parameter blocks and
+// their moments in place (w3d_backward_raw_adam) — unless the forward overflowed its list buffer, in which case
+// nothing is touched and the host repeats the view.
+template <bool HAS_SH, bool HAS_SCALE_ROT, bool RAW, bool FAST16, bool ADAM = false>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
                       const float *__restrict__ scales, const float *__restrict__ rotations,
@@ -402,6 +457,8 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
     if (!(HAS_SH && FAST16) && !active) return;
     const int g = active ? gid : P - 1;       // FAST16: idle lanes of the last block still reach the barrier
     const int Mc = v.sh_coeffs;
+    // (uniform over the grid) the forward's lists fitted their buffer, so this backward is final
+    const bool adam_ok = ADAM && raw.counters[1] <= raw.counters[3];
     float inv_qnorm = 1.f;
     float q_act[4] = {1.f, 0.f, 0.f, 0.f}, s_act[3] = {0.f, 0.f, 0.f};
     const ushort4 rc = rect[g];
@@ -615,7 +672,10 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
         __syncthreads();
         const size_t g0 = (size_t)blockIdx.x * 256;
         const int rows = (int)min((size_t)256, (size_t)P - g0);
-        if (RAW) {
+        if (RAW && ADAM) {
+            if (adam_ok && !(raw.skip_mask & 2u)) coop_adam<3, 1>(raw, 1, g0, rows, sh_stage, W3D_SHROW, 0);
+            if (adam_ok && !(raw.skip_mask & 4u)) coop_adam<45, 4>(raw, 2, g0, rows, sh_stage, W3D_SHROW, 3);
+        } else if (RAW) {
             float *ddc = dL_dshs + g0 * 3, *drest = raw.dL_df_rest + g0 * 45;
             for (int e = threadIdx.x; e < rows * 3; e += 256) ddc[e] = sh_stage[(e / 3) * W3D_SHROW + e % 3];
             for (int e = threadIdx.x; e < rows * 45; e += 256) drest[e] = sh_stage[(e / 45) * W3D_SHROW + 3 + e % 45];
@@ -623,7 +683,7 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
             float *dall = dL_dshs + g0 * 48;
             for (int e = threadIdx.x; e < rows * 48; e += 256) dall[e] = sh_stage[(e / 48) * W3D_SHROW + e % 48];
         }
-        if (!active) return;
+        if (!ADAM && !active) return;      // (ADAM: every thread stays for the cooperative phases below)
     }
     if (RAW) {
         // chain through the activations: s = exp(ls), o = sigmoid(lo), q = r / |r|
@@ -636,8 +696,8 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
 #pragma unroll
         for (int i = 0; i < 4; i++) drot[i] = (drot[i] - q_act[i] * qd) * inv_qnorm;
         const float gn = sqrtf(dm2[0] * dm2[0] + dm2[1] * dm2[1]);
-        if (raw.gnorm_out) raw.gnorm_out[g] = vis ? gn : 0.f;
-        if (raw.accum && vis) {
+        if (raw.gnorm_out && active) raw.gnorm_out[g] = vis ? gn : 0.f;
+        if (raw.accum && vis && active) {
             // add_densification_stats + max_radii2D update (scene/gaussian_model.py:461-463,
             // train_vanilla_3dgs.py:102) fused for the single-GPU step
             raw.accum[g] += gn;
@@ -645,8 +705,25 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
             raw.max_radii[g] = fmaxf(raw.max_radii[g], (float)raw.radii[g]);
         }
     }
+    if (dL_dmeans2D && active) { dL_dmeans2D[3 * (size_t)g] = dm2[0]; dL_dmeans2D[3 * (size_t)g + 1] = dm2[1]; dL_dmeans2D[3 * (size_t)g + 2] = 0.f; }
+    if (ADAM) {
+        // the narrow blocks go through the (now free) LDS stage as well: row = [dmean 3 | dop 1 | dscale 3 | drot 4], stride 15
+        __syncthreads();
+        float *st2 = sh_stage + threadIdx.x * 15;
+        st2[0] = dmean[0]; st2[1] = dmean[1]; st2[2] = dmean[2]; st2[3] = dop;
+        st2[4] = dscale[0]; st2[5] = dscale[1]; st2[6] = dscale[2];
+        st2[7] = drot[0]; st2[8] = drot[1]; st2[9] = drot[2]; st2[10] = drot[3];
+        __syncthreads();
+        if (!adam_ok) return;
+        const size_t g0 = (size_t)blockIdx.x * 256;
+        const int rows = (int)min((size_t)256, (size_t)P - g0);
+        if (!(raw.skip_mask & 1u)) coop_adam<3, 1>(raw, 0, g0, rows, sh_stage, 15, 0);
+        if (!(raw.skip_mask & 8u)) coop_adam<1, 1>(raw, 3, g0, rows, sh_stage, 15, 3);
+        if (!(raw.skip_mask & 16u)) coop_adam<3, 1>(raw, 4, g0, rows, sh_stage, 15, 4);
+        if (!(raw.skip_mask & 32u)) coop_adam<4, 1>(raw, 5, g0, rows, sh_stage, 15, 7);
+        return;
+    }
     dL_dmeans3D[3 * (size_t)g] = dmean[0]; dL_dmeans3D[3 * (size_t)g + 1] = dmean[1]; dL_dmeans3D[3 * (size_t)g + 2] = dmean[2];
-    if (dL_dmeans2D) { dL_dmeans2D[3 * (size_t)g] = dm2[0]; dL_dmeans2D[3 * (size_t)g + 1] = dm2[1]; dL_dmeans2D[3 * (size_t)g + 2] = 0.f; }
     dL_dopacity[g] = dop;
     if (!HAS_SH && dL_dcolors) {
         dL_dcolors[3 * (size_t)g] = dcol[0]; dL_dcolors[3 * (size_t)g + 1] = dcol[1]; dL_dcolors[3 * (size_t)g + 2] = dcol[2];
@@ -715,6 +792,24 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
         raw.gnorm_out = rawargs->gnorm_out; raw.radii = rawargs->radii; raw.accum = rawargs->accum;
         raw.denom = rawargs->denom; raw.max_radii = rawargs->max_radii;
     }
+    const bool fused_adam = rawargs && rawargs->adam;
+    if (fused_adam) {
+        if (v.sh_coeffs != 16) { w3d_set_error("fused Adam needs 16 SH coefficients"); return W3D_ERR_INVALID; }
+        const w3d_adam_fused &a = *rawargs->adam;
+        const w3d_raw_blocks &pw = *rawargs->params_rw;
+        float *const pws[6] = {pw.xyz, pw.f_dc, pw.f_rest, pw.opacity, pw.scaling, pw.rotation};
+        float *const ms[6] = {a.exp_avg.xyz, a.exp_avg.f_dc, a.exp_avg.f_rest, a.exp_avg.opacity, a.exp_avg.scaling, a.exp_avg.rotation};
+        float *const vs[6] = {a.exp_avg_sq.xyz, a.exp_avg_sq.f_dc, a.exp_avg_sq.f_rest, a.exp_avg_sq.opacity, a.exp_avg_sq.scaling,
+                              a.exp_avg_sq.rotation};
+        for (int i = 0; i < 6; i++) {
+            if (!pws[i] || !ms[i] || !vs[i]) { w3d_set_error("fused Adam: NULL parameter / moment block"); return W3D_ERR_INVALID; }
+            raw.pw[i] = pws[i]; raw.m[i] = ms[i]; raw.v[i] = vs[i];
+            raw.step_size[i] = a.lr[i] / a.bias_correction1;
+            if (a.skip[i]) raw.skip_mask |= 1u << i;
+        }
+        raw.b1 = a.beta1; raw.b2 = a.beta2; raw.eps = a.eps; raw.inv_sqrt_bc2 = 1.0f / sqrtf(a.bias_correction2);
+        raw.counters = reinterpret_cast<const uint32_t *>(state + L.o_counters);
+    }
 #define LAUNCH(A, B, C)                                                                                                  \
     if (A && v.sh_coeffs == 16)                                                                                          \
         LAUNCH2(A, B, C, true);                                                                                          \
@@ -726,7 +821,12 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
                        reinterpret_cast<const uint8_t *>(state + L.o_clamped), grad2d, dL_dmeans3D, dL_dmeans2D,         \
                        dL_dcolors, dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
     W3D_PROF("preprocess_bwd", stream);
-    if (rawargs) LAUNCH(true, true, true);
+    if (fused_adam)
+        hipLaunchKernelGGL((preprocess_bwd_kernel<true, true, true, true, true>), dim3(grid), dim3(block), 0, stream, v, L.P, means3D, shs,
+                           scales, rotations, cov3D_precomp, raw, reinterpret_cast<const ushort4 *>(state + L.o_rect),
+                           reinterpret_cast<const uint8_t *>(state + L.o_clamped), grad2d, dL_dmeans3D, dL_dmeans2D, dL_dcolors,
+                           dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D);
+    else if (rawargs) LAUNCH(true, true, true);
     else if (has_sh && has_sr) LAUNCH(true, true, false);
     else if (has_sh) LAUNCH(true, false, false);
     else if (has_sr) LAUNCH(false, true, false);

@@ -38,6 +38,18 @@ lib.w3d_backward_raw.argtypes = [ctypes.POINTER(W3DView), _i32, ctypes.POINTER(W
 lib.w3d_backward_raw.restype = ctypes.c_int
 
 
+class W3DAdamFused(ctypes.Structure):
+    _fields_ = [("exp_avg", W3DRawGrads), ("exp_avg_sq", W3DRawGrads), ("lr", ctypes.c_float * 6), ("skip", _i32 * 6),
+                ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("bias_correction1", ctypes.c_float), ("bias_correction2", ctypes.c_float)]
+
+
+lib.w3d_backward_raw_adam.argtypes = [ctypes.POINTER(W3DView), _i32, ctypes.POINTER(W3DRawGrads), _vp, _vp, _vp, _vp, _vp,
+                                      ctypes.POINTER(W3DAdamFused), ctypes.POINTER(W3DDensifyStats), _vp, _vp]
+lib.w3d_backward_raw_adam.restype = ctypes.c_int
+_BLOCK_ORDER = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+
+
 def _raw_params(model):
     p = W3DRawParams()
     p.xyz, p.f_dc, p.f_rest = model._xyz.data_ptr(), model._features_dc.data_ptr(), model._features_rest.data_ptr()
@@ -191,3 +203,42 @@ def backward_raw(model, handle, dL_dimage, dL_ddepth=None, dL_dalpha=None, updat
                                    ptr(handle["point_list"]), ptr(dL_dimage.contiguous()), ptr(dL_ddepth), ptr(dL_dalpha),
                                    ctypes.byref(g), ctypes.byref(st), ptr(scratch), stream_ptr(dev)))
     return gnorm, m2d
+
+
+def backward_raw_adam(model, handle, dL_dimage, skip=(), want_norm=True):
+    """Backward with the optimizer fused in (single GPU): the kernel that finishes each Gaussian's gradient applies
+    FlatAdam's update to the parameter blocks and both moments in place, so the 59*P gradient bucket is neither written
+    nor read back (model.flat_grad is left untouched).  If the forward overflowed its speculative list buffer the kernel
+    updates NOTHING; the caller checks finish(handle) and only then calls model.optimizer.note_fused_step().
+    Returns the per-Gaussian ||dL/dmean2D|| (0 for culled) when want_norm."""
+    import math
+    dev = model.flat.device
+    P, view = handle["P"], handle["view"]
+    opt = model.optimizer
+    if P != model.num_points:
+        raise RuntimeError("model was resized between forward and backward")
+    prm, ad = W3DRawGrads(), W3DAdamFused()
+    sl = model.block_slices()
+    b1, b2 = opt.betas
+    t = opt.step_count + 1
+    for i, n in enumerate(_BLOCK_ORDER):
+        a, _ = sl[n]
+        setattr(prm, n, model._p[n].data_ptr())
+        setattr(ad.exp_avg, n, opt.exp_avg.data_ptr() + 4 * a)
+        setattr(ad.exp_avg_sq, n, opt.exp_avg_sq.data_ptr() + 4 * a)
+        ad.lr[i] = float(opt.lrs[n])
+        ad.skip[i] = int(n in skip)
+    ad.beta1, ad.beta2, ad.eps = float(b1), float(b2), float(opt.eps)
+    ad.bias_correction1, ad.bias_correction2 = 1.0 - math.pow(b1, t), 1.0 - math.pow(b2, t)
+    st = W3DDensifyStats()
+    gnorm = torch.empty(P, dtype=torch.float32, device=dev) if want_norm else None
+    st.grad2d_norm = None if gnorm is None else gnorm.data_ptr()
+    st.radii = handle["radii"].data_ptr()
+    with torch.cuda.device(dev):
+        sb = ctypes.c_uint64()
+        check(lib.w3d_backward_sizes(P, ctypes.byref(sb)))
+        scratch = torch.empty(sb.value, dtype=torch.uint8, device=dev)
+        check(lib.w3d_backward_raw_adam(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(handle["state"]),
+                                        ptr(handle["point_list"]), ptr(dL_dimage.contiguous()), None, None,
+                                        ctypes.byref(ad), ctypes.byref(st), ptr(scratch), stream_ptr(dev)))
+    return gnorm

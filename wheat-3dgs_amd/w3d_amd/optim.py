@@ -67,6 +67,10 @@ class FlatAdam:
         self.step_count = int(d["step"])
         self.lrs.update(d["lrs"])
 
+    def note_fused_step(self):
+        """The backward kernel applied this step's update itself (fused_step.backward_raw_adam)."""
+        self.step_count += 1
+
     @torch.no_grad()
     def step(self, zero_grad=False, skip=(), elem_range=None):
         """One Adam step on every block.  zero_grad=True clears the gradient bucket in the same

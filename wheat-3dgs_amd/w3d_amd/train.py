@@ -61,6 +61,9 @@ class Trainer:
         # with the banded walk only ~12 Gaussians per 64-batch reach the serial loop, so the per-lane
         # pre-filter over each Gaussian's tiles costs as much as it saves, and the fast-changing synthetic
         # scene misses its cuts on ~60 % of the revisits.
+        # single GPU: the optimizer update is applied by the backward kernel itself (fused_step.backward_raw_adam), except
+        # in the iterations that densify / reset opacity (there the reference skips the replaced parameters' update)
+        self.fused_adam = os.environ.get("W3D_FUSED_ADAM", "1") == "1"
         self.use_depth_cuts = os.environ.get("W3D_DEPTH_CUTS", "0") == "1"
         self.depth_cuts = {}
         self.cut_misses = 0
@@ -152,6 +155,14 @@ class Trainer:
             buf.copy_(full[:n])
         self._moments_sharded = False
 
+    def _structure_change_due(self, iteration):
+        """Does _post_backward densify / prune / reset opacity in this iteration?"""
+        opt = self.opt
+        if not (iteration < opt.densify_until_iter and self.densify):
+            return False
+        return (iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0) or \
+            iteration % opt.opacity_reset_interval == 0
+
     def _post_backward(self, iteration, nsum, vcount, rmax, stats_done):
         """Densification bookkeeping + optimizer step shared by both step flavours."""
         m, opt = self.model, self.opt
@@ -182,7 +193,7 @@ class Trainer:
         raw-parameter backward writing the flat gradient bucket and — on one GPU — the
         densification statistics.  No autograd graph is built."""
         from .fused import l1_ssim_fwd_bwd
-        from .fused_step import backward_raw, finish, render_raw
+        from .fused_step import backward_raw, backward_raw_adam, finish, render_raw
         m, opt = self.model, self.opt
         m.update_learning_rate(iteration)
         if iteration % 1000 == 0:
@@ -197,14 +208,19 @@ class Trainer:
             # per-camera depth cuts from the previous visit (speculative list truncation, verified by finish())
             key = id(cam)
             cut = self.depth_cuts.get(key) if self.use_depth_cuts else None
+            use_adam = (single and self.fused_adam and not self.use_depth_cuts and iteration < opt.iterations and
+                        m.max_sh_degree == 3 and not self._structure_change_due(iteration))
             while True:
                 pkg = render_raw(cam, m, self.bg, sync=False, depth_cut=cut, want_cut=self.use_depth_cuts)
                 loss, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
                 if not single and self.world > 1:
                     dimg.mul_(1.0 / self.world)      # the bucket then holds grad/world: reduce-scatter(SUM) = mean
-                gnorm, _ = backward_raw(m, pkg["handle"], dimg, update_stats=fused_stats, want_norm=True)
+                if use_adam:
+                    gnorm = backward_raw_adam(m, pkg["handle"], dimg, want_norm=True)
+                else:
+                    gnorm, _ = backward_raw(m, pkg["handle"], dimg, update_stats=fused_stats, want_norm=True)
                 if finish(pkg["handle"]):        # the only host wait of the step, with the backward already queued
-                    break
+                    break                        # (on overflow the fused-Adam kernel updated nothing: repeat the view)
                 if pkg["handle"]["suspect_tiles"]:
                     cut = None                   # some tile needed more than its cut allowed: repeat without cuts
                     self.cut_misses += 1
@@ -224,7 +240,9 @@ class Trainer:
             else:
                 nsum = vcount = rmax = None
             skip = self._post_backward(iteration, nsum, vcount, rmax, stats_done=single)
-            if iteration < opt.iterations:
+            if use_adam:
+                m.optimizer.note_fused_step()
+            elif iteration < opt.iterations:
                 # the next backward overwrites the whole bucket: no zeroing pass needed
                 self.optimizer_step_and_gather(zero_grad=bool(skip), skip=skip)
         self.last = dict(loss=loss, image=pkg["render"], radii=pkg["radii"])
