@@ -179,7 +179,8 @@ int w3d_backward_raw(const w3d_view *view, int32_t P, const w3d_raw_params *para
  * lr[i] / skip[i] in block order xyz, f_dc, f_rest, opacity, scaling, rotation; a skipped block keeps parameters and
  * moments untouched (the reference's replaced nn.Parameters have .grad None in that step).  If the forward's speculative
  * list buffer was too small (counters on the device say so) NOTHING is updated, so the caller can repeat the view.
- * Needs sh_coeffs == 16.  The gradient norms / statistics of `stats` are produced as in w3d_backward_raw. */
+ * Needs sh_coeffs == 16.  grad2d_norm of `stats` is always produced; its in-place densification statistics are, like the
+ * parameters, only updated when the lists fitted. */
 typedef struct w3d_raw_blocks {
     float *xyz, *f_dc, *f_rest, *opacity, *scaling, *rotation;
 } w3d_raw_blocks;

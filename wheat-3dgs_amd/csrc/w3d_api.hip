@@ -321,8 +321,8 @@ int w3d_backward_raw_adam(const w3d_view *view, int32_t P, const w3d_raw_blocks 
         w3d_set_error("fused Adam: bias corrections must be positive (step >= 1)");
         return W3D_ERR_INVALID;
     }
-    if (stats && stats->xyz_gradient_accum) {
-        w3d_set_error("fused Adam: statistics are applied by the caller once the view is known to be final");
+    if (stats && stats->xyz_gradient_accum && (!stats->denom || !stats->max_radii2D || !stats->radii)) {
+        w3d_set_error("fused statistics need accum, denom, max_radii2D and radii together");
         return W3D_ERR_INVALID;
     }
     const char *st = static_cast<const char *>(state);
@@ -332,7 +332,11 @@ int w3d_backward_raw_adam(const w3d_view *view, int32_t P, const w3d_raw_blocks 
     W3DRawBwdArgs ra = {};
     ra.f_rest = prm->f_rest; ra.opacity_logit = prm->opacity;
     ra.adam = adam; ra.params_rw = prm;
-    if (stats) { ra.gnorm_out = stats->grad2d_norm; ra.radii = stats->radii; }
+    if (stats) {
+        // (the statistics, like the parameters, are only updated when the forward's lists fitted their buffer)
+        ra.gnorm_out = stats->grad2d_norm; ra.radii = stats->radii; ra.accum = stats->xyz_gradient_accum;
+        ra.denom = stats->denom; ra.max_radii = stats->max_radii2D;
+    }
     return w3d_launch_preprocess_backward(L, *view, prm->xyz, prm->f_dc, nullptr, prm->scaling, prm->rotation, nullptr, st,
                                           grad2d, nullptr, stats ? stats->dL_dmeans2D : nullptr, nullptr, nullptr, nullptr,
                                           nullptr, nullptr, nullptr, &ra, stream);

@@ -697,7 +697,8 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
         for (int i = 0; i < 4; i++) drot[i] = (drot[i] - q_act[i] * qd) * inv_qnorm;
         const float gn = sqrtf(dm2[0] * dm2[0] + dm2[1] * dm2[1]);
         if (raw.gnorm_out && active) raw.gnorm_out[g] = vis ? gn : 0.f;
-        if (raw.accum && vis && active) {
+        // (ADAM: only when this backward is final — the host does not touch the statistics in that mode)
+        if (raw.accum && vis && active && (!ADAM || adam_ok)) {
             // add_densification_stats + max_radii2D update (scene/gaussian_model.py:461-463,
             // train_vanilla_3dgs.py:102) fused for the single-GPU step
             raw.accum[g] += gn;

@@ -205,7 +205,7 @@ def backward_raw(model, handle, dL_dimage, dL_ddepth=None, dL_dalpha=None, updat
     return gnorm, m2d
 
 
-def backward_raw_adam(model, handle, dL_dimage, skip=(), want_norm=True):
+def backward_raw_adam(model, handle, dL_dimage, skip=(), want_norm=True, update_stats=False):
     """Backward with the optimizer fused in (single GPU): the kernel that finishes each Gaussian's gradient applies
     FlatAdam's update to the parameter blocks and both moments in place, so the 59*P gradient bucket is neither written
     nor read back (model.flat_grad is left untouched).  If the forward overflowed its speculative list buffer the kernel
@@ -234,6 +234,9 @@ def backward_raw_adam(model, handle, dL_dimage, skip=(), want_norm=True):
     gnorm = torch.empty(P, dtype=torch.float32, device=dev) if want_norm else None
     st.grad2d_norm = None if gnorm is None else gnorm.data_ptr()
     st.radii = handle["radii"].data_ptr()
+    if update_stats:     # add_densification_stats + max_radii2D inside the kernel, applied only if the view is final
+        st.xyz_gradient_accum, st.denom = model.xyz_gradient_accum.data_ptr(), model.denom.data_ptr()
+        st.max_radii2D = model.max_radii2D.data_ptr()
     with torch.cuda.device(dev):
         sb = ctypes.c_uint64()
         check(lib.w3d_backward_sizes(P, ctypes.byref(sb)))

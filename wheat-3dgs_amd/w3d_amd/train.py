@@ -216,7 +216,7 @@ class Trainer:
                 if not single and self.world > 1:
                     dimg.mul_(1.0 / self.world)      # the bucket then holds grad/world: reduce-scatter(SUM) = mean
                 if use_adam:
-                    gnorm = backward_raw_adam(m, pkg["handle"], dimg, want_norm=True)
+                    gnorm = backward_raw_adam(m, pkg["handle"], dimg, want_norm=False, update_stats=tracking)
                 else:
                     gnorm, _ = backward_raw(m, pkg["handle"], dimg, update_stats=fused_stats, want_norm=True)
                 if finish(pkg["handle"]):        # the only host wait of the step, with the backward already queued
@@ -226,7 +226,7 @@ class Trainer:
                     self.cut_misses += 1
             if self.use_depth_cuts and pkg["handle"]["depth_cut_out"] is not None:
                 self.depth_cuts[key] = pkg["handle"]["depth_cut_out"]
-            if single and tracking:
+            if single and tracking and not use_adam:       # (the fused-Adam kernel updated the statistics itself)
                 vis = pkg["radii"] > 0
                 m.xyz_gradient_accum += gnorm[:, None]          # gnorm is 0 on culled Gaussians
                 m.denom += vis[:, None]
