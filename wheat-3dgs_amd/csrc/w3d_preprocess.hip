@@ -191,39 +191,47 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float *c, const float *
 }
 
 // ---------------------------------------------------------------------------------------------
-// Exact footprint test (tile_cull): can ANY pixel centre of tile (tx,ty) reach alpha >= 1/255 for this
-// Gaussian?  alpha = o*exp(-q(d)) with q(d) = 0.5*(A dx^2 + C dy^2) + B dx dy, so the question is
-// whether min over the tile's pixel box of q is <= tau = ln(255 o).  q is convex with its minimum at
-// the Gaussian's centre: either the centre lies in the box, or the box minimum sits on one of the
-// four edges, where it is a clamped 1-D parabola minimum.  tau carries a +1e-3 safety margin, far
-// above the fp32 rounding of either this test or the blend kernels' power, so an instance is only
-// dropped when it provably contributes nothing: every output is unchanged, R and R_walk shrink.
-__device__ __forceinline__ bool footprint_hits_tile(float mx, float my, float A, float B, float C, float tau,
-                                                    uint32_t tx, uint32_t ty, float wmax, float hmax) {
-    const float x0 = (float)(tx * W3D_TILE), y0 = (float)(ty * W3D_TILE);
-    const float x1 = fminf(x0 + (float)(W3D_TILE - 1), wmax), y1 = fminf(y0 + (float)(W3D_TILE - 1), hmax);
-    const float dxl = mx - x1, dxh = mx - x0, dyl = my - y1, dyh = my - y0;
-    if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;
-    if (!(A > 0.f && C > 0.f)) return true;
-    const float iA = 1.0f / A, iC = 1.0f / C;
-    float best;
-    {
-        const float dy = fminf(fmaxf(-B * dxl * iC, dyl), dyh);
-        best = 0.5f * (A * dxl * dxl + C * dy * dy) + B * dxl * dy;
+// Exact footprint culling (tile_cull): which tiles of the rect can reach alpha >= 1/255 for this Gaussian at
+// ANY pixel centre?  alpha = o*exp(-q(d)) with q(d) = 0.5*(A dx^2 + C dy^2) + B dx dy, so the reachable region is the
+// ellipse q <= tau = ln(255 o).  It is rasterised at tile granularity row by row: within the strip of pixel rows of
+// one tile row (offsets w in [w0, w1] from the centre) the ellipse spans u in [l(w), r(w)] with
+//     r(w), l(w) = (-B w +- sqrt(2 A tau - det w^2)) / A,       det = A C - B^2,
+// r concave / l convex in w, so the strip's extent is taken at the strip ends or at the stationary points
+// w* = -+ B sqrt(2 tau / (C det)) where r, l reach the ellipse's own extent +- sqrt(2 tau C / det).  The ellipse cut by a
+// strip is convex, hence the tiles it meets in a row are exactly the ones whose pixel columns meet [l, r]: one
+// contiguous run of mask bits per row, no per-tile test (the per-lane loop over up to 64 tiles used to dominate
+// the kernel: a wave runs as long as its largest rect).  tau carries a +1e-3 margin and the intervals a +0.01 px
+// margin, far above fp32 rounding, so a tile is only dropped when the Gaussian provably contributes nothing there:
+// every output is unchanged, R and R_walk shrink.  Bit k of the result = k-th tile of the rect, row-major.
+__device__ __forceinline__ uint64_t footprint_tile_mask(float mx, float my, float A, float B, float C, float tau,
+                                                        int minx, int miny, int maxx, int maxy) {
+    if (tau < 0.f) return 0ull;                       // o <= 1/255: alpha >= 1/255 is unreachable anywhere
+    const float det = A * C - B * B;
+    if (!(A > 0.f && C > 0.f && det > 0.f)) return ~0ull;
+    const float T2 = 2.f * tau, idet = 1.0f / det, iA = 1.0f / A;
+    const float pad = 0.01f;
+    const float wmax = sqrtf(T2 * A * idet) + pad;    // the ellipse's half height
+    const float xext = sqrtf(T2 * C * idet) + pad;    // ... and half width
+    const float wstar = B * sqrtf(T2 * idet / C);     // l is extremal at +wstar, r at -wstar
+    const int rw = maxx - minx;
+    uint64_t m = 0ull;
+    for (int ty = miny; ty < maxy; ty++) {
+        const float w0 = (float)(ty * W3D_TILE) - my, w1 = w0 + (float)(W3D_TILE - 1);
+        const float a = fmaxf(w0, -wmax), b = fminf(w1, wmax);
+        if (a > b) continue;                          // the strip misses the ellipse
+        const float sa = sqrtf(fmaxf(T2 * A - det * a * a, 0.f)), sb = sqrtf(fmaxf(T2 * A - det * b * b, 0.f));
+        const float ra = (-B * a + sa) * iA, rb = (-B * b + sb) * iA;
+        const float la = (-B * a - sa) * iA, lb = (-B * b - sb) * iA;
+        const float xr = ((-wstar >= a && -wstar <= b) ? xext : fmaxf(ra, rb) + pad) + mx;
+        const float xl = ((wstar >= a && wstar <= b) ? -xext : fminf(la, lb) - pad) + mx;
+        // tile tx holds the pixel columns [16 tx, 16 tx + 15]
+        const int t_lo = max(minx, (int)ceilf((xl - (float)(W3D_TILE - 1)) * (1.0f / W3D_TILE)));
+        const int t_hi = min(maxx - 1, (int)floorf(xr * (1.0f / W3D_TILE)));
+        if (t_lo > t_hi) continue;
+        const int cnt = t_hi - t_lo + 1, start = (ty - miny) * rw + (t_lo - minx);
+        m |= (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) << start;
     }
-    {
-        const float dy = fminf(fmaxf(-B * dxh * iC, dyl), dyh);
-        best = fminf(best, 0.5f * (A * dxh * dxh + C * dy * dy) + B * dxh * dy);
-    }
-    {
-        const float dx = fminf(fmaxf(-B * dyl * iA, dxl), dxh);
-        best = fminf(best, 0.5f * (A * dx * dx + C * dyl * dyl) + B * dx * dyl);
-    }
-    {
-        const float dx = fminf(fmaxf(-B * dyh * iA, dxl), dxh);
-        best = fminf(best, 0.5f * (A * dx * dx + C * dyh * dyh) + B * dx * dyh);
-    }
-    return !(best > tau);
+    return m;
 }
 
 // Activations of the raw (pre-activation) parameter path — what GaussianModel's getters apply
@@ -325,13 +333,7 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
             if (rn <= 64) {
                 // o <= 1/255 can never reach alpha >= 1/255: tau < 0 drops every tile
                 const float tau = (opac > 0.f) ? (__logf(255.0f * opac) + 1e-3f) : -1.0f;
-                m = 0ull;
-                int k = 0;
-                for (int ty = miny; ty < maxy; ty++)
-                    for (int tx = minx; tx < maxx; tx++, k++)
-                        if (footprint_hits_tile(px, py, conx, cony, conz, tau, (uint32_t)tx, (uint32_t)ty,
-                                                (float)(v.image_width - 1), (float)(v.image_height - 1)))
-                            m |= 1ull << k;
+                m = footprint_tile_mask(px, py, conx, cony, conz, tau, minx, miny, maxx, maxy);
             }
             tile_mask[g] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
         }
