@@ -19,6 +19,9 @@
  *        <- utils/loss_utils.py:17-63 (l1_loss, ssim) as used at train_vanilla_3dgs.py:77-80
  *   w3d_backward_raw_adam (next-row N2, single GPU)
  *        <- train_vanilla_3dgs.py:80 loss.backward() + :113-115 optimizer.step() / zero_grad()
+ *   w3d_backward_raw_lowrank, w3d_sh_adam_lowrank (row e, view-parallel exchange)
+ *        <- no reference counterpart (the reference is single-GPU); same arithmetic as
+ *           w3d_backward_raw + w3d_adam_step on the mean gradient of the views
  *   w3d_densify_compact (next-row N3)
  *        <- scene/gaussian_model.py:332-397,441-455 (optimizer-state surgery of densify / prune)
  *   w3d_adam_step (next-row N2)
@@ -194,6 +197,24 @@ int w3d_backward_raw_adam(const w3d_view *view, int32_t P, const w3d_raw_blocks 
                           const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth,
                           const float *dL_dalpha, const w3d_adam_fused *adam, const w3d_densify_stats *stats,
                           void *scratch, w3d_stream_t stream);
+
+/* View-parallel training: what the ranks exchange.  The SH gradient of ONE view is rank one per Gaussian —
+ * dL/dSH[k][c] = basis_k(view direction) * dL/dRGB[c] — so a rank does not ship its 48-float SH gradient rows:
+ * w3d_backward_raw_lowrank writes the clamp-masked dL/dRGB (P,3) into dcolor_out (zeros for culled Gaussians) and the
+ * gradients of the other four blocks into grads->{xyz, opacity, scaling, rotation} (grads->f_dc / f_rest are not
+ * touched and may be NULL); the ranks all-gather the (P,3) arrays, all-reduce the 11 geometry floats, and every rank
+ * then runs w3d_sh_adam_lowrank: it rebuilds  sum_v basis_k(normalize(xyz - campos_v)) * dcolor_v  for all n_views in
+ * view order (bit-identical on every rank) and applies Adam to f_dc / f_rest and their moments in place.
+ * campos_all: (n_views,3) device array; dcolor_all: (n_views,P,3); sh_degree = active degree; 16 coefficients. */
+int w3d_backward_raw_lowrank(const w3d_view *view, int32_t P, const w3d_raw_params *params, const void *state,
+                             const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth,
+                             const float *dL_dalpha, const w3d_raw_grads *grads, float *dcolor_out,
+                             const w3d_densify_stats *stats, void *scratch, w3d_stream_t stream);
+int w3d_sh_adam_lowrank(int32_t P, int32_t n_views, int32_t sh_degree, const float *campos_all, const float *xyz,
+                        const float *dcolor_all, float *f_dc, float *f_rest, float *exp_avg_dc, float *exp_avg_sq_dc,
+                        float *exp_avg_rest, float *exp_avg_sq_rest, float lr_dc, float lr_rest, int32_t skip_dc,
+                        int32_t skip_rest, float beta1, float beta2, float eps, float bias_correction1,
+                        float bias_correction2, w3d_stream_t stream);
 
 /* mean squared distance to the 3 nearest other points; points (N,3) -> out (N,) */
 int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream);

@@ -110,3 +110,88 @@ def test_view_parallel_exchange_two_ranks():
         m.flat_grad.copy_((_view_grad(0 + 10 * step, m.flat.numel()) + _view_grad(1 + 10 * step, m.flat.numel())) / world)
         m.optimizer.step()
     assert torch.allclose(m.optimizer.exp_avg, res[0][5], atol=1e-7)
+
+
+def _lowrank_inputs(rank, step, P, nflat):
+    """what a rank would hold after its own backward_raw_lowrank: dcolor (P,3) with culled rows, geometry gradients"""
+    g = torch.Generator().manual_seed(1000 + 17 * rank + step)
+    dcol = torch.randn(P, 3, generator=g) * 1e-2
+    dcol[torch.rand(P, generator=g) < 0.3] = 0.0
+    return dcol, torch.randn(nflat, generator=g) * 1e-2
+
+
+def _cams(n=10):
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(77)
+    return [SimpleNamespace(camera_center=torch.randn(3, generator=g) * 3.0) for _ in range(n)]
+
+
+def _lowrank_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, opt = _model()
+    m.active_sh_degree = 2
+    from w3d_amd.train import Trainer
+    P = m.num_points
+    tr = Trainer(m, _cams(), opt, torch.zeros(3), densify=True)
+    assert tr.exchange_mode == "lowrank"
+    for step in range(1, 4):
+        dcol, geo = _lowrank_inputs(rank, step, P, m.flat.numel())
+        m.flat_grad.copy_(geo / world)                       # SH blocks of the bucket are ignored by the exchange
+        gnorm = torch.rand(P) * 1e-3
+        vis = dcol.abs().sum(1) > 0
+        radii = (torch.rand(P) * 30).to(torch.int32) * vis
+        tr.exchange_lowrank(dcol / world, gnorm, vis, radii)
+        tr.wait_stats()
+        tr.optimizer_step_lowrank(step, skip=({"opacity"} if step == 2 else ()))
+    out.put((rank, m.flat.detach().clone(), m.optimizer.exp_avg.clone(), m.optimizer.exp_avg_sq.clone(), m.optimizer.step_count))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lowrank_exchange_two_ranks():
+    """exchange_lowrank + optimizer_step_lowrank on 2 gloo ranks == one process stepping Adam on the mean over the two views
+    of the DENSE gradient (SH gradient = basis(direction to that view's camera) x dcolor), and the replicas stay bit-identical
+    although no parameters are ever exchanged."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lowrank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in (1, 2, 3):
+        assert torch.equal(res[0][k], res[1][k])
+    assert res[0][4] == 3
+    # single-process reference
+    from w3d_amd.sh import sh_basis
+    from w3d_amd.train import Trainer
+    m, opt = _model()
+    m.active_sh_degree = 2
+    tr = Trainer(m, _cams(), opt, torch.zeros(3), densify=True)
+    tr.world = world                                        # only to enumerate the two views of each iteration
+    P = m.num_points
+    sl = m.block_slices()
+    for step in range(1, 4):
+        campos = tr.campos_of_all_ranks(step)
+        total = torch.zeros_like(m.flat)
+        sh = torch.zeros(P, 16, 3)
+        for r in range(world):
+            dcol, geo = _lowrank_inputs(r, step, P, m.flat.numel())
+            total += geo / world
+            dirs = m._p["xyz"].detach() - campos[r][None]
+            dirs = dirs / dirs.norm(dim=1, keepdim=True)
+            b = sh_basis(2, dirs)
+            sh[:, :9] += b[:, :, None] * (dcol / world)[:, None, :]
+        m.flat_grad.copy_(total)
+        m.flat_grad[sl["f_dc"][0]:sl["f_dc"][1]] = sh[:, :1].reshape(-1)
+        m.flat_grad[sl["f_rest"][0]:sl["f_rest"][1]] = sh[:, 1:].reshape(-1)
+        m.optimizer.step(skip=({"opacity"} if step == 2 else ()))
+    assert torch.allclose(m.flat, res[0][1], rtol=0, atol=2e-7)
+    assert torch.allclose(m.optimizer.exp_avg, res[0][2], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(m.optimizer.exp_avg_sq, res[0][3], rtol=1e-5, atol=1e-12)

@@ -1,0 +1,71 @@
+"""GPU, one rank: the view-parallel exchange paths of the fused step on a real RCCL process group (world_size 1 — the only
+world a 1-GPU box offers; the 2-rank logic is covered on CPU by tests/test_dist_gloo.py).  Both exchanges must reproduce the
+plain single-GPU step: "lowrank" (colour gradients gathered, SH gradient rebuilt by sh_adam_lowrank_kernel, geometry
+all-reduced, replicated Adam) and "dense" (in-place reduce-scatter, sharded Adam, in-place all-gather)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def one_rank_group():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    yield
+    dist.destroy_process_group()
+
+
+def test_exchange_paths_equal_single_gpu_step(one_rank_group):
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    W, H = 208, 160
+    cams = [c.to(dev) for c in make_cameras(4, W, H)]
+    g = torch.Generator().manual_seed(5)
+    for cam in cams:
+        cam.original_image = torch.rand(3, H, W, generator=g).to(dev)
+    bg = torch.tensor([0.1, 0.1, 0.0], device=dev)
+    sc = make_scene(7000, seed=13, scale_mean=0.02)
+    runs = {}
+    for name in ("single", "lowrank", "dense"):
+        m = GaussianModel(3, device=dev)
+        m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+        m.active_sh_degree = 2
+        opt = OptimizationParams()
+        m.training_setup(opt)
+        tr = Trainer(m, cams, opt, bg, densify=False, force_exchange=(name != "single"))
+        tr.fused_adam = False
+        tr.exchange_mode = name
+        tr.step(1)
+        one = (m.flat.clone(), m.optimizer.exp_avg.clone(), m.optimizer.exp_avg_sq.clone(), m.xyz_gradient_accum.clone(),
+               m.denom.clone(), m.max_radii2D.clone())
+        for it in range(2, 5):
+            tr.step(it)
+        assert m.optimizer.step_count == 4
+        if name != "single":
+            tr.gather_moments()
+        runs[name] = (one, m.flat.clone(), m)
+    ref1, ref4, mref = runs["single"]
+    for name in ("lowrank", "dense"):
+        one, four, m = runs[name]
+        for k, tol in ((1, 2e-4), (2, 4e-4)):           # moments after one step are (1-b1) g and (1-b2) g^2
+            for blk, (lo, hi) in m.block_slices().items():
+                r = ref1[k][lo:hi]
+                err = float((one[k][lo:hi] - r).abs().max() / (r.abs().max() + 1e-30))
+                assert err <= tol, f"{name}: moment {k} of {blk}: rel err {err:.2e}"
+        d1 = (one[0] - ref1[0]).abs()
+        assert float((d1 > 1e-6).float().mean()) <= 2e-3 and float(d1.max()) <= 0.11, name
+        assert torch.equal(one[4], ref1[4]) and torch.equal(one[5], ref1[5]), name
+        assert float((one[3] - ref1[3]).abs().max() / ref1[3].abs().max()) <= 2e-4, name
+        d4 = (four - ref4).abs()
+        assert float((d4 > 1e-4).float().mean()) <= 2e-3 and float(d4.max()) <= 0.25, name

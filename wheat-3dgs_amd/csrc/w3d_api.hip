@@ -342,6 +342,54 @@ int w3d_backward_raw_adam(const w3d_view *view, int32_t P, const w3d_raw_blocks 
                                           nullptr, nullptr, nullptr, &ra, stream);
 }
 
+int w3d_backward_raw_lowrank(const w3d_view *view, int32_t P, const w3d_raw_params *prm, const void *state,
+                             const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                             const w3d_raw_grads *grads, float *dcolor_out, const w3d_densify_stats *stats, void *scratch,
+                             w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    int rc = check_view(view);
+    if (rc) return rc;
+    W3DLayout L;
+    rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
+    if (rc) { w3d_set_error("bad sizes"); return rc; }
+    if (P == 0) return W3D_OK;
+    if (!state || !scratch || !dL_dcolor || !prm || !grads || !grads->xyz || !grads->opacity || !grads->scaling ||
+        !grads->rotation || !dcolor_out) {
+        w3d_set_error("NULL buffer");
+        return W3D_ERR_INVALID;
+    }
+    if (stats && stats->xyz_gradient_accum) {
+        w3d_set_error("view-parallel statistics are reduced across ranks by the caller");
+        return W3D_ERR_INVALID;
+    }
+    const char *st = static_cast<const char *>(state);
+    float *grad2d = static_cast<float *>(scratch);
+    rc = w3d_launch_render_backward(L, *view, st, point_list, dL_dcolor, dL_ddepth, dL_dalpha, grad2d, stream);
+    if (rc) return rc;
+    W3DRawBwdArgs ra = {};
+    ra.f_rest = prm->f_rest; ra.opacity_logit = prm->opacity; ra.dcolor_out = dcolor_out;
+    if (stats) { ra.gnorm_out = stats->grad2d_norm; ra.radii = stats->radii; }
+    return w3d_launch_preprocess_backward(L, *view, prm->xyz, prm->f_dc, nullptr, prm->scaling, prm->rotation, nullptr, st,
+                                          grad2d, grads->xyz, stats ? stats->dL_dmeans2D : nullptr, nullptr, nullptr,
+                                          grads->opacity, grads->scaling, grads->rotation, nullptr, &ra, stream);
+}
+
+int w3d_sh_adam_lowrank(int32_t P, int32_t n_views, int32_t sh_degree, const float *campos_all, const float *xyz,
+                        const float *dcolor_all, float *f_dc, float *f_rest, float *m_dc, float *v_dc, float *m_rest,
+                        float *v_rest, float lr_dc, float lr_rest, int32_t skip_dc, int32_t skip_rest, float beta1, float beta2,
+                        float eps, float bc1, float bc2, w3d_stream_t stream_) {
+    if (P < 0 || n_views < 0 || sh_degree < 0 || sh_degree > 3) { w3d_set_error("sh_adam_lowrank: bad sizes"); return W3D_ERR_INVALID; }
+    if (P == 0 || n_views == 0) return W3D_OK;
+    if (!campos_all || !xyz || !dcolor_all || !f_dc || !f_rest || !m_dc || !v_dc || !m_rest || !v_rest) {
+        w3d_set_error("sh_adam_lowrank: NULL buffer");
+        return W3D_ERR_INVALID;
+    }
+    if (!(bc1 > 0.f) || !(bc2 > 0.f)) { w3d_set_error("sh_adam_lowrank: bias corrections must be positive"); return W3D_ERR_INVALID; }
+    return w3d_launch_sh_adam_lowrank(P, n_views, sh_degree, campos_all, xyz, dcolor_all, f_dc, f_rest, m_dc, v_dc, m_rest, v_rest,
+                                      lr_dc, lr_rest, skip_dc, skip_rest, beta1, beta2, eps, bc1, bc2,
+                                      reinterpret_cast<hipStream_t>(stream_));
+}
+
 int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream_) {
     if (N < 0 || (N > 0 && (!points || !out))) { w3d_set_error("bad knn arguments"); return W3D_ERR_INVALID; }
     return w3d_launch_knn(N, points, out, reinterpret_cast<hipStream_t>(stream_));

@@ -146,6 +146,7 @@ struct W3DRawBwdArgs {
     float *dL_df_rest, *gnorm_out;
     const int32_t *radii;
     float *accum, *denom, *max_radii;
+    float *dcolor_out;                // non-NULL: write the (P,3) clamp-masked dL/dRGB instead of the SH gradient blocks
     const w3d_adam_fused *adam;       // non-NULL: apply Adam in place instead of writing gradients
     const w3d_raw_blocks *params_rw;  // ... to these parameter blocks
 };
@@ -185,6 +186,10 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
                                    float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
                                    const struct W3DRawBwdArgs *rawargs, hipStream_t stream);
 int w3d_launch_knn(int32_t N, const float *points, float *out, hipStream_t stream);
+int w3d_launch_sh_adam_lowrank(int32_t P, int32_t nviews, int32_t sh_degree, const float *campos_all, const float *xyz,
+                               const float *dcolor_all, float *f_dc, float *f_rest, float *m_dc, float *v_dc, float *m_rest,
+                               float *v_rest, float lr_dc, float lr_rest, int skip_dc, int skip_rest, float beta1, float beta2,
+                               float eps, float bc1, float bc2, hipStream_t stream);
 
 // per-Gaussian 2-D gradient record accumulated by the blend backward (16 floats = one 64-B line)
 //  [0] dL/dmean2D.x  [1] dL/dmean2D.y  [2] dL/dconic.x  [3] dL/dconic.y(half)  [4] dL/dconic.z

@@ -386,6 +386,7 @@ struct RawBwd {
     uint32_t skip_mask;                 // bit i: leave block i untouched
     float b1, b2, eps, inv_sqrt_bc2;
     const uint32_t *counters;           // forward counters: [1] = list length needed, [3] = list capacity used
+    float *dcolor_out;                  // MODE 2: (P,3) clamp-masked dL/dRGB per Gaussian (zeros for culled)
 };
 
 // Adam on the `rows` x DIM contiguous floats a workgroup owns in parameter block b, gradients taken from an LDS stage
@@ -443,7 +444,11 @@ __device__ __forceinline__ void coop_adam(const RawBwd &raw, int b, size_t g0, i
 // ADAM (with RAW and FAST16): instead of writing the gradients, apply the optimizer update to the parameter blocks and
 // their moments in place (w3d_backward_raw_adam) — unless the forward overflowed its list buffer, in which case
 // nothing is touched and the host repeats the view.
-template <bool HAS_SH, bool HAS_SCALE_ROT, bool RAW, bool FAST16, bool ADAM = false>
+// MODE 2 (with RAW, view-parallel exchange): the SH gradient of a view is the outer product of the SH basis at the view
+// direction with the clamp-masked dL/dRGB, so only those 3 floats per Gaussian are written (dcolor_out) — the ranks
+// exchange them instead of 48 floats and rebuild the sum over views in sh_adam_lowrank_kernel.  The gradients of the
+// other blocks are written as in MODE 0.  No LDS stage, no workgroup barrier.
+template <bool HAS_SH, bool HAS_SCALE_ROT, bool RAW, bool FAST16, int MODE = 0>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
                       const float *__restrict__ scales, const float *__restrict__ rotations,
@@ -453,10 +458,13 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
                       float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dcolors,
                       float *__restrict__ dL_dshs, float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
                       float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D) {
-    __shared__ float sh_stage[(HAS_SH && FAST16) ? 256 * W3D_SHROW : 1];
+    constexpr bool ADAM = MODE == 1;
+    constexpr bool STAGED = HAS_SH && FAST16 && MODE != 2;     // SH gradient rows go through the LDS stage
+    __shared__ float sh_stage[STAGED ? 256 * W3D_SHROW : 1];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = gid < P;
-    if (!(HAS_SH && FAST16) && !active) return;
+    if (!STAGED && !active) return;
+    float dRGB_out[3] = {0.f, 0.f, 0.f};
     const int g = active ? gid : P - 1;       // FAST16: idle lanes of the last block still reach the barrier
     const int Mc = v.sh_coeffs;
     // (uniform over the grid) the forward's lists fitted their buffer, so this backward is final
@@ -474,10 +482,10 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
     // coefficient k, channel c of the SH gradient: interleaved (P,M,3) or split dc | rest blocks
     float *dsh = HAS_SH ? (RAW ? dL_dshs + 3 * (size_t)g : dL_dshs + (size_t)g * Mc * 3) : nullptr;
     float *dsh_rest = (HAS_SH && RAW) ? raw.dL_df_rest + (size_t)g * (Mc - 1) * 3 : nullptr;
-#define DSH(k, c) (*(FAST16 ? (sh_stage + threadIdx.x * W3D_SHROW + 3 * (k) + (c)) \
+#define DSH(k, c) (*(STAGED ? (sh_stage + threadIdx.x * W3D_SHROW + 3 * (k) + (c)) \
                             : ((RAW && (k) > 0) ? (dsh_rest + 3 * ((k)-1) + (c)) : (dsh + 3 * (k) + (c)))))
     if (!vis) {
-        if (HAS_SH) {
+        if (HAS_SH && MODE != 2) {
             if (FAST16) {
 #pragma unroll
                 for (int i = 0; i < 48; i++) sh_stage[threadIdx.x * W3D_SHROW + i] = 0.f;
@@ -596,14 +604,17 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
             B[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); B[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
             B[14] = SH_C3[5] * z * (xx - yy); B[15] = SH_C3[6] * x * (xx - 3.f * yy);
             const int ncoef = (deg + 1) * (deg + 1);
+            dRGB_out[0] = dRGB[0]; dRGB_out[1] = dRGB[1]; dRGB_out[2] = dRGB[2];
+            if (MODE != 2) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) {   // static indices keep B[] in registers
-                if (k < Mc) {
-                    const float b = (k < ncoef) ? B[k] : 0.f;
-                    DSH(k, 0) = b * dRGB[0]; DSH(k, 1) = b * dRGB[1]; DSH(k, 2) = b * dRGB[2];
+                for (int k = 0; k < 16; k++) {   // static indices keep B[] in registers
+                    if (k < Mc) {
+                        const float b = (k < ncoef) ? B[k] : 0.f;
+                        DSH(k, 0) = b * dRGB[0]; DSH(k, 1) = b * dRGB[1]; DSH(k, 2) = b * dRGB[2];
+                    }
                 }
+                for (int k = 16; k < Mc; k++) { DSH(k, 0) = 0.f; DSH(k, 1) = 0.f; DSH(k, 2) = 0.f; }
             }
-            for (int k = 16; k < Mc; k++) { DSH(k, 0) = 0.f; DSH(k, 1) = 0.f; DSH(k, 2) = 0.f; }
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
 #define SH(k) sh[(k)*3 + ch]
@@ -669,7 +680,7 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
         }
     }
 #undef DSH
-    if (HAS_SH && FAST16) {
+    if (STAGED) {
         // coalesced write-out of the block's SH gradient rows
         __syncthreads();
         const size_t g0 = (size_t)blockIdx.x * 256;
@@ -726,6 +737,10 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
         if (!(raw.skip_mask & 32u)) coop_adam<4, 1>(raw, 5, g0, rows, sh_stage, 15, 7);
         return;
     }
+    if (MODE == 2) {
+        raw.dcolor_out[3 * (size_t)g] = dRGB_out[0]; raw.dcolor_out[3 * (size_t)g + 1] = dRGB_out[1];
+        raw.dcolor_out[3 * (size_t)g + 2] = dRGB_out[2];
+    }
     dL_dmeans3D[3 * (size_t)g] = dmean[0]; dL_dmeans3D[3 * (size_t)g + 1] = dmean[1]; dL_dmeans3D[3 * (size_t)g + 2] = dmean[2];
     dL_dopacity[g] = dop;
     if (!HAS_SH && dL_dcolors) {
@@ -741,7 +756,73 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
     }
 }
 
+// View-parallel optimizer step of the SH blocks (f_dc, f_rest) from the EXCHANGED colour gradients: for every Gaussian
+//   dL/dSH[k][c] = sum over views v of  basis_k(normalize(xyz - campos_v)) * dcolor_v[c]      (k < (deg+1)^2, else 0)
+// (dcolor_v = what preprocess_bwd_kernel<MODE 2> wrote on rank v, already scaled by 1/world), summed in view order so
+// that every rank computes bit-identical values, then torch.optim.Adam's update in place through the LDS stage exactly
+// as in the fused single-GPU backward.  14 instead of 59 floats per Gaussian and view cross the links, and because the
+// update is replicated no parameter all-gather follows.
+__global__ void __launch_bounds__(256)
+sh_adam_lowrank_kernel(int P, int nviews, int deg, const float *__restrict__ campos_all, const float *__restrict__ xyz,
+                       const float *__restrict__ dcolor_all, RawBwd raw) {
+    __shared__ float sh_stage[256 * W3D_SHROW];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = gid < P;
+    const int g = active ? gid : P - 1;
+    const int ncoef = (deg + 1) * (deg + 1);
+    float acc[48];
+#pragma unroll
+    for (int i = 0; i < 48; i++) acc[i] = 0.f;
+    const float p[3] = {xyz[3 * (size_t)g], xyz[3 * (size_t)g + 1], xyz[3 * (size_t)g + 2]};
+    for (int vw = 0; vw < nviews; vw++) {
+        const float *dc = dcolor_all + ((size_t)vw * P + g) * 3;
+        const float dr = dc[0], dg = dc[1], db = dc[2];
+        if (dr == 0.f && dg == 0.f && db == 0.f) continue;      // culled (or fully clamped) in that view
+        const float d0 = p[0] - campos_all[3 * vw], d1 = p[1] - campos_all[3 * vw + 1], d2 = p[2] - campos_all[3 * vw + 2];
+        const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        const float x = d0 / len, y = d1 / len, z = d2 / len;
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        float B[16];
+        B[0] = SH_C0;
+        B[1] = -SH_C1 * y; B[2] = SH_C1 * z; B[3] = -SH_C1 * x;
+        B[4] = SH_C2[0] * xy; B[5] = SH_C2[1] * yz; B[6] = SH_C2[2] * (2.f * zz - xx - yy);
+        B[7] = SH_C2[3] * xz; B[8] = SH_C2[4] * (xx - yy);
+        B[9] = SH_C3[0] * y * (3.f * xx - yy); B[10] = SH_C3[1] * xy * z; B[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+        B[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); B[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+        B[14] = SH_C3[5] * z * (xx - yy); B[15] = SH_C3[6] * x * (xx - 3.f * yy);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float b = (k < ncoef) ? B[k] : 0.f;
+            acc[3 * k] += b * dr; acc[3 * k + 1] += b * dg; acc[3 * k + 2] += b * db;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 48; i++) sh_stage[threadIdx.x * W3D_SHROW + i] = acc[i];
+    __syncthreads();
+    const size_t g0 = (size_t)blockIdx.x * 256;
+    const int rows = (int)min((size_t)256, (size_t)P - g0);
+    if (!(raw.skip_mask & 2u)) coop_adam<3, 1>(raw, 1, g0, rows, sh_stage, W3D_SHROW, 0);
+    if (!(raw.skip_mask & 4u)) coop_adam<45, 4>(raw, 2, g0, rows, sh_stage, W3D_SHROW, 3);
+}
+
 }  // namespace
+
+int w3d_launch_sh_adam_lowrank(int32_t P, int32_t nviews, int32_t sh_degree, const float *campos_all, const float *xyz,
+                               const float *dcolor_all, float *f_dc, float *f_rest, float *m_dc, float *v_dc, float *m_rest,
+                               float *v_rest, float lr_dc, float lr_rest, int skip_dc, int skip_rest, float beta1, float beta2,
+                               float eps, float bc1, float bc2, hipStream_t stream) {
+    if (P == 0 || nviews == 0) return W3D_OK;
+    RawBwd raw = {};
+    raw.pw[1] = f_dc; raw.m[1] = m_dc; raw.v[1] = v_dc; raw.step_size[1] = lr_dc / bc1;
+    raw.pw[2] = f_rest; raw.m[2] = m_rest; raw.v[2] = v_rest; raw.step_size[2] = lr_rest / bc1;
+    raw.skip_mask = (skip_dc ? 2u : 0u) | (skip_rest ? 4u : 0u);
+    raw.b1 = beta1; raw.b2 = beta2; raw.eps = eps; raw.inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    W3D_PROF("sh_adam_lowrank", stream);
+    hipLaunchKernelGGL(sh_adam_lowrank_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, nviews, sh_degree, campos_all, xyz,
+                       dcolor_all, raw);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}
 
 int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,
                           const float *colors_precomp, const float *opacities, const float *scales,
@@ -824,8 +905,15 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
                        reinterpret_cast<const uint8_t *>(state + L.o_clamped), grad2d, dL_dmeans3D, dL_dmeans2D,         \
                        dL_dcolors, dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
     W3D_PROF("preprocess_bwd", stream);
-    if (fused_adam)
-        hipLaunchKernelGGL((preprocess_bwd_kernel<true, true, true, true, true>), dim3(grid), dim3(block), 0, stream, v, L.P, means3D, shs,
+    if (rawargs && rawargs->dcolor_out) {
+        if (v.sh_coeffs != 16) { w3d_set_error("low-rank colour-gradient output needs 16 SH coefficients"); return W3D_ERR_INVALID; }
+        raw.dcolor_out = rawargs->dcolor_out;
+        hipLaunchKernelGGL((preprocess_bwd_kernel<true, true, true, true, 2>), dim3(grid), dim3(block), 0, stream, v, L.P, means3D, shs,
+                           scales, rotations, cov3D_precomp, raw, reinterpret_cast<const ushort4 *>(state + L.o_rect),
+                           reinterpret_cast<const uint8_t *>(state + L.o_clamped), grad2d, dL_dmeans3D, dL_dmeans2D, dL_dcolors,
+                           dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D);
+    } else if (fused_adam)
+        hipLaunchKernelGGL((preprocess_bwd_kernel<true, true, true, true, 1>), dim3(grid), dim3(block), 0, stream, v, L.P, means3D, shs,
                            scales, rotations, cov3D_precomp, raw, reinterpret_cast<const ushort4 *>(state + L.o_rect),
                            reinterpret_cast<const uint8_t *>(state + L.o_clamped), grad2d, dL_dmeans3D, dL_dmeans2D, dL_dcolors,
                            dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D);

@@ -48,6 +48,14 @@ lib.w3d_backward_raw_adam.argtypes = [ctypes.POINTER(W3DView), _i32, ctypes.POIN
                                       ctypes.POINTER(W3DAdamFused), ctypes.POINTER(W3DDensifyStats), _vp, _vp]
 lib.w3d_backward_raw_adam.restype = ctypes.c_int
 _BLOCK_ORDER = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+lib.w3d_backward_raw_lowrank.argtypes = [ctypes.POINTER(W3DView), _i32, ctypes.POINTER(W3DRawParams), _vp, _vp, _vp, _vp, _vp,
+                                         ctypes.POINTER(W3DRawGrads), _vp, ctypes.POINTER(W3DDensifyStats), _vp, _vp]
+lib.w3d_backward_raw_lowrank.restype = ctypes.c_int
+lib.w3d_sh_adam_lowrank.argtypes = [_i32, _i32, _i32] + [_vp] * 9 + [ctypes.c_float, ctypes.c_float, _i32, _i32] + \
+    [ctypes.c_float] * 5 + [_vp]
+lib.w3d_sh_adam_lowrank.restype = ctypes.c_int
+GEO_BLOCKS = ("xyz", "opacity", "scaling", "rotation")      # their gradients are all-reduced as they are (11 floats)
+SH_BLOCKS = ("f_dc", "f_rest")                               # rebuilt on every rank from the exchanged dL/dRGB
 
 
 def _raw_params(model):
@@ -245,3 +253,70 @@ def backward_raw_adam(model, handle, dL_dimage, skip=(), want_norm=True, update_
                                         ptr(handle["point_list"]), ptr(dL_dimage.contiguous()), None, None,
                                         ctypes.byref(ad), ctypes.byref(st), ptr(scratch), stream_ptr(dev)))
     return gnorm
+
+
+def backward_raw_lowrank(model, handle, dL_dimage, want_norm=True):
+    """Backward of the view-parallel step: gradients of the geometry blocks (xyz, opacity, scaling, rotation) into
+    model.flat_grad, and instead of the 48-float SH gradient rows the (P,3) clamp-masked dL/dRGB per Gaussian — the SH
+    gradient of one view is basis(view direction) x dL/dRGB, so that is all the other ranks need (sh_adam_lowrank).
+    Returns (||dL/dmean2D|| or None, dcolor (P,3))."""
+    dev = model.flat.device
+    P, view = handle["P"], handle["view"]
+    if P != model.num_points:
+        raise RuntimeError("model was resized between forward and backward")
+    prm = _raw_params(model)
+    g = W3DRawGrads()
+    for n in GEO_BLOCKS:
+        setattr(g, n, model._p[n].grad.data_ptr())
+    st = W3DDensifyStats()
+    gnorm = torch.empty(P, dtype=torch.float32, device=dev) if want_norm else None
+    dcol = torch.empty(P, 3, dtype=torch.float32, device=dev)
+    st.grad2d_norm = None if gnorm is None else gnorm.data_ptr()
+    st.radii = handle["radii"].data_ptr()
+    with torch.cuda.device(dev):
+        sb = ctypes.c_uint64()
+        check(lib.w3d_backward_sizes(P, ctypes.byref(sb)))
+        scratch = torch.empty(sb.value, dtype=torch.uint8, device=dev)
+        check(lib.w3d_backward_raw_lowrank(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(handle["state"]),
+                                           ptr(handle["point_list"]), ptr(dL_dimage.contiguous()), None, None,
+                                           ctypes.byref(g), ptr(dcol), ctypes.byref(st), ptr(scratch), stream_ptr(dev)))
+    return gnorm, dcol
+
+
+def sh_adam_lowrank(model, dcolor_all, campos_all, skip=()):
+    """Adam step of f_dc / f_rest from the colour gradients of ALL views of this iteration (dcolor_all (V,P,3), campos_all
+    (V,3)): dL/dSH[k] = sum_v basis_k(normalize(xyz - campos_v)) * dcolor_v, summed in view order.  The optimizer's step
+    counter must already be advanced for this iteration.  GPU: csrc sh_adam_lowrank_kernel, in place; CPU (host-logic
+    tests): the same formula with torch ops through FlatAdam's CPU path."""
+    opt = model.optimizer
+    P, V = model.num_points, int(dcolor_all.shape[0])
+    deg = int(model.active_sh_degree)
+    if model.max_sh_degree != 3:
+        raise RuntimeError("the low-rank exchange is written for 16 SH coefficients")
+    if not model.flat.is_cuda:
+        from .sh import sh_basis
+        xyz = model._p["xyz"].detach()
+        grad = torch.zeros(P, 16, 3, dtype=torch.float32)
+        for v in range(V):                                   # view order, as in the kernel
+            dirs = xyz - campos_all[v][None]
+            dirs = dirs / dirs.norm(dim=1, keepdim=True)
+            basis = sh_basis(deg, dirs)                      # (P, (deg+1)^2)
+            grad[:, :basis.shape[1]] += basis[:, :, None] * dcolor_all[v][:, None, :]
+        model._p["f_dc"].grad.copy_(grad[:, :1])
+        model._p["f_rest"].grad.copy_(grad[:, 1:])
+        opt.step(only=SH_BLOCKS, skip=skip, advance=False)
+        return
+    sl = model.block_slices()
+    bc1, bc2 = opt.bias_corrections()
+    b1, b2 = opt.betas
+    m, v = opt.exp_avg, opt.exp_avg_sq
+    (a_dc, _), (a_rest, _) = sl["f_dc"], sl["f_rest"]
+    dev = model.flat.device
+    d_all = dcolor_all.contiguous()
+    cp = campos_all.to(device=dev, dtype=torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        check(lib.w3d_sh_adam_lowrank(P, V, deg, ptr(cp), ptr(model._p["xyz"]), ptr(d_all), ptr(model._p["f_dc"]),
+                                      ptr(model._p["f_rest"]), m.data_ptr() + 4 * a_dc, v.data_ptr() + 4 * a_dc,
+                                      m.data_ptr() + 4 * a_rest, v.data_ptr() + 4 * a_rest, float(opt.lrs["f_dc"]),
+                                      float(opt.lrs["f_rest"]), int("f_dc" in skip), int("f_rest" in skip), float(b1),
+                                      float(b2), float(opt.eps), float(bc1), float(bc2), stream_ptr(dev)))

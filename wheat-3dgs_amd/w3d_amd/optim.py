@@ -71,13 +71,20 @@ class FlatAdam:
         """The backward kernel applied this step's update itself (fused_step.backward_raw_adam)."""
         self.step_count += 1
 
+    def bias_corrections(self):
+        b1, b2 = self.betas
+        return 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
+
     @torch.no_grad()
-    def step(self, zero_grad=False, skip=(), elem_range=None):
+    def step(self, zero_grad=False, skip=(), elem_range=None, only=None, advance=True):
         """One Adam step on every block.  zero_grad=True clears the gradient bucket in the same
         sweep (what `optimizer.zero_grad(set_to_none=True)` achieves at train_vanilla_3dgs.py:115).
         elem_range=(lo, hi): only that slice of the flat buffer is stepped — the shard this rank owns in
-        the view-parallel loop (the other shards arrive through the parameter all-gather)."""
-        self.step_count += 1
+        the dense view-parallel exchange (the other shards arrive through the parameter all-gather).
+        only=names: step just these blocks; advance=False: the step counter was already advanced for this
+        iteration (the low-rank exchange steps the geometry blocks and the SH blocks separately)."""
+        if advance:
+            self.step_count += 1
         b1, b2 = self.betas
         bc1 = 1.0 - b1 ** self.step_count
         bc2 = 1.0 - b2 ** self.step_count
@@ -86,7 +93,7 @@ class FlatAdam:
         for name, (a, b) in self.model.block_slices().items():
             if elem_range is not None:
                 a, b = max(a, elem_range[0]), min(b, elem_range[1])
-            if a < b:
+            if a < b and (only is None or name in only):
                 slices[name] = (a, b)
         if p.is_cuda:
             from .fused import adam_step

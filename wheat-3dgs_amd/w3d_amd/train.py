@@ -64,6 +64,11 @@ class Trainer:
         # single GPU: the optimizer update is applied by the backward kernel itself (fused_step.backward_raw_adam), except
         # in the iterations that densify / reset opacity (there the reference skips the replaced parameters' update)
         self.fused_adam = os.environ.get("W3D_FUSED_ADAM", "1") == "1"
+        # view-parallel exchange of the fused step: "lowrank" ships dL/dRGB (3 floats per Gaussian and view) + the 11
+        # geometry gradients and replicates the optimizer; "dense" reduce-scatters the 59-float bucket, shards Adam and
+        # all-gathers the parameters (also what the autograd step uses)
+        self.exchange_mode = os.environ.get("W3D_EXCHANGE", "lowrank")
+        self._d_all = self._d_work = self._geo_work = None
         self.use_depth_cuts = os.environ.get("W3D_DEPTH_CUTS", "0") == "1"
         self.depth_cuts = {}
         self.cut_misses = 0
@@ -116,6 +121,62 @@ class Trainer:
             self._stat_work = (w1, w2)
             return stats[0], stats[1], r
         return grad2d_norm * visible, visible.to(grad2d_norm.dtype), radii
+
+    def campos_of_all_ranks(self, iteration):
+        """(world, 3) camera centres of the views all ranks render in this iteration (known locally: same camera list,
+        same permutation)."""
+        n = len(self.cameras)
+        cams = [self.cameras[self.perm[((iteration - 1) * self.world + r) % n]] for r in range(self.world)]
+        return torch.stack([c.camera_center.detach().reshape(3).float() for c in cams])
+
+    def exchange_lowrank(self, dcolor, grad2d_norm, visible, radii, tracking=True):
+        """Low-rank exchange of the view-parallel step.  Contract as exchange(): dcolor and the geometry blocks of the
+        gradient bucket hold this view's values scaled by 1/world.  Issues, asynchronously and in this order: the
+        all-gather of the (P,3) colour gradients (the SH update waits for it), the all-reduces (SUM) of the geometry
+        blocks of the bucket — xyz, and opacity|scaling|rotation, which are contiguous — and the statistics.
+        14 floats per Gaussian and view cross the links instead of 59, and nothing is gathered afterwards because every
+        rank applies the identical update (optimizer_step_lowrank).  Returns the reduced statistics."""
+        m = self.model
+        P = m.num_points
+        d_all = torch.empty(self.world, P, 3, dtype=torch.float32, device=dcolor.device)
+        self._d_all = d_all
+        self._d_work = dist.all_gather_into_tensor(d_all.view(-1), dcolor.contiguous().view(-1), async_op=True)
+        sl = m.block_slices()
+        (a0, b0), (a1, _), (_, b1) = sl["xyz"], sl["opacity"], sl["rotation"]
+        assert sl["opacity"][1] == sl["scaling"][0] and sl["scaling"][1] == sl["rotation"][0]
+        self._geo_work = [dist.all_reduce(m.flat_grad[a0:b0], op=dist.ReduceOp.SUM, async_op=True),
+                          dist.all_reduce(m.flat_grad[a1:b1], op=dist.ReduceOp.SUM, async_op=True)]
+        if not tracking:
+            return None, None, None
+        stats = torch.stack([grad2d_norm * visible, visible.to(grad2d_norm.dtype)])
+        w1 = dist.all_reduce(stats, op=dist.ReduceOp.SUM, async_op=True)
+        r = radii.clone()
+        w2 = dist.all_reduce(r, op=dist.ReduceOp.MAX, async_op=True)
+        self._stat_work = (w1, w2)
+        return stats[0], stats[1], r
+
+    def optimizer_step_lowrank(self, iteration, skip):
+        """Replicated optimizer step after exchange_lowrank: SH blocks from the gathered colour gradients (needs the
+        pre-update xyz, so it runs first, while the geometry all-reduces are still in flight), then the geometry blocks
+        from the reduced bucket.  Identical inputs and a fixed view order keep the replicas bit-identical."""
+        from .fused_step import GEO_BLOCKS, sh_adam_lowrank
+        m = self.model
+        m.optimizer.step_count += 1
+        if self._d_work is not None:
+            self._d_work.wait()
+        sh_adam_lowrank(m, self._d_all, self.campos_of_all_ranks(iteration).to(self._d_all.device), skip=skip)
+        for w in self._geo_work or ():
+            w.wait()
+        m.optimizer.step(only=GEO_BLOCKS, skip=skip, advance=False)
+        self._d_all = self._d_work = self._geo_work = None
+
+    def _drain_lowrank(self):
+        """Make the current stream wait for the gradient collectives (before anything may recycle their buffers)."""
+        if self._d_work is not None:
+            self._d_work.wait()
+        for w in self._geo_work or ():
+            w.wait()
+        self._d_work = self._geo_work = None
 
     def wait_stats(self):
         """Make the current stream wait for the statistics all-reduces of exchange()."""
@@ -193,7 +254,7 @@ class Trainer:
         raw-parameter backward writing the flat gradient bucket and — on one GPU — the
         densification statistics.  No autograd graph is built."""
         from .fused import l1_ssim_fwd_bwd
-        from .fused_step import backward_raw, backward_raw_adam, finish, render_raw
+        from .fused_step import backward_raw, backward_raw_adam, backward_raw_lowrank, finish, render_raw
         m, opt = self.model, self.opt
         m.update_learning_rate(iteration)
         if iteration % 1000 == 0:
@@ -208,6 +269,8 @@ class Trainer:
             # per-camera depth cuts from the previous visit (speculative list truncation, verified by finish())
             key = id(cam)
             cut = self.depth_cuts.get(key) if self.use_depth_cuts else None
+            lowrank = (not single) and self.exchange_mode == "lowrank" and m.max_sh_degree == 3
+            dcol = None
             use_adam = (single and self.fused_adam and not self.use_depth_cuts and iteration < opt.iterations and
                         m.max_sh_degree == 3 and not self._structure_change_due(iteration))
             while True:
@@ -217,6 +280,8 @@ class Trainer:
                     dimg.mul_(1.0 / self.world)      # the bucket then holds grad/world: reduce-scatter(SUM) = mean
                 if use_adam:
                     gnorm = backward_raw_adam(m, pkg["handle"], dimg, want_norm=False, update_stats=tracking)
+                elif lowrank:
+                    gnorm, dcol = backward_raw_lowrank(m, pkg["handle"], dimg, want_norm=True)
                 else:
                     gnorm, _ = backward_raw(m, pkg["handle"], dimg, update_stats=fused_stats, want_norm=True)
                 if finish(pkg["handle"]):        # the only host wait of the step, with the backward already queued
@@ -235,13 +300,24 @@ class Trainer:
                 vis = pkg["radii"] > 0
                 if self.world > 1:
                     gnorm = gnorm * float(self.world)           # statistics use the unscaled per-view norm
-                nsum, vcount, rmax = self.exchange(gnorm, vis, pkg["radii"], tracking=tracking)
+                if lowrank:
+                    nsum, vcount, rmax = self.exchange_lowrank(dcol, gnorm, vis, pkg["radii"], tracking=tracking)
+                    if self._structure_change_due(iteration):
+                        self._drain_lowrank()        # densification recycles the gradient bucket
+                else:
+                    nsum, vcount, rmax = self.exchange(gnorm, vis, pkg["radii"], tracking=tracking)
                 self.wait_stats()
             else:
                 nsum = vcount = rmax = None
             skip = self._post_backward(iteration, nsum, vcount, rmax, stats_done=single)
             if use_adam:
                 m.optimizer.note_fused_step()
+            elif lowrank:
+                if iteration < opt.iterations and len(skip) < 6:
+                    self.optimizer_step_lowrank(iteration, skip)
+                else:
+                    # (the reference's step skips every replaced parameter in a densification iteration)
+                    self._drain_lowrank()
             elif iteration < opt.iterations:
                 # the next backward overwrites the whole bucket: no zeroing pass needed
                 self.optimizer_step_and_gather(zero_grad=bool(skip), skip=skip)
