@@ -17,8 +17,9 @@ import numpy as np
 import torch
 from torch import nn
 
-BLOCKS = (("xyz", (3,)), ("f_dc", (1, 3)), ("f_rest", (15, 3)), ("opacity", (1,)), ("scaling", (3,)),
-          ("rotation", (4,)))
+# Order of the blocks inside the flat buffers: the four geometry blocks first (11 contiguous floats per Gaussian: the
+# view-parallel exchange all-reduces exactly that span of the gradient bucket in one collective), then the SH blocks.
+BLOCKS = (("xyz", (3,)), ("opacity", (1,)), ("scaling", (3,)), ("rotation", (4,)), ("f_dc", (1, 3)), ("f_rest", (15, 3)))
 FLOATS_PER_GAUSSIAN = sum(int(np.prod(s)) for _, s in BLOCKS)  # 59
 
 

@@ -132,8 +132,8 @@ class Trainer:
     def exchange_lowrank(self, dcolor, grad2d_norm, visible, radii, tracking=True):
         """Low-rank exchange of the view-parallel step.  Contract as exchange(): dcolor and the geometry blocks of the
         gradient bucket hold this view's values scaled by 1/world.  Issues, asynchronously and in this order: the
-        all-gather of the (P,3) colour gradients (the SH update waits for it), the all-reduces (SUM) of the geometry
-        blocks of the bucket — xyz, and opacity|scaling|rotation, which are contiguous — and the statistics.
+        all-gather of the (P,3) colour gradients (the SH update waits for it), the all-reduce (SUM) of the geometry
+        blocks of the bucket (xyz | opacity | scaling | rotation are one contiguous span) and the statistics.
         14 floats per Gaussian and view cross the links instead of 59, and nothing is gathered afterwards because every
         rank applies the identical update (optimizer_step_lowrank).  Returns the reduced statistics."""
         m = self.model
@@ -142,10 +142,10 @@ class Trainer:
         self._d_all = d_all
         self._d_work = dist.all_gather_into_tensor(d_all.view(-1), dcolor.contiguous().view(-1), async_op=True)
         sl = m.block_slices()
-        (a0, b0), (a1, _), (_, b1) = sl["xyz"], sl["opacity"], sl["rotation"]
-        assert sl["opacity"][1] == sl["scaling"][0] and sl["scaling"][1] == sl["rotation"][0]
-        self._geo_work = [dist.all_reduce(m.flat_grad[a0:b0], op=dist.ReduceOp.SUM, async_op=True),
-                          dist.all_reduce(m.flat_grad[a1:b1], op=dist.ReduceOp.SUM, async_op=True)]
+        a, b = sl["xyz"][0], sl["rotation"][1]                # xyz | opacity | scaling | rotation: one contiguous span
+        assert b - a == 11 * P and sl["xyz"][1] == sl["opacity"][0] and sl["opacity"][1] == sl["scaling"][0] and \
+            sl["scaling"][1] == sl["rotation"][0]
+        self._geo_work = [dist.all_reduce(m.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True)]
         if not tracking:
             return None, None, None
         stats = torch.stack([grad2d_norm * visible, visible.to(grad2d_norm.dtype)])
