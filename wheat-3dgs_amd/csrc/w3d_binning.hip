@@ -481,7 +481,10 @@ tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, u
     }
     if (threadIdx.x == 0) {
         tile_start[T] = carry;
-        if (!append) counters[2] = carry;       // length of the front layer's lists
+        if (!append) {
+            counters[2] = carry;                // length of the front layer's lists
+            counters[8] = 0;                    // tiles whose truncated list ended unsaturated (render_fwd, depth cuts)
+        }
         counters[1] = carry;
     }
 }
@@ -586,8 +589,10 @@ int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, ch
                        reinterpret_cast<uint4 *>(scratch + L.s_rec),
                        reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);
     W3D_LAUNCH_CHECK(v.debug, stream);
-    hipLaunchKernelGGL(layer_split_kernel, dim3(1), dim3(64), 0, stream, counters, L.chunk, (uint32_t)W3D_FRONT_LAYER_256);
-    W3D_LAUNCH_CHECK(v.debug, stream);
+    if (v.depth_layers == 2) {       // chunk ranges of the two depth layers (opt-in layered binning only)
+        hipLaunchKernelGGL(layer_split_kernel, dim3(1), dim3(64), 0, stream, counters, L.chunk, (uint32_t)W3D_FRONT_LAYER_256);
+        W3D_LAUNCH_CHECK(v.debug, stream);
+    }
     return W3D_OK;
 }
 

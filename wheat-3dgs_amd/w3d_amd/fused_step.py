@@ -283,18 +283,23 @@ def backward_raw_lowrank(model, handle, dL_dimage, want_norm=True):
     return gnorm, dcol
 
 
-def sh_adam_lowrank(model, dcolor_all, campos_all, skip=()):
+def sh_adam_lowrank(model, dcolor_all, campos_all, skip=(), rows=None):
     """Adam step of f_dc / f_rest from the colour gradients of ALL views of this iteration (dcolor_all (V,P,3), campos_all
     (V,3)): dL/dSH[k] = sum_v basis_k(normalize(xyz - campos_v)) * dcolor_v, summed in view order.  The optimizer's step
     counter must already be advanced for this iteration.  GPU: csrc sh_adam_lowrank_kernel, in place; CPU (host-logic
     tests): the same formula with torch ops through FlatAdam's CPU path."""
     opt = model.optimizer
     P, V = model.num_points, int(dcolor_all.shape[0])
+    r0, r1 = (0, P) if rows is None else rows          # rows=(r0, r1): dcolor_all holds only these Gaussians
+    n = r1 - r0
+    assert dcolor_all.shape[1] == n
     deg = int(model.active_sh_degree)
     if model.max_sh_degree != 3:
         raise RuntimeError("the low-rank exchange is written for 16 SH coefficients")
     if not model.flat.is_cuda:
         from .sh import sh_basis
+        if rows is not None:
+            raise RuntimeError("row chunks are a GPU-path feature")
         xyz = model._p["xyz"].detach()
         grad = torch.zeros(P, 16, 3, dtype=torch.float32)
         for v in range(V):                                   # view order, as in the kernel
@@ -315,8 +320,10 @@ def sh_adam_lowrank(model, dcolor_all, campos_all, skip=()):
     d_all = dcolor_all.contiguous()
     cp = campos_all.to(device=dev, dtype=torch.float32).contiguous()
     with torch.cuda.device(dev):
-        check(lib.w3d_sh_adam_lowrank(P, V, deg, ptr(cp), ptr(model._p["xyz"]), ptr(d_all), ptr(model._p["f_dc"]),
-                                      ptr(model._p["f_rest"]), m.data_ptr() + 4 * a_dc, v.data_ptr() + 4 * a_dc,
-                                      m.data_ptr() + 4 * a_rest, v.data_ptr() + 4 * a_rest, float(opt.lrs["f_dc"]),
+        check(lib.w3d_sh_adam_lowrank(n, V, deg, ptr(cp), model._p["xyz"].data_ptr() + 12 * r0, ptr(d_all),
+                                      model._p["f_dc"].data_ptr() + 12 * r0, model._p["f_rest"].data_ptr() + 180 * r0,
+                                      m.data_ptr() + 4 * (a_dc + 3 * r0), v.data_ptr() + 4 * (a_dc + 3 * r0),
+                                      m.data_ptr() + 4 * (a_rest + 45 * r0), v.data_ptr() + 4 * (a_rest + 45 * r0),
+                                      float(opt.lrs["f_dc"]),
                                       float(opt.lrs["f_rest"]), int("f_dc" in skip), int("f_rest" in skip), float(b1),
                                       float(b2), float(opt.eps), float(bc1), float(bc2), stream_ptr(dev)))

@@ -68,7 +68,8 @@ class Trainer:
         # geometry gradients and replicates the optimizer; "dense" reduce-scatters the 59-float bucket, shards Adam and
         # all-gathers the parameters (also what the autograd step uses)
         self.exchange_mode = os.environ.get("W3D_EXCHANGE", "lowrank")
-        self._d_all = self._d_work = self._geo_work = None
+        self._d_chunks, self._geo_work = [], None
+        self.lowrank_chunks = None          # row chunks of the colour-gradient all-gather (None: 4 above 256 k Gaussians)
         self.use_depth_cuts = os.environ.get("W3D_DEPTH_CUTS", "0") == "1"
         self.depth_cuts = {}
         self.cut_misses = 0
@@ -138,9 +139,17 @@ class Trainer:
         rank applies the identical update (optimizer_step_lowrank).  Returns the reduced statistics."""
         m = self.model
         P = m.num_points
-        d_all = torch.empty(self.world, P, 3, dtype=torch.float32, device=dcolor.device)
-        self._d_all = d_all
-        self._d_work = dist.all_gather_into_tensor(d_all.view(-1), dcolor.contiguous().view(-1), async_op=True)
+        # the colour gradients travel in a few row chunks, so that the SH update of the first chunk starts while the
+        # later ones (and then the geometry all-reduce) are still on the wire
+        nchunk = self.lowrank_chunks or (4 if (dcolor.is_cuda and P >= (1 << 18)) else 1)
+        step = ((P + nchunk - 1) // nchunk + 255) // 256 * 256
+        dcolor = dcolor.contiguous()
+        self._d_chunks = []
+        for r0 in range(0, P, step):
+            r1 = min(P, r0 + step)
+            d_all = torch.empty(self.world, r1 - r0, 3, dtype=torch.float32, device=dcolor.device)
+            work = dist.all_gather_into_tensor(d_all.view(-1), dcolor[r0:r1].view(-1), async_op=True)
+            self._d_chunks.append([(r0, r1), d_all, work])
         sl = m.block_slices()
         a, b = sl["xyz"][0], sl["rotation"][1]                # xyz | opacity | scaling | rotation: one contiguous span
         assert b - a == 11 * P and sl["xyz"][1] == sl["opacity"][0] and sl["opacity"][1] == sl["scaling"][0] and \
@@ -162,21 +171,26 @@ class Trainer:
         from .fused_step import GEO_BLOCKS, sh_adam_lowrank
         m = self.model
         m.optimizer.step_count += 1
-        if self._d_work is not None:
-            self._d_work.wait()
-        sh_adam_lowrank(m, self._d_all, self.campos_of_all_ranks(iteration).to(self._d_all.device), skip=skip)
+        campos = self.campos_of_all_ranks(iteration).to(m.flat.device)
+        whole = len(self._d_chunks) == 1
+        for rows, d_all, work in self._d_chunks:
+            if work is not None:
+                work.wait()
+            sh_adam_lowrank(m, d_all, campos, skip=skip, rows=None if whole else rows)
         for w in self._geo_work or ():
             w.wait()
         m.optimizer.step(only=GEO_BLOCKS, skip=skip, advance=False)
-        self._d_all = self._d_work = self._geo_work = None
+        self._d_chunks, self._geo_work = [], None
 
     def _drain_lowrank(self):
         """Make the current stream wait for the gradient collectives (before anything may recycle their buffers)."""
-        if self._d_work is not None:
-            self._d_work.wait()
+        for c in self._d_chunks:
+            if c[2] is not None:
+                c[2].wait()
+                c[2] = None
         for w in self._geo_work or ():
             w.wait()
-        self._d_work = self._geo_work = None
+        self._geo_work = None
 
     def wait_stats(self):
         """Make the current stream wait for the statistics all-reduces of exchange()."""
@@ -273,7 +287,11 @@ class Trainer:
             dcol = None
             use_adam = (single and self.fused_adam and not self.use_depth_cuts and iteration < opt.iterations and
                         m.max_sh_degree == 3 and not self._structure_change_due(iteration))
+            attempts = 0
             while True:
+                attempts += 1
+                if attempts > 4:      # one repeat sizes the list buffer exactly; more means the counters are corrupt
+                    raise RuntimeError("fused step: the forward keeps reporting an overflowing list buffer")
                 pkg = render_raw(cam, m, self.bg, sync=False, depth_cut=cut, want_cut=self.use_depth_cuts)
                 loss, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
                 if not single and self.world > 1:
@@ -300,10 +318,17 @@ class Trainer:
                 vis = pkg["radii"] > 0
                 if self.world > 1:
                     gnorm = gnorm * float(self.world)           # statistics use the unscaled per-view norm
+                stepped_early = False
                 if lowrank:
                     nsum, vcount, rmax = self.exchange_lowrank(dcol, gnorm, vis, pkg["radii"], tracking=tracking)
                     if self._structure_change_due(iteration):
                         self._drain_lowrank()        # densification recycles the gradient bucket
+                    elif iteration < opt.iterations:
+                        # ordinary iteration: step BEFORE waiting for the statistics — they are the last collectives in
+                        # the queue, and waiting for them first would serialise the SH update behind the geometry
+                        # all-reduce it is meant to overlap
+                        self.optimizer_step_lowrank(iteration, ())
+                        stepped_early = True
                 else:
                     nsum, vcount, rmax = self.exchange(gnorm, vis, pkg["radii"], tracking=tracking)
                 self.wait_stats()
@@ -313,7 +338,9 @@ class Trainer:
             if use_adam:
                 m.optimizer.note_fused_step()
             elif lowrank:
-                if iteration < opt.iterations and len(skip) < 6:
+                if stepped_early:
+                    assert not skip
+                elif iteration < opt.iterations and len(skip) < 6:
                     self.optimizer_step_lowrank(iteration, skip)
                 else:
                     # (the reference's step skips every replaced parameter in a densification iteration)
