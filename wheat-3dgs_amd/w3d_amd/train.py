@@ -383,10 +383,23 @@ def render_views(model, cameras, background, pipe=None):
     raw = (hasattr(model, "flat") and model.flat.is_cuda and not pipe.convert_SHs_python
            and not pipe.compute_cov3D_python)
     with torch.no_grad():
-        for cam in cameras:
-            if raw:      # pre-activation parameters straight into the kernels (no exp/sigmoid/normalize/cat launches)
-                from .fused_step import render_raw
-                out.append(render_raw(cam, model, background)["render"])
-            else:
-                out.append(render(cam, model, pipe, background)["render"])
+        if not raw:
+            return [render(cam, model, pipe, background)["render"] for cam in cameras]
+        # pre-activation parameters straight into the kernels (no exp/sigmoid/normalize/cat launches), no host round
+        # trip per frame: the list buffer is sized speculatively (fused_step.ListCapacity) and the counters of frame i
+        # are only inspected after frame i+1 has been enqueued; a frame whose buffer was too small is rendered again
+        from .fused_step import finish, render_raw
+        pending = []
+
+        def settle(i, pkg):
+            if not finish(pkg["handle"]):
+                out[i] = render_raw(cameras[i], model, background)["render"]      # synchronous: exact buffer size
+        for i, cam in enumerate(cameras):
+            pkg = render_raw(cam, model, background, sync=False)
+            out.append(pkg["render"])
+            pending.append((i, pkg))
+            if len(pending) > 1:
+                settle(*pending.pop(0))
+        for item in pending:
+            settle(*item)
     return out
