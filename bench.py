@@ -197,6 +197,25 @@ def main():
     elapsed = float(elapsed)
     final_loss = float(trainer.last["loss"])
 
+    # per-stage times, OUTSIDE the timed region (an event pair around every stage costs ~4 % of the step): 20 more steps
+    stage_ms = {}
+    if not args.all_stages:
+        sync()
+        _lib.lib.w3d_profile_enable(b"*")
+        for _ in range(20):
+            it += 1
+            trainer.step(it)
+        sync()
+        _lib.lib.w3d_profile_enable(None)
+        buf2 = ctypes.create_string_buffer(1 << 16)
+        _lib.lib.w3d_profile_collect(buf2, len(buf2))
+        for line in buf2.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            if int(cnt) > 0:
+                stage_ms[name] = round(float(ms) / int(cnt), 4)
+    else:
+        stage_ms = {k: round(ms / c, 4) for k, (c, ms) in stages.items() if c > 0}
+
     # forward-only render throughput (reference render.py's use), same scene, views cycled
     n_r = max(4, min(args.steps, 36))
     render_views(model, cams[:2], bg)
@@ -269,7 +288,17 @@ def main():
                        "step": "fused raw-parameter kernels (no autograd)" if trainer.fused else "drop-in render() + autograd",
                        "final_loss": round(final_loss, 6)},
             "roofline": roof,
+            "stage_ms": stage_ms,
         }
+        # the HBM-bound kernel of the step next to the (VALU-bound) dominant one: per-Gaussian backward + Adam + statistics
+        fused_adam = trainer.fused and trainer.fused_adam and world == 1 and not force_dist
+        if fused_adam and "preprocess_bwd" in stage_ms:
+            b = 6 * 236.0 * P + 104.0 * V          # parameters + both moments read and written; 2-D gradient records read
+            ach = b / (stage_ms["preprocess_bwd"] * 1e-3) / 1e9
+            out["roofline_hbm_kernel"] = {"bound": "hbm", "kernel": "preprocess_bwd+adam", "achieved": round(ach, 1),
+                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                          "traffic": pmc_traffic("preprocess_bwd_kernel"),
+                                          "avg_launch_ms": stage_ms["preprocess_bwd"], "algorithmic_bytes_per_launch": int(b)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         else:
