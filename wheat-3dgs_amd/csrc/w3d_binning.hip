@@ -138,10 +138,10 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
         if (i + 64 < end) { nkey = keys_in[i + 64]; nval = vals_in[i + 64]; }
         const uint32_t d = (key >> shift) & (W3D_RADIX_BINS - 1u);
         // lanes holding the same digit (stable rank = number of such lanes below me)
-        uint64_t peers = __ballot(valid);
+        uint64_t peers = w3d_ballot(valid);
 #pragma unroll
         for (int b = 0; b < W3D_RADIX_BITS; b++) {
-            const uint64_t m = __ballot((d >> b) & 1u);
+            const uint64_t m = w3d_ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
         const uint32_t rank = __popcll(peers & lt);
@@ -278,7 +278,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         const uint32_t kind = ea.w;                               // 0 = lane-parallel, 1 = whole wave (<= 64 tiles), 2 = whole wave (big rect)
         const uint64_t rm = (uint64_t)eb.x | ((uint64_t)eb.y << 32);
         const float depth = __uint_as_float(eb.z);
-        const uint64_t coop = __ballot(lane < nq && kind != 0u);
+        const uint64_t coop = w3d_ballot(lane < nq && kind != 0u);
         auto tile_ok = [&](uint32_t tl, float d) -> bool {
             bool ok = true;
             if (LAYER == 2) ok = open8[tl] != 0;
@@ -294,7 +294,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
 #pragma unroll
             for (int i = 0; i < W3D_WALK_SMALL; i++) {
                 const bool v = m != 0ull;
-                if (__ballot(v) != 0ull) kmax = (uint32_t)i + 1u;
+                if (w3d_ballot(v) != 0ull) kmax = (uint32_t)i + 1u;
                 const uint32_t k = (uint32_t)__ffsll((unsigned long long)m) - 1u;
                 m &= m - 1ull;
                 const uint32_t ty = __umul24(k, magic) >> 16;
@@ -409,7 +409,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
             ea = make_uint4(cur_rec.x, cur_rec.y, (magic << 7) | min(w, 127u), kind);
             eb = make_uint4((uint32_t)rm, (uint32_t)(rm >> 32), cur_rec.w, cur_rec.z);
         }
-        const uint64_t bal = __ballot(relevant);
+        const uint64_t bal = w3d_ballot(relevant);
         if (bal) {
             if (relevant) {
                 const uint32_t slot = (q_head + q_len + (uint32_t)__popcll(bal & lanemask_lt())) & (W3D_WALK_QUEUE - 1u);

@@ -151,6 +151,10 @@ struct W3DRawBwdArgs {
     const w3d_raw_blocks *params_rw;  // ... to these parameter blocks
 };
 
+// wave64 ballot of a predicate.  HIP's __ballot(int) makes the backend materialise the bool as 0/1 in a VGPR and compare it
+// again (v_cndmask + v_cmp per call); the builtin consumes the lane mask the comparison already produced.
+__device__ __forceinline__ uint64_t w3d_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // torch.optim.Adam's element update (no weight decay / amsgrad), shared by the sweep kernel and the fused backward;
 // contraction off so that both compile to the same roundings
 __device__ __forceinline__ void w3d_adam1(float &p, float g, float &m, float &v, float step_size, float b1, float b2,

@@ -146,7 +146,12 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     const uint32_t tx0 = (tile % gx) * W3D_TILE, ty0 = (tile / gx) * W3D_TILE;
     const uint32_t lx = lane & 7, ly = lane >> 3;
     float pxf[4], pyf[4];
-    bool inside[4], done[4];
+    // hi[k]: upper bound of the exponent a pixel still accepts — 0 while it is live, -inf once it is done (saturated or
+    // outside the image).  A float so that "live && power <= 0" is ONE v_cmp whose lane mask feeds the ballot directly
+    // (a bool array would be decoded from a 0/1 VGPR and re-encoded for every ballot).
+    bool inside[4];
+    float hi[4];
+#define W3D_DONE(k) (hi[k] < 0.f)
     float Tr[4], C0[4], C1[4], C2[4], D[4], A[4];
     uint32_t last[4];
     int napplied[4];
@@ -156,7 +161,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         const uint32_t px = tx0 + (k & 1) * 8 + lx, py = ty0 + (k >> 1) * 8 + ly;
         pxf[k] = (float)px; pyf[k] = (float)py;
         inside[k] = (px < (uint32_t)W) && (py < (uint32_t)H);
-        done[k] = !inside[k];
+        hi[k] = inside[k] ? 0.f : -INFINITY;
         Tr[k] = 1.f; C0[k] = C1[k] = C2[k] = D[k] = A[k] = 0.f;
         last[k] = 0; napplied[k] = 0;
         if (LAYER == 2 && inside[k]) {
@@ -165,7 +170,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             C0[k] = out_color[pix]; C1[k] = out_color[HWp + pix]; C2[k] = out_color[2 * HWp + pix];
             D[k] = out_depth[pix]; A[k] = out_alpha[pix];
             Tr[k] = final_T[pix]; last[k] = n_contrib[pix];
-            done[k] = Tr[k] < 0.f;              // a saturated pixel was parked with its sign bit set
+            hi[k] = (Tr[k] < 0.f) ? -INFINITY : 0.f;     // a saturated pixel was parked with its sign bit set
             Tr[k] = fabsf(Tr[k]);
         }
         label[k] = -1;
@@ -197,7 +202,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     uint32_t deepest = 0;        // 1-based position of the deepest entry that changed any pixel's state
     const bool track_cut = (cut_in != nullptr) || (cut_out != nullptr);
     for (uint32_t base = start; base < end; base += 64) {
-        if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
+        if ((w3d_ballot(hi[0] == 0.f) | w3d_ballot(hi[1] == 0.f) | w3d_ballot(hi[2] == 0.f) | w3d_ballot(hi[3] == 0.f)) == 0ull) break;
         const uint32_t n = min(64u, end - base);
         stage_entries(s, lane, n, point_list + base, xy, conic_op, rgbd, (float)tx0, (float)ty0);
         for (uint32_t j = 0; j < n; j++) {
@@ -212,8 +217,9 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 if (!(qm & (1u << k))) continue;
                 const float dx = ea.x - pxf[k], dy = ea.y - pyf[k];
                 const float power = fmaf(ed.z * dy, dy, fmaf(ed.y, dy, ed.x * dx) * dx);      // log2 domain
-                const bool cand = !done[k] && power <= 0.f && power >= ea.z;
-                if (__ballot(cand) == 0ull) continue;   // whole quadrant untouched by this Gaussian
+                // (two ballots of plain compares ANDed as scalars: the ballot of a compound predicate is materialised in a VGPR)
+                if ((w3d_ballot(power <= hi[k]) & w3d_ballot(power >= ea.z)) == 0ull) continue;   // whole quadrant untouched
+                const bool cand = power <= hi[k] && power >= ea.z;
                 const float alpha = fminf(0.99f, ed.w * __builtin_amdgcn_exp2f(power));
                 const float test_T = Tr[k] * (1.f - alpha);
                 const bool ok = cand && alpha >= (1.0f / 255.0f);
@@ -224,12 +230,12 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 D[k] += ec.w * w; A[k] += w;
                 Tr[k] = apply ? test_T : Tr[k];
                 last[k] = apply ? contributor : last[k];
-                done[k] = done[k] || stop;
-                if (LAYER == 0 && track_cut && __ballot(apply || stop) != 0ull) deepest = contributor;
+                hi[k] = stop ? -INFINITY : hi[k];
+                if (LAYER == 0 && track_cut && w3d_ballot(apply || stop) != 0ull) deepest = contributor;
                 if (FLASH) { wk[k] = w; napplied[k] += apply ? 1 : 0; any_applied = any_applied || apply; }
             }
             if (FLASH && gt_mask && used_count) {
-                if (__ballot(any_applied) != 0ull) {
+                if (w3d_ballot(any_applied) != 0ull) {
                     const uint32_t g = __float_as_uint(ea.w);
                     for (int li = 0; li < nlabels; li++) {
                         const int L = s_labels[wv][li];
@@ -248,7 +254,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     const size_t HW = (size_t)H * W;
     if (LAYER == 0 && (cut_in || cut_out)) {
         // speculative list truncation (w3d_view.tile_depth_cut): verify this visit, prepare the next one
-        const bool saturated = __ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull;
+        const bool saturated = (w3d_ballot(hi[0] == 0.f) | w3d_ballot(hi[1] == 0.f) | w3d_ballot(hi[2] == 0.f) | w3d_ballot(hi[3] == 0.f)) == 0ull;
         if (lane == 0) {
             if (cut_out) {
                 float c = __builtin_inff();
@@ -263,7 +269,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         }
     }
     if (LAYER == 1) {
-        const bool open = __ballot(!(done[0] && done[1] && done[2] && done[3])) != 0ull;
+        const bool open = (w3d_ballot(hi[0] == 0.f) | w3d_ballot(hi[1] == 0.f) | w3d_ballot(hi[2] == 0.f) | w3d_ballot(hi[3] == 0.f)) != 0ull;
         if (lane == 0) tile_open[tile] = open ? 1 : 0;
         if (open) {
             // park the running state; saturated pixels carry their "done" flag in the sign of T
@@ -273,7 +279,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                     const size_t pix = (size_t)(uint32_t)pyf[k] * W + (uint32_t)pxf[k];
                     out_color[pix] = C0[k]; out_color[HW + pix] = C1[k]; out_color[2 * HW + pix] = C2[k];
                     out_depth[pix] = D[k]; out_alpha[pix] = A[k];
-                    final_T[pix] = done[k] ? -Tr[k] : Tr[k];
+                    final_T[pix] = W3D_DONE(k) ? -Tr[k] : Tr[k];
                     n_contrib[pix] = last[k];
                 }
             }
@@ -445,13 +451,15 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 if (!(qm & (1u << k))) continue;
                 const float dx = ea.x - (pxb + (float)((k & 1) * 8)), dy = ea.y - (pyb + (float)((k >> 1) * 8));
                 const float power = fmaf(ed.z * dy, dy, fmaf(ed.y, dy, ed.x * dx) * dx);      // log2 domain
+                // (ballots of plain compares, ANDed as scalars — see the forward kernel)
+                const uint64_t mc = w3d_ballot(idx0 < last[k]) & w3d_ballot(power <= 0.f) & w3d_ballot(power >= ea.z);
+                if (mc == 0ull) continue;
                 const bool cand = idx0 < last[k] && power <= 0.f && power >= ea.z;
-                if (__ballot(cand) == 0ull) continue;
                 const float Graw = __builtin_amdgcn_exp2f(power);
                 const float araw = fminf(0.99f, ed.w * Graw);
                 const bool ok = cand && araw >= (1.0f / 255.0f);
-                if (__ballot(ok) == 0ull) continue;
-                any = any || ok;
+                if ((mc & w3d_ballot(araw >= (1.0f / 255.0f))) == 0ull) continue;
+                any = true;                                        // wave-uniform: some lane blends this Gaussian
                 // Branch-free per lane: a lane that does not blend this Gaussian runs the same recurrences
                 // with alpha = G = 0, which leaves T and the suffix accumulators untouched and adds zeros.
                 const float alpha = ok ? araw : 0.f;
@@ -478,7 +486,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 v[5] += G * dL_dalpha;
                 v[6] += dch * dp0[k]; v[7] += dch * dp1[k]; v[8] += dch * dp2[k];
             }
-            if (__ballot(any) == 0ull) continue;
+            if (!any) continue;
             // reduce within the 16-lane rows in registers (4 DPP stages), then one lane per row adds the row sums
             // into this entry's LDS accumulator (4 lanes on one address per ds_add_f32); the batch is flushed
             // below with 4 records per atomic instruction
