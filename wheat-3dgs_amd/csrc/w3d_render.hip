@@ -478,7 +478,11 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 }
                 Tr[k] = Tn;
                 dL_dalpha *= Tn;
-                if (has_bg) dL_dalpha -= (Tfin[k] * inv) * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);
+                if (has_bg) {
+                    // (the empty asm keeps this a scalar branch: if-converted it costs 3 VALU per quadrant on black backgrounds)
+                    asm volatile("" : "+v"(dL_dalpha));
+                    dL_dalpha -= (Tfin[k] * inv) * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);
+                }
                 const float m = ed.w * dL_dalpha * G;      // dL/dG * G
                 const float mx = m * dx, my = m * dy;
                 v[0] += mx; v[1] += my;
