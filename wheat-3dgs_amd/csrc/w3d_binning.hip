@@ -168,16 +168,23 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
 // Depth-ordered packed records {id, rect lo, rect hi, -} + tile mask, so that the (chunk, band) walkers —
 // which re-read their chunk once per band and per pass — stream them coalesced instead of gathering.
 __global__ void __launch_bounds__(256)
-gather_sorted_kernel(const uint32_t *__restrict__ sorted_ids, const uint2 *__restrict__ rect,
-                     const uint2 *__restrict__ tile_mask, const float4 *__restrict__ rgbd,
+gather_sorted_kernel(const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ sorted_keys,
+                     const uint2 *__restrict__ rect, const uint4 *__restrict__ rect_mask,
                      const uint32_t *__restrict__ counters, uint32_t P,
                      uint4 *__restrict__ rec, uint2 *__restrict__ rec_mask, int cull) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= P || s >= counters[0]) return;
     const uint32_t g = sorted_ids[s];
-    const uint2 rc = rect[g];
-    rec[s] = make_uint4(g, rc.x, rc.y, __float_as_uint(rgbd[g].w));     // .w = view depth (for the depth cuts)
-    rec_mask[s] = cull ? tile_mask[g] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    const uint32_t depth_bits = sorted_keys[s];          // the sort key IS the view depth (for the depth cuts): no gather
+    if (cull) {
+        const uint4 b = rect_mask[g];                    // one 16-B record per Gaussian: a single random line
+        rec[s] = make_uint4(g, b.x, b.y, depth_bits);
+        rec_mask[s] = make_uint2(b.z, b.w);
+    } else {
+        const uint2 rc = rect[g];
+        rec[s] = make_uint4(g, rc.x, rc.y, depth_bits);
+        rec_mask[s] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
 }
 
 // LAYER 0: all chunks.  LAYER 1 / 2: front / back depth layer (chunk ranges in counters[4..7], see
@@ -562,7 +569,7 @@ int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, ch
     uint32_t *vals[2] = {reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(scratch + L.s_vals1)};
     uint32_t *hist = reinterpret_cast<uint32_t *>(scratch + L.s_hist);
     uint32_t *rowtot = reinterpret_cast<uint32_t *>(scratch + L.s_rowtot);
-    const uint32_t *sorted_ids = vals[0];
+    const uint32_t *sorted_ids = vals[0], *sorted_keys = keys[0];
     if (L.P == 0) return W3D_OK;
     {
         // ---- stable LSD radix sort of (depth bits, id), PASSES x BITS bits; culled Gaussians carry key 0xFFFFFFFF
@@ -582,10 +589,11 @@ int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, ch
             src ^= 1;
         }
         sorted_ids = vals[src];
+        sorted_keys = keys[src];
     }
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3((L.P + 255) / 256), dim3(256), 0, stream, sorted_ids,
-                       reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint2 *>(state + L.o_tile_mask),
-                       reinterpret_cast<const float4 *>(state + L.o_rgbd), counters, (uint32_t)L.P,
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3((L.P + 255) / 256), dim3(256), 0, stream, sorted_ids, sorted_keys,
+                       reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint4 *>(state + L.o_tile_mask),
+                       counters, (uint32_t)L.P,
                        reinterpret_cast<uint4 *>(scratch + L.s_rec),
                        reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);
     W3D_LAUNCH_CHECK(v.debug, stream);

@@ -37,7 +37,8 @@ struct W3DLayout {
     uint64_t o_rgbd;       // float4[P]  (r,g,b,depth)
     uint64_t o_rect;       // ushort4[P] (minx,miny,maxx,maxy) tile units
     uint64_t o_clamped;    // u8[P] bit c set: SH colour channel c clamped at 0
-    uint64_t o_tile_mask;  // u64[P] bit k: k-th tile of the rect (row-major) is reachable (tile_cull)
+    uint64_t o_tile_mask;  // uint4[P] {rect lo, rect hi, mask lo, mask hi}; mask bit k: k-th tile of the rect (row-major) is
+                           // reachable (tile_cull) — rect and mask in ONE 16-B record so that the depth-order gather reads one line
     uint64_t o_tile_start; // u32[T+1]  (front layer, or the only layer)
     uint64_t o_tile_startB; // u32[T+1] back layer (absolute list positions)
     uint64_t o_tile_open;  // u8[T]     1 = tile still open after the front layer
@@ -82,7 +83,7 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->o_rgbd = o;       o += w3d_align_up(Pp * 16);
     L->o_rect = o;       o += w3d_align_up(Pp * 8);
     L->o_clamped = o;    o += w3d_align_up(Pp);
-    L->o_tile_mask = o;  o += w3d_align_up(Pp * 8);
+    L->o_tile_mask = o;  o += w3d_align_up(Pp * 16);
     L->o_tile_start = o; o += w3d_align_up((T + 1) * 4);
     L->o_tile_startB = o; o += w3d_align_up((T + 1) * 4);
     L->o_tile_open = o;  o += w3d_align_up(T);

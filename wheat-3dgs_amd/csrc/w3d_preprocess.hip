@@ -254,7 +254,7 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
                       int32_t *__restrict__ radii, float2 *__restrict__ xy, float4 *__restrict__ conic_op,
                       float4 *__restrict__ rgbd, ushort4 *__restrict__ rect, uint8_t *__restrict__ clamped_out,
                       uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ counters,
-                      uint2 *__restrict__ tile_mask) {
+                      uint4 *__restrict__ tile_mask) {
 #pragma clang fp contract(off)
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= P) return;
@@ -335,7 +335,8 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
                 const float tau = (opac > 0.f) ? (__logf(255.0f * opac) + 1e-3f) : -1.0f;
                 m = footprint_tile_mask(px, py, conx, cony, conz, tau, minx, miny, maxx, maxy);
             }
-            tile_mask[g] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+            tile_mask[g] = make_uint4((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)maxx | ((uint32_t)maxy << 16), (uint32_t)m,
+                                      (uint32_t)(m >> 32));
         }
         rgbd[g] = make_float4(rgb[0], rgb[1], rgb[2], pv[2]);
         rect[g] = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
@@ -841,7 +842,7 @@ int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *me
         reinterpret_cast<float4 *>(state + L.o_rgbd), reinterpret_cast<ushort4 *>(state + L.o_rect),                 \
         reinterpret_cast<uint8_t *>(state + L.o_clamped), reinterpret_cast<uint32_t *>(scratch + L.s_keys0),         \
         reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(state + L.o_counters),       \
-        reinterpret_cast<uint2 *>(state + L.o_tile_mask)
+        reinterpret_cast<uint4 *>(state + L.o_tile_mask)
     if (f_rest_raw) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(grid), dim3(block), 0, stream, ARGS);
     else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(grid), dim3(block), 0, stream, ARGS);
 #undef ARGS
