@@ -264,6 +264,15 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
     uint32_t key = W3D_INVALID_KEY;
     do {
         float p[3] = {means3D[3 * (size_t)g], means3D[3 * (size_t)g + 1], means3D[3 * (size_t)g + 2]};
+        // scale, rotation and opacity are requested together with the position (one memory latency instead of three
+        // dependent ones; 32 B per Gaussian that the culled ones would not have needed)
+        float s_in[3] = {0.f, 0.f, 0.f};
+        float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
+        if (!cov3D_precomp) {
+            s_in[0] = scales[3 * (size_t)g]; s_in[1] = scales[3 * (size_t)g + 1]; s_in[2] = scales[3 * (size_t)g + 2];
+            q_in = reinterpret_cast<const float4 *>(rotations)[g];
+        }
+        const float op_in = opacities[g];
         float pv[3];
         xform4x3(cam.V, p, pv);
         if (!(pv[2] > W3D_NEAR)) break;   // near cull (also rejects NaN depth)
@@ -276,8 +285,8 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
 #pragma unroll
             for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * (size_t)g + i];
         } else {
-            float s[3] = {scales[3 * (size_t)g], scales[3 * (size_t)g + 1], scales[3 * (size_t)g + 2]};
-            const float4 q4 = reinterpret_cast<const float4 *>(rotations)[g];
+            float s[3] = {s_in[0], s_in[1], s_in[2]};
+            const float4 q4 = q_in;
             float q[4] = {q4.x, q4.y, q4.z, q4.w};
             if (RAW) {
                 s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
@@ -324,7 +333,7 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
         radius = r;
         key = __float_as_uint(pv[2]);
         xy[g] = make_float2(px, py);
-        const float opac = RAW ? act_sigmoid(opacities[g]) : opacities[g];
+        const float opac = RAW ? act_sigmoid(op_in) : op_in;
         conic_op[g] = make_float4(conx, cony, conz, opac);
         if (v.tile_cull) {
             // which tiles of the rect can this Gaussian reach at all?  (rects of > 64 tiles are left whole)
