@@ -409,3 +409,34 @@ def test_fused_adam_backward_equals_separate_adam_sweep():
     assert float((a1[3] - b1[3]).abs().max() / a1[3].abs().max()) <= 2e-4
     d4 = (a4 - b4).abs()
     assert float((d4 > 1e-4).float().mean()) <= 2e-3 and float(d4.max()) <= 0.25
+
+
+def test_flashsplat_raw_fast_path_equals_drop_in_path():
+    """flashsplat_render under no_grad on a flat GaussianModel takes the raw-parameter forward (no activation / cat kernels);
+    with autograd enabled it goes through the drop-in FlashSplatRasterizer.  Same 10-key dict, same integers, same counts."""
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel
+    from w3d_amd.gaussian_renderer import flashsplat_render
+    from w3d_amd.train import PipelineParams
+    dev = torch.device("cuda:0")
+    W, H = 200, 136
+    cam = make_cameras(3, W, H)[1].to(dev)
+    sc = make_scene(5000, seed=21, scale_mean=0.03)
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    m.active_sh_degree = 3
+    bg = torch.tensor([0.2, 0.1, 0.0], device=dev)
+    yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    labels = ((xx // 50) % 3).float()                    # labels 0..2 -> obj_num = 2, rows 0..2
+    slow = flashsplat_render(cam, m, PipelineParams(), bg, gt_mask=labels, obj_num=2)
+    with torch.no_grad():
+        fast = flashsplat_render(cam, m, PipelineParams(), bg, gt_mask=labels, obj_num=2)
+    assert set(fast.keys()) == set(slow.keys())
+    assert torch.equal(fast["radii"], slow["radii"]) and torch.equal(fast["visibility_filter"], slow["visibility_filter"])
+    assert fast["used_count"].shape == (3, m.num_points)
+    assert float((fast["contrib_num"] != slow["contrib_num"]).float().mean()) <= 1e-3
+    for k in ("render", "alpha", "depth", "proj_xy", "gs_depth"):
+        assert float((fast[k] - slow[k]).abs().max()) <= 5e-5 * max(1.0, float(slow[k].abs().max())), k
+    uc_f, uc_s = fast["used_count"], slow["used_count"]
+    assert float((uc_f - uc_s).abs().max() / uc_s.abs().max()) <= 1e-4
+    assert float(uc_s.sum()) > 0

@@ -112,7 +112,7 @@ def finish(handle):
     return handle["num_rendered"] <= handle["capacity"] and handle["suspect_tiles"] == 0
 
 
-def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, depth_cut=None, want_cut=False):
+def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, depth_cut=None, want_cut=False, flash=None):
     """Forward on the raw parameters.  Returns the dict of render() (minus viewspace_points) plus a
     `handle` for backward_raw().  sync=False: no host synchronisation (see ListCapacity); the caller
     must call finish(handle) before trusting the outputs.
@@ -165,8 +165,25 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, depth_cut=
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
         alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        gt_mask = used_count = contrib_num = proj_xy = gs_depth = None
+        num_obj = 0
+        if flash is not None:
+            # FlashSplat outputs (reference gaussian_renderer/__init__.py:194-204): forward only
+            num_obj = int(flash["num_obj"])
+            if num_obj < 1:
+                raise RuntimeError("num_obj must be >= 1")
+            gt_mask = flash.get("gt_mask")
+            if gt_mask is not None:
+                gt_mask = gt_mask.detach().to(device=dev, dtype=torch.float32).contiguous()
+                if tuple(gt_mask.shape[-2:]) != (H, W) or gt_mask.numel() != H * W:
+                    raise RuntimeError("gt_mask must have dimensions (image_height, image_width)")
+            used_count = torch.zeros(num_obj + 1, P, dtype=torch.float32, device=dev)
+            contrib_num = torch.empty(H, W, dtype=torch.int32, device=dev)
+            proj_xy = torch.empty(P, 2, dtype=torch.float32, device=dev)
+            gs_depth = torch.empty(P, dtype=torch.float32, device=dev)
         check(lib.w3d_forward_stage2(ctypes.byref(view.c), P, ptr(state), ptr(scratch), ptr(plist), ctypes.c_uint64(R),
-                                     ptr(color), ptr(depth), ptr(alpha), None, 0, None, None, None, None, stream))
+                                     ptr(color), ptr(depth), ptr(alpha), ptr(gt_mask), num_obj, ptr(used_count),
+                                     ptr(contrib_num), ptr(proj_xy), ptr(gs_depth), stream))
         if guess != 0:
             # counters (offset 0 of the state) travel to pinned memory AFTER the blend so that the depth-cut
             # verdict is included; finish() waits on the event
@@ -177,7 +194,10 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, depth_cut=
             pending = (pinned, ev)
     handle = dict(view=view, P=P, state=state, point_list=plist, radii=radii, num_rendered=R, num_visible=V,
                   capacity=R, pending=pending, depth_cut=depth_cut, depth_cut_out=cut_out, suspect_tiles=0)
-    return {"render": color, "radii": radii, "depth": depth, "alpha": alpha, "handle": handle}
+    out = {"render": color, "radii": radii, "depth": depth, "alpha": alpha, "handle": handle}
+    if flash is not None:
+        out.update(contrib_num=contrib_num, used_count=used_count, proj_xy=proj_xy, gs_depth=gs_depth)
+    return out
 
 
 def backward_raw(model, handle, dL_dimage, dL_ddepth=None, dL_dalpha=None, update_stats=False, want_norm=False,

@@ -56,6 +56,15 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
 def flashsplat_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, gt_mask=None,
                       used_mask=None, unique_label=None, setpdb=False, obj_num=2):
     xyz = pc.get_xyz
+    if (not torch.is_grad_enabled() and used_mask is None and override_color is None and hasattr(pc, "flat") and
+            pc.flat.is_cuda and not pipe.compute_cov3D_python and not pipe.convert_SHs_python and pc.max_sh_degree == 3):
+        # every call site of the reference runs under no_grad (run_3d_seg.py:91,130,362): take the raw-parameter forward —
+        # no exp / sigmoid / normalize launches and no cat of the (P,16,3) features (0.77 GB of traffic at 2 M) per view
+        from .fused_step import render_raw
+        r = render_raw(viewpoint_camera, pc, bg_color, scaling_modifier, flash=dict(gt_mask=gt_mask, num_obj=obj_num))
+        return {"render": r["render"], "viewspace_points": torch.zeros_like(xyz), "visibility_filter": r["radii"] > 0,
+                "radii": r["radii"], "alpha": r["alpha"], "depth": r["depth"], "contrib_num": r["contrib_num"],
+                "used_count": r["used_count"], "proj_xy": r["proj_xy"], "gs_depth": r["gs_depth"]}
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
         screenspace_points.retain_grad()
