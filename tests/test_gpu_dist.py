@@ -35,7 +35,7 @@ def test_exchange_paths_equal_single_gpu_step(one_rank_group):
     for cam in cams:
         cam.original_image = torch.rand(3, H, W, generator=g).to(dev)
     bg = torch.tensor([0.1, 0.1, 0.0], device=dev)
-    sc = make_scene(7000, seed=13, scale_mean=0.02)
+    sc = make_scene(6999, seed=13, scale_mean=0.02)      # odd: the SH blocks are not 16-B aligned (dword fallback paths)
     runs = {}
     for name in ("single", "lowrank", "lowrank3", "dense"):
         m = GaussianModel(3, device=dev)
