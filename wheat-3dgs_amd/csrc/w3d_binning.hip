@@ -245,6 +245,10 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         for (uint32_t t = lane; t < Tb; t += 64) open8[t] = tile_open[tb0 + t];
     if (has_cut)
         for (uint32_t t = lane; t < Tb; t += 64) cut32[t] = depth_cut[tb0 + t];
+    // LAYER 0: the chunks partition the V VISIBLE records evenly (V is only known on the device), not the P slots the
+    // host sized the matrices for — all C chunk-waves of a band get work, each a 1/C-th of it.  (The layered mode keeps
+    // the host's chunk size: its layer boundaries are chunk indices computed from it.)
+    if (LAYER == 0) chunk = min(chunk, max(64u, ((V + C - 1u) / C + 63u) & ~63u));
     const uint32_t s_beg = min(V, c * chunk), s_end = min(V, s_beg + chunk);
     // the first records are requested before the LDS set-up below, which hides their latency; NB 64-record
     // batches are kept in flight (rotating registers, so the loop body — and process() — exists once)
