@@ -27,19 +27,23 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x
 // One pass = histogram, row scan, scatter.  A "run" is the contiguous slice of keys one wave owns.
 __global__ void __launch_bounds__(256)
 radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items, uint32_t n_runs, int shift,
-                  uint32_t *__restrict__ hist /* [256][n_runs] */) {
+                  uint32_t *__restrict__ hist /* [256][n_runs] */, const uint32_t *__restrict__ n_dev, int drop_invalid) {
     __shared__ uint32_t h_all[4][W3D_RADIX_BINS];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
     uint32_t *h = h_all[wv];
     for (int i = lane; i < W3D_RADIX_BINS; i += 64) h[i] = 0;
     __builtin_amdgcn_wave_barrier();
+    // passes after the first sort only the visible Gaussians (the first pass dropped the culled ones and counted the
+    // rest): n comes from the device and the runs re-partition it evenly
+    if (n_dev) { n = *n_dev; items = max(64u, ((n + n_runs - 1u) / n_runs + 63u) & ~63u); }
     if (run < n_runs) {
-        const uint32_t beg = run * items, end = min(n, beg + items);
+        const uint32_t beg = min(n, run * items), end = min(n, beg + items);
 #pragma unroll 8
         for (uint32_t i = beg + lane; i < end; i += 64) {
-            const uint32_t d = (keys[i] >> shift) & (W3D_RADIX_BINS - 1u);
-            atomicAdd(const_cast<uint32_t *>(&h_all[wv][d]), 1u);
+            const uint32_t key = keys[i];
+            const uint32_t d = (key >> shift) & (W3D_RADIX_BINS - 1u);
+            if (!drop_invalid || key != W3D_INVALID_KEY) atomicAdd(const_cast<uint32_t *>(&h_all[wv][d]), 1u);
         }
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < W3D_RADIX_BINS; i += 64) hist[(size_t)i * n_runs + run] = h[i];
@@ -97,11 +101,16 @@ __global__ void __launch_bounds__(256)
 radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                      uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t items,
                      uint32_t n_runs, int shift, const uint32_t *__restrict__ offs /* row-scanned [256][n_runs] */,
-                     const uint32_t *__restrict__ rowtot /* [BINS] */, uint32_t *__restrict__ num_visible) {
+                     const uint32_t *__restrict__ rowtot /* [BINS] */, uint32_t *__restrict__ num_visible,
+                     const uint32_t *__restrict__ n_dev) {
     __shared__ uint32_t cur_all[4][W3D_RADIX_BINS];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
     if (run >= n_runs) return;
+    // num_visible != NULL: FIRST pass — culled Gaussians (key 0xFFFFFFFF) are dropped and the number of survivors is
+    // published; n_dev != NULL: later pass over those survivors only (same re-partition as radix_hist_kernel)
+    const bool drop_invalid = num_visible != nullptr;
+    if (n_dev) { n = *n_dev; items = max(64u, ((n + n_runs - 1u) / n_runs + 63u) & ~63u); }
     uint32_t *cur = cur_all[wv];
     {
         // digit bases = exclusive scan of the row totals, BINS/64 consecutive digits per lane
@@ -114,27 +123,26 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
             tot[i] = t4.x; tot[i + 1] = t4.y; tot[i + 2] = t4.z; tot[i + 3] = t4.w;
             lsum += t4.x + t4.y + t4.z + t4.w;
         }
-        uint32_t base = wave_inclusive_scan(lsum) - lsum;
+        const uint32_t incl = wave_inclusive_scan(lsum);
+        uint32_t base = incl - lsum;
+        if (num_visible && run == 0 && lane == 63) *num_visible = incl;      // all counted keys = the visible Gaussians
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             const uint32_t d = lane * PER + i;
             cur[d] = base + offs[(size_t)d * n_runs + run];
-            // depth keys are positive floats (top bit clear); culled Gaussians carry 0xFFFFFFFF: in the last
-            // pass the base of the first digit with the top key bit set is the number of visible Gaussians.
-            if (num_visible && run == 0 && d == (1u << (31 - W3D_RADIX_BITS * (W3D_RADIX_PASSES - 1)))) *num_visible = base;
             base += tot[i];
         }
     }
     __builtin_amdgcn_wave_barrier();
-    const uint32_t beg = run * items, end = min(n, beg + items);
+    const uint32_t beg = min(n, run * items), end = min(n, beg + items);
     const uint64_t lt = lanemask_lt();
     // software pipeline: the next 64 (key, id) pairs are in flight while the current ones are ranked
     uint32_t nkey = (beg + lane < end) ? keys_in[beg + lane] : 0u;
     uint32_t nval = (beg + lane < end) ? vals_in[beg + lane] : 0u;
     for (uint32_t base = beg; base < end; base += 64) {
         const uint32_t i = base + lane;
-        const bool valid = i < end;
         const uint32_t key = nkey, val = nval;
+        const bool valid = i < end && !(drop_invalid && key == W3D_INVALID_KEY);
         if (i + 64 < end) { nkey = keys_in[i + 64]; nval = vals_in[i + 64]; }
         const uint32_t d = (key >> shift) & (W3D_RADIX_BINS - 1u);
         // lanes holding the same digit (stable rank = number of such lanes below me)
@@ -582,13 +590,16 @@ int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, ch
         W3D_PROF("depth_sort", stream);
         for (int pass = 0; pass < W3D_RADIX_PASSES; pass++) {
             const int shift = W3D_RADIX_BITS * pass;
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], n, L.sort_items, runs, shift, hist);
+            // pass 0 reads all P keys, drops the culled ones and publishes V = counters[0]; passes 1.. sort V keys
+            const uint32_t *n_dev = pass == 0 ? (const uint32_t *)nullptr : counters;
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], n, L.sort_items, runs, shift, hist,
+                               n_dev, pass == 0 ? 1 : 0);
             W3D_LAUNCH_CHECK(v.debug, stream);
             hipLaunchKernelGGL(radix_rowscan_kernel, dim3(W3D_RADIX_BINS), dim3(256), 0, stream, hist, runs, rowtot);
             W3D_LAUNCH_CHECK(v.debug, stream);
             hipLaunchKernelGGL(radix_scatter_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], vals[src], keys[src ^ 1],
                                vals[src ^ 1], n, L.sort_items, runs, shift, hist, rowtot,
-                               pass == W3D_RADIX_PASSES - 1 ? counters : (uint32_t *)nullptr);
+                               pass == 0 ? counters : (uint32_t *)nullptr, n_dev);
             W3D_LAUNCH_CHECK(v.debug, stream);
             src ^= 1;
         }
