@@ -91,7 +91,7 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->o_n_contrib = o;  o += w3d_align_up(HW * 4);
     L->state_bytes = o;
     // radix sort geometry: one wave per contiguous run of sort_items keys
-    uint64_t max_runs = 2048;                    // aim at <= 2048 waves
+    uint64_t max_runs = 1024;                    // one wave per SIMD (measured at P = 2 M: 512 runs 0.216 ms, 1024 0.161, 2048 0.177, 4096 0.214)
     if (const char *e = getenv("W3D_TUNE_SORT_RUNS")) max_runs = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : max_runs;
     uint64_t items = (Pp + max_runs - 1) / max_runs;
     items = (items + 63) / 64 * 64;
