@@ -14,7 +14,11 @@ namespace {
 #define LT 32            // output tile edge (256 threads: 4 output rows per thread)
 #define LH 5             // window half width
 #define LW (LT + 2 * LH) // 42: tile + halo
-#define LSEG 8           // horizontal pass: outputs per thread (18 inputs in registers, sliding window)
+#ifndef LNT
+#define LNT 512          // threads per block (measured: 256 -> 64.5 + 49.9 us, 512 -> 59.0 + 46.1, 1024 -> 68.1 + 47.1)
+#endif
+#define LSEG (LNT == 1024 ? 2 : (LNT == 512 ? 4 : 8))   // horizontal pass: outputs per thread (LSEG + 10 inputs in registers, sliding window)
+#define LROWS (LT * LT / LNT)       // vertical pass: output rows per thread
 
 struct GW11 { float w[11]; };   // window weights, passed by value as a kernel argument
 
@@ -30,27 +34,27 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
     return s;
 }
 
-// Both passes share one shape: a 32x32 output tile per 256-thread block, a 42x42 zero-padded halo tile in LDS,
+// Both passes share one shape: a 32x32 output tile per LNT-thread block, a 42x42 zero-padded halo tile in LDS,
 // rows filtered by 168 threads (42 rows x 4 segments of 8 outputs, the 18 inputs of a segment held in registers),
 // columns filtered by all 256 threads (column = tid % 32, 4 consecutive output rows from 14 row-filtered values).
 // Against one output per thread on a 16x16 tile this reads LDS 3x less and filters 1.7x fewer halo elements.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(LNT)
 ssim_pass_a(int H, int W, const float *__restrict__ img, const float *__restrict__ gt, float *__restrict__ d_mu1,
             float *__restrict__ d_ex2, float *__restrict__ d_exy, float *__restrict__ sums, GW11 gw) {
     __shared__ float sx[LW][LW + 1], sy[LW][LW + 1];
     __shared__ float h[5][LW][LT + 1];
-    __shared__ float red[4];
+    __shared__ float red[LNT / 64];
     const int c = blockIdx.z;
     const size_t plane = (size_t)c * H * W;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
     const int tid = threadIdx.x;
     {
         // all halo loads of the thread are issued before the first LDS store: one memory latency per block, not seven
-        constexpr int NIT = (LW * LW + 255) / 256;
+        constexpr int NIT = (LW * LW + LNT - 1) / LNT;
         float vx[NIT], vy[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            const int i = tid + it * 256;
+            const int i = tid + it * LNT;
             const int ly = i / LW, lx = i - ly * LW;
             const int gy = y0 + ly - LH, gx = x0 + lx - LH;
             const bool in = i < LW * LW && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -59,7 +63,7 @@ ssim_pass_a(int H, int W, const float *__restrict__ img, const float *__restrict
         }
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            const int i = tid + it * 256;
+            const int i = tid + it * LNT;
             const int ly = i / LW, lx = i - ly * LW;
             if (i < LW * LW) { sx[ly][lx] = vx[it]; sy[ly][lx] = vy[it]; }
         }
@@ -85,15 +89,15 @@ ssim_pass_a(int H, int W, const float *__restrict__ img, const float *__restrict
         }
     }
     __syncthreads();
-    const int lx = tid & 31, ry = (tid >> 5) * 4;
-    float acc[5][4];
+    const int lx = tid & 31, ry = (tid >> 5) * LROWS;
+    float acc[5][LROWS];
 #pragma unroll
     for (int q = 0; q < 5; q++) {
-        float hv[14];
+        float hv[LROWS + 10];
 #pragma unroll
-        for (int j = 0; j < 14; j++) hv[j] = h[q][ry + j][lx];
+        for (int j = 0; j < LROWS + 10; j++) hv[j] = h[q][ry + j][lx];
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
+        for (int o = 0; o < LROWS; o++) {
             float t = 0;
 #pragma unroll
             for (int k = 0; k < 11; k++) t += w[k] * hv[o + k];
@@ -104,7 +108,7 @@ ssim_pass_a(int H, int W, const float *__restrict__ img, const float *__restrict
     float l1 = 0.f, sv = 0.f;
     const int gx = x0 + lx;
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
+    for (int o = 0; o < LROWS; o++) {
         const int gy = y0 + ry + o;
         const float mu1 = acc[0][o], mu2 = acc[1][o], ex2 = acc[2][o], ey2 = acc[3][o], exy = acc[4][o];
         const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, m12 = mu1 * mu2;
@@ -132,7 +136,7 @@ ssim_pass_a(int H, int W, const float *__restrict__ img, const float *__restrict
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(LNT)
 ssim_pass_b(int H, int W, const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ d_mu1,
             const float *__restrict__ d_ex2, const float *__restrict__ d_exy, float lambda, float inv_n,
             float *__restrict__ grad, GW11 gw) {
@@ -143,11 +147,11 @@ ssim_pass_b(int H, int W, const float *__restrict__ img, const float *__restrict
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
     const int tid = threadIdx.x;
     {
-        constexpr int NIT = (LW * LW + 255) / 256;
+        constexpr int NIT = (LW * LW + LNT - 1) / LNT;
         float v0[NIT], v1[NIT], v2[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            const int i = tid + it * 256;
+            const int i = tid + it * LNT;
             const int ly = i / LW, lx = i - ly * LW;
             const int gy = y0 + ly - LH, gx = x0 + lx - LH;
             const bool in = i < LW * LW && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -158,7 +162,7 @@ ssim_pass_b(int H, int W, const float *__restrict__ img, const float *__restrict
         }
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            const int i = tid + it * 256;
+            const int i = tid + it * LNT;
             const int ly = i / LW, lx = i - ly * LW;
             if (i < LW * LW) { s[0][ly][lx] = v0[it]; s[1][ly][lx] = v1[it]; s[2][ly][lx] = v2[it]; }
         }
@@ -184,15 +188,15 @@ ssim_pass_b(int H, int W, const float *__restrict__ img, const float *__restrict
         }
     }
     __syncthreads();
-    const int lx = tid & 31, ry = (tid >> 5) * 4;
-    float acc[3][4];
+    const int lx = tid & 31, ry = (tid >> 5) * LROWS;
+    float acc[3][LROWS];
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-        float hv[14];
+        float hv[LROWS + 10];
 #pragma unroll
-        for (int j = 0; j < 14; j++) hv[j] = h[q][ry + j][lx];
+        for (int j = 0; j < LROWS + 10; j++) hv[j] = h[q][ry + j][lx];
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
+        for (int o = 0; o < LROWS; o++) {
             float t = 0;
 #pragma unroll
             for (int k = 0; k < 11; k++) t += w[k] * hv[o + k];
@@ -201,7 +205,7 @@ ssim_pass_b(int H, int W, const float *__restrict__ img, const float *__restrict
     }
     const int gx = x0 + lx;
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
+    for (int o = 0; o < LROWS; o++) {
         const int gy = y0 + ry + o;
         if (gx < W && gy < H) {
             const size_t pix = plane + (size_t)gy * W + gx;
@@ -254,10 +258,10 @@ extern "C" int w3d_l1_ssim_fwd_bwd(int32_t C, int32_t H, int32_t W, const float 
     for (int i = 0; i < 11; i++) gw.w[i] /= sum;
     const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
     const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
-    hipLaunchKernelGGL(ssim_pass_a, grid, dim3(256), 0, stream, H, W, image, gt, d_mu1, d_ex2, d_exy, sums, gw);
+    hipLaunchKernelGGL(ssim_pass_a, grid, dim3(LNT), 0, stream, H, W, image, gt, d_mu1, d_ex2, d_exy, sums, gw);
     W3D_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)(grid.x * grid.y * grid.z), lambda_dssim, inv_n, loss_out);
-    hipLaunchKernelGGL(ssim_pass_b, grid, dim3(256), 0, stream, H, W, image, gt, d_mu1, d_ex2, d_exy, lambda_dssim, inv_n,
+    hipLaunchKernelGGL(ssim_pass_b, grid, dim3(LNT), 0, stream, H, W, image, gt, d_mu1, d_ex2, d_exy, lambda_dssim, inv_n,
                        dL_dimage, gw);
     W3D_HIP_CHECK(hipGetLastError());
     return W3D_OK;
