@@ -35,9 +35,10 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 }
 
 // Both passes share one shape: a 32x32 output tile per LNT-thread block, a 42x42 zero-padded halo tile in LDS,
-// rows filtered by 168 threads (42 rows x 4 segments of 8 outputs, the 18 inputs of a segment held in registers),
-// columns filtered by all 256 threads (column = tid % 32, 4 consecutive output rows from 14 row-filtered values).
-// Against one output per thread on a 16x16 tile this reads LDS 3x less and filters 1.7x fewer halo elements.
+// rows filtered by 42 x (32 / LSEG) threads (each holds the LSEG + 10 inputs of its segment in registers and slides the
+// window over them), columns filtered by all threads (column = tid % 32, LROWS consecutive output rows from LROWS + 10
+// row-filtered values).  Against one output per thread on a 16x16 tile this reads LDS ~3x less and filters 1.7x fewer
+// halo elements; 512 threads per tile put twice the waves behind the same 42 KB of LDS.
 __global__ void __launch_bounds__(LNT)
 ssim_pass_a(int H, int W, const float *__restrict__ img, const float *__restrict__ gt, float *__restrict__ d_mu1,
             float *__restrict__ d_ex2, float *__restrict__ d_exy, float *__restrict__ sums, GW11 gw) {
