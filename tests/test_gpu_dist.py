@@ -123,3 +123,39 @@ def test_densifying_training_under_exchange(one_rank_group, mode):
     assert s0[:first + 1] == s1[:first + 1]
     assert abs(s0[-1] - s1[-1]) <= 0.05 * s0[-1]
     assert abs(np.mean(l0[-10:]) - np.mean(l1[-10:])) <= 0.02
+
+
+@pytest.mark.parametrize("P,deg", [(5000, 3), (3001, 1)])
+def test_sh_adam_lowrank_kernel_three_views_against_torch(P, deg):
+    """sh_adam_lowrank_kernel with several views (what ranks > 1 produce) against the torch formula of the same update on a
+    CPU copy of the model: gradient = sum over views of basis(direction to that view's camera) x dcolor, then Adam."""
+    from w3d_amd.synth import make_scene
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.fused_step import sh_adam_lowrank
+    sc = make_scene(P, seed=31, scale_mean=0.02)
+    g = torch.Generator().manual_seed(3)
+    V = 3
+    dcol = torch.randn(V, P, 3, generator=g) * 1e-2
+    dcol[torch.rand(V, P, generator=g) < 0.4] = 0.0                 # culled in that view
+    campos = torch.randn(V, 3, generator=g) * 3.0 + torch.tensor([0.0, 0.0, 4.0])
+    models = []
+    for dev in ("cpu", "cuda:0"):
+        m = GaussianModel(3, device=dev)
+        m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+        m.active_sh_degree = deg
+        m.training_setup(OptimizationParams())
+        for step in range(2):
+            m.optimizer.step_count += 1
+            sh_adam_lowrank(m, (dcol * (step + 1)).to(dev), campos.to(dev), skip=(("f_dc",) if step == 1 else ()))
+        models.append(m)
+    a, b = models
+    sl = a.block_slices()
+    for name in ("f_dc", "f_rest"):
+        lo, hi = sl[name]
+        assert torch.allclose(b.flat[lo:hi].cpu(), a.flat[lo:hi], rtol=0, atol=3e-7), name
+        assert torch.allclose(b.optimizer.exp_avg[lo:hi].cpu(), a.optimizer.exp_avg[lo:hi], rtol=1e-4, atol=1e-9), name
+        assert torch.allclose(b.optimizer.exp_avg_sq[lo:hi].cpu(), a.optimizer.exp_avg_sq[lo:hi], rtol=2e-4, atol=1e-13), name
+    for name in ("xyz", "opacity", "scaling", "rotation"):          # untouched blocks
+        lo, hi = sl[name]
+        assert torch.equal(b.flat[lo:hi].cpu(), a.flat[lo:hi])
+    assert float(a.optimizer.exp_avg[sl["f_rest"][0]:sl["f_rest"][1]].abs().max()) > 0
