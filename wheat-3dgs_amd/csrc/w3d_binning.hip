@@ -236,11 +236,11 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
     const uint32_t Tbpad = (band_rows * gx + 63u) & ~63u;
     const uint32_t V = counters[0];
     (void)T;
-    // per-wave LDS: [ring 2 x 128 x 16 B][MODE 1: bitmap 8 B x Tbpad][counters / cursors][open bytes][depth cuts]
+    // per-wave LDS: [ring 128 x 24 B][MODE 1: bitmap 8 B x Tbpad][counters / cursors][open bytes][depth cuts]
     unsigned char *base_w = smem + (size_t)wv * wave_bytes;
-    uint4 *qa = reinterpret_cast<uint4 *>(base_w);
-    uint4 *qb = qa + W3D_WALK_QUEUE;
-    unsigned char *p = base_w + 2 * W3D_WALK_QUEUE * sizeof(uint4);
+    uint4 *qa = reinterpret_cast<uint4 *>(base_w);               // raw records {id, rect lo, rect hi, depth}
+    uint2 *qb = reinterpret_cast<uint2 *>(qa + W3D_WALK_QUEUE);   // their tile masks
+    unsigned char *p = base_w + W3D_WALK_QUEUE * (sizeof(uint4) + sizeof(uint2));
     unsigned long long *bm = reinterpret_cast<unsigned long long *>(p);
     if (MODE == 1) p += (size_t)Tbpad * 8;
     uint32_t *h32 = reinterpret_cast<uint32_t *>(p);             // MODE 0: Tbpad/2 words of two u16 counters; MODE 1: cursors
@@ -291,12 +291,31 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
     // bins the first nq (<= 64) queued records
     auto process = [&](uint32_t nq) {
         const uint32_t slot = (q_head + lane) & (W3D_WALK_QUEUE - 1u);
-        uint4 ea = make_uint4(0u, 0u, 1u, 0u), eb = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < nq) { ea = qa[slot]; eb = qb[slot]; }
-        const uint32_t g = ea.x, minx = ea.y & 0xFFFFu, miny = ea.y >> 16, w = ea.z & 0x7Fu, magic = ea.z >> 7;
-        const uint32_t kind = ea.w;                               // 0 = lane-parallel, 1 = whole wave (<= 64 tiles), 2 = whole wave (big rect)
-        const uint64_t rm = (uint64_t)eb.x | ((uint64_t)eb.y << 32);
-        const float depth = __uint_as_float(eb.z);
+        // the ring holds the raw records; everything derived from them is computed HERE, once per queued record, not in
+        // the scan loop where seven of eight lanes would compute it for records that miss the band
+        uint4 er = make_uint4(0u, 0u, 0u, 0u);
+        uint2 em = make_uint2(0u, 0u);
+        if (lane < nq) { er = qa[slot]; em = qb[slot]; }
+        const uint32_t g = er.x, minx = er.y & 0xFFFFu, miny = er.y >> 16, maxx = er.z & 0xFFFFu, maxy = er.z >> 16;
+        const uint32_t w = maxx - minx, nt = w * (maxy - miny);
+        uint64_t rm = 0ull;
+        uint32_t kind = 0u;                                       // 0 = lane-parallel, 1 = whole wave (<= 64 tiles), 2 = whole wave (big rect)
+        if (lane < nq) {
+            if (nt <= 64u) {
+                // bit k: k-th tile of the rect (row-major) can be reached — restricted to the rows of this band
+                const uint32_t k_lo = (max(miny, y0) - miny) * w, k_hi = (min(maxy, y1) - miny) * w;
+                rm = (k_hi >= 64u ? ~0ull : ((1ull << k_hi) - 1ull)) & ~((1ull << k_lo) - 1ull);
+                if (CULL) rm &= (uint64_t)em.x | ((uint64_t)em.y << 32);
+                kind = __popcll(rm) > W3D_WALK_SMALL ? 1u : 0u;
+            } else {
+                kind = 2u;
+            }
+        }
+        // floor(k / w) == (k * magic) >> 16 for k < 64, w <= 64 with magic = floor(65536 / w) + 1; through the float
+        // reciprocal (65536 / w is either an integer, where rcp is exact enough, or >= 1/64 away from one)
+        const uint32_t magic = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)max(w, 1u)) + 0.004f) + 1u;
+        const float depth = __uint_as_float(er.w);
+        const uint4 eb = make_uint4((uint32_t)rm, (uint32_t)(rm >> 32), er.w, er.z);     // (layout the whole-wave part reads)
         const uint64_t coop = w3d_ballot(lane < nq && kind != 0u);
         auto tile_ok = [&](uint32_t tl, float d) -> bool {
             bool ok = true;
@@ -406,33 +425,13 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
 #pragma unroll
         for (int i = 0; i + 1 < NB; i++) { nx_rec[i] = nx_rec[i + 1]; nx_mask[i] = nx_mask[i + 1]; }
         fetch_one(base + 64u * NB, nx_rec[NB - 1], nx_mask[NB - 1]);
-        bool relevant = false;
-        uint4 ea, eb;
-        if (lane < nb) {
-            const uint32_t minx = cur_rec.y & 0xFFFFu, miny = cur_rec.y >> 16, maxx = cur_rec.z & 0xFFFFu, maxy = cur_rec.z >> 16;
-            relevant = miny < y1 && maxy > y0;                   // rect reaches into this band
-            const uint32_t w = maxx - minx, n = w * (maxy - miny);
-            uint64_t rm = ~0ull;
-            uint32_t kind = 2u;
-            if (relevant && n <= 64u) {
-                // bit k: k-th tile of the rect (row-major) can be reached — restricted to the rows of this band
-                const uint32_t k_lo = (max(miny, y0) - miny) * w, k_hi = (min(maxy, y1) - miny) * w;
-                rm = (k_hi >= 64u ? ~0ull : ((1ull << k_hi) - 1ull)) & ~((1ull << k_lo) - 1ull);
-                if (CULL) rm &= (uint64_t)cur_mask.x | ((uint64_t)cur_mask.y << 32);
-                relevant = rm != 0ull;
-                kind = __popcll(rm) > W3D_WALK_SMALL ? 1u : 0u;
-            }
-            // floor(k / w) == (k * magic) >> 16 for k < 64, w <= 64 with magic = floor(65536 / w) + 1; through the float
-            // reciprocal (65536 / w is either an integer, where rcp is exact enough, or >= 1/64 away from one)
-            const uint32_t magic = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)max(w, 1u)) + 0.004f) + 1u;
-            ea = make_uint4(cur_rec.x, cur_rec.y, (magic << 7) | min(w, 127u), kind);
-            eb = make_uint4((uint32_t)rm, (uint32_t)(rm >> 32), cur_rec.w, cur_rec.z);
-        }
+        // rect reaches into this band?  (whether its tile mask does is settled when the record is binned)
+        const bool relevant = lane < nb && (cur_rec.y >> 16) < y1 && (cur_rec.z >> 16) > y0;
         const uint64_t bal = w3d_ballot(relevant);
         if (bal) {
             if (relevant) {
                 const uint32_t slot = (q_head + q_len + (uint32_t)__popcll(bal & lanemask_lt())) & (W3D_WALK_QUEUE - 1u);
-                qa[slot] = ea; qb[slot] = eb;
+                qa[slot] = cur_rec; qb[slot] = cur_mask;
             }
             q_len += (uint32_t)__popcll(bal);
             __builtin_amdgcn_wave_barrier();
@@ -559,7 +558,8 @@ __global__ void copy_ranges_kernel(const uint32_t *__restrict__ tile_start, uint
 struct W3DBands { uint32_t rows, count, tbpad; };
 W3DBands w3d_pick_bands(const W3DLayout &L, int mode) {
     W3DBands b;
-    uint32_t band_tiles = mode == 0 ? 1024u : 512u;  // tiles per band (the fill pass holds 12 B of LDS per tile, the count pass 2 B)
+    uint32_t band_tiles = mode == 0 ? 1024u : 320u;  // tiles per band (the fill pass holds 12 B of LDS per tile, the count pass 2 B;
+                                                     // measured fill at 1600x1200: 200 -> 0.188 ms, 300 -> 0.171, 500 -> 0.179, 700 -> 0.193)
     if (const char *e = getenv(mode == 0 ? "W3D_TUNE_BAND_TILES" : "W3D_TUNE_BAND_TILES_FILL"))
         band_tiles = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : band_tiles;
     uint32_t rows = band_tiles / (uint32_t)L.gx;
@@ -625,7 +625,7 @@ static void launch_walk(const W3DLayout &L, const w3d_view &v, char *state, char
     const W3DBands bands = w3d_pick_bands(L, MODE);
     const dim3 grid(L.C, (bands.count + 3) / 4);
     const float *cut = (LAYER == 0) ? v.tile_depth_cut : nullptr;      // depth cuts only in the single-pass mode
-    const uint32_t wave_bytes = 2u * W3D_WALK_QUEUE * 16u + bands.tbpad * (MODE == 0 ? 2u : 12u) +
+    const uint32_t wave_bytes = W3D_WALK_QUEUE * 24u + bands.tbpad * (MODE == 0 ? 2u : 12u) +
                                 (LAYER == 2 ? bands.tbpad : 0u) + (cut ? bands.tbpad * 4u : 0u);
     const size_t lds = (size_t)wave_bytes * 4;
     const uint4 *rec = reinterpret_cast<const uint4 *>(scratch + L.s_rec);
