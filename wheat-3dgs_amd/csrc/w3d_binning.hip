@@ -327,12 +327,15 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         constexpr uint32_t NONE = 0xFFFFFFFFu;
         uint32_t tls[W3D_WALK_SMALL];
         uint32_t kmax = 0;                                         // wave-uniform: slots [0, kmax) hold a tile for some lane
+#pragma unroll
+        for (int i = 0; i < W3D_WALK_SMALL; i++) tls[i] = NONE;
         {
             uint64_t m = (lane < nq && kind == 0u) ? rm : 0ull;
 #pragma unroll
             for (int i = 0; i < W3D_WALK_SMALL; i++) {
                 const bool v = m != 0ull;
-                if (w3d_ballot(v) != 0ull) kmax = (uint32_t)i + 1u;
+                if (w3d_ballot(v) == 0ull) break;                  // every lane has run out of tiles
+                kmax = (uint32_t)i + 1u;
                 const uint32_t k = (uint32_t)__ffsll((unsigned long long)m) - 1u;
                 m &= m - 1ull;
                 const uint32_t ty = __umul24(k, magic) >> 16;
