@@ -247,6 +247,20 @@ def main():
         f1 = time.perf_counter()
     flash_vps = world * n_f / (f1 - f0)
     del counts
+    # ... and run_3d_seg.py's real loop shape: several object masks per view — one forward, the blend repeated per mask
+    from w3d_amd.gaussian_renderer import flashsplat_render_masks
+    n_m = 8
+    masks = torch.stack([torch.roll(mask, shifts=40 * k, dims=1) for k in range(n_m)])
+    with torch.no_grad():
+        flashsplat_render_masks(cams[0], model, PipelineParams(), bg, masks[:2], obj_num=1)
+        sync()
+        f0 = time.perf_counter()
+        for i in range(4):
+            uc = flashsplat_render_masks(cams[i % len(cams)], model, PipelineParams(), bg, masks, obj_num=1)["used_count"]
+        sync()
+        f1 = time.perf_counter()
+    flash_mps = world * 4 * n_m / (f1 - f0)
+    del uc, masks
 
     if rank == 0:
         ws = [workload_stats(model, cams[i], bg, dev) for i in (0, len(cams) // 2)]
@@ -279,6 +293,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "render_mpix_per_s": round(mpix, 1), "flashsplat_views_per_s": round(flash_vps, 1),
+            "flashsplat_masks_per_s_8_per_view": round(flash_mps, 1),
             "config": {"workload": f"C3: plot-shaped synthetic scene, {P} Gaussians, SH degree 3, "
                                    f"{args.width}x{args.height}, {args.views} overhead cameras, depth+alpha channels",
                        "points": P, "image": [args.width, args.height], "views_per_step": world,

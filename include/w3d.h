@@ -17,6 +17,8 @@
  *        <- simple_knn._C.distCUDA2            reference scene/gaussian_model.py:20,148
  *   w3d_l1_ssim_fwd_bwd (next-row N1)
  *        <- utils/loss_utils.py:17-63 (l1_loss, ssim) as used at train_vanilla_3dgs.py:77-80
+ *   w3d_flash_reblend (next-row N4)
+ *        <- the per-mask inner call of run_3d_seg.py:88-97 / :127-134 (same view, another gt_mask)
  *   w3d_backward_raw_adam (next-row N2, single GPU)
  *        <- train_vanilla_3dgs.py:80 loss.backward() + :113-115 optimizer.step() / zero_grad()
  *   w3d_backward_raw_lowrank, w3d_sh_adam_lowrank (row e, view-parallel exchange)
@@ -139,6 +141,13 @@ int w3d_backward(const w3d_view *view, int32_t P, const float *means3D, const fl
                  const float *dL_dalpha, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors,
                  float *dL_dshs, float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
                  void *scratch, w3d_stream_t stream);
+
+/* FlashSplat's per-mask loop (run_3d_seg.py:88-97 renders the SAME view once per object mask): re-run only the blend on
+ * the state and lists a completed w3d_forward_stage2 of this view left behind, with another label image.  Outputs as in
+ * stage 2 (colour / depth / alpha are rewritten with identical values; used_count must be zeroed by the caller). */
+int w3d_flash_reblend(const w3d_view *view, int32_t P, void *state, const uint32_t *point_list, uint64_t list_capacity,
+                      float *out_color, float *out_depth, float *out_alpha, const float *gt_mask, int32_t num_obj,
+                      float *used_count, int32_t *contrib_num, w3d_stream_t stream);
 
 /* ---- next-row N2 (fused activations): the same two calls on the PRE-ACTIVATION parameters exactly as
  * GaussianModel stores them (reference scene/gaussian_model.py:101-121 applies exp / sigmoid /

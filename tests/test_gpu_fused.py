@@ -441,3 +441,32 @@ def test_flashsplat_raw_fast_path_equals_drop_in_path():
     uc_f, uc_s = fast["used_count"], slow["used_count"]
     assert float((uc_f - uc_s).abs().max() / uc_s.abs().max()) <= 1e-4
     assert float(uc_s.sum()) > 0
+
+
+def test_flashsplat_masks_of_one_view_reuse_the_forward():
+    """flashsplat_render_masks (one forward, the blend repeated per mask) == flashsplat_render called once per mask."""
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel
+    from w3d_amd.gaussian_renderer import flashsplat_render, flashsplat_render_masks
+    from w3d_amd.train import PipelineParams
+    dev = torch.device("cuda:0")
+    W, H = 200, 136
+    cam = make_cameras(3, W, H)[2].to(dev)
+    sc = make_scene(5000, seed=22, scale_mean=0.03)
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    m.active_sh_degree = 3
+    bg = torch.zeros(3, device=dev)
+    yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    masks = torch.stack([(xx < 60).float(), ((xx - 100) ** 2 + (yy - 70) ** 2 < 900).float(), (yy > 100).float()])
+    out = flashsplat_render_masks(cam, m, PipelineParams(), bg, masks, obj_num=1)
+    assert out["used_count"].shape == (3, 2, m.num_points)
+    with torch.no_grad():
+        for k in range(3):
+            ref = flashsplat_render(cam, m, PipelineParams(), bg, gt_mask=masks[k], obj_num=1)
+            err = float((out["used_count"][k] - ref["used_count"]).abs().max() / ref["used_count"].abs().max())
+            assert err <= 1e-5, (k, err)
+            assert torch.equal(out["render"], ref["render"])
+    # every blended weight lands in exactly one of the two rows: the row sum does not depend on the mask
+    tot = out["used_count"].sum(1)
+    assert float((tot[0] - tot[1]).abs().max() / tot[0].abs().max()) <= 1e-5

@@ -205,6 +205,23 @@ int w3d_forward_stage2(const w3d_view *view, int32_t P, void *state, void *scrat
     return W3D_OK;
 }
 
+int w3d_flash_reblend(const w3d_view *view, int32_t P, void *state, const uint32_t *point_list, uint64_t list_capacity,
+                      float *out_color, float *out_depth, float *out_alpha, const float *gt_mask, int32_t num_obj,
+                      float *used_count, int32_t *contrib_num, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    int rc = check_view(view);
+    if (rc) return rc;
+    W3DLayout L;
+    rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
+    if (rc) { w3d_set_error("bad sizes"); return rc; }
+    if (!state || !out_color || !out_depth || !out_alpha) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
+    if (list_capacity > 0 && !point_list) { w3d_set_error("point_list is NULL"); return W3D_ERR_INVALID; }
+    if (gt_mask && used_count && num_obj < 0) { w3d_set_error("num_obj must be >= 0"); return W3D_ERR_INVALID; }
+    if (view->depth_layers == 2 || view->tile_depth_cut) { w3d_set_error("reblend needs the plain single-pass lists"); return W3D_ERR_UNSUPPORTED; }
+    return w3d_launch_render(L, *view, static_cast<char *>(state), point_list, list_capacity, out_color, out_depth, out_alpha,
+                             gt_mask, num_obj, used_count, contrib_num, 0, stream);
+}
+
 int w3d_backward_sizes(int32_t P, uint64_t *scratch_bytes) {
     if (P < 0) { w3d_set_error("P < 0"); return W3D_ERR_INVALID; }
     if (scratch_bytes) *scratch_bytes = w3d_align_up((uint64_t)(P > 0 ? P : 1) * W3D_G2D_STRIDE * sizeof(float));

@@ -48,6 +48,8 @@ lib.w3d_backward_raw_adam.argtypes = [ctypes.POINTER(W3DView), _i32, ctypes.POIN
                                       ctypes.POINTER(W3DAdamFused), ctypes.POINTER(W3DDensifyStats), _vp, _vp]
 lib.w3d_backward_raw_adam.restype = ctypes.c_int
 _BLOCK_ORDER = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+lib.w3d_flash_reblend.argtypes = [ctypes.POINTER(W3DView), _i32, _vp, _vp, ctypes.c_uint64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]
+lib.w3d_flash_reblend.restype = ctypes.c_int
 lib.w3d_backward_raw_lowrank.argtypes = [ctypes.POINTER(W3DView), _i32, ctypes.POINTER(W3DRawParams), _vp, _vp, _vp, _vp, _vp,
                                          ctypes.POINTER(W3DRawGrads), _vp, ctypes.POINTER(W3DDensifyStats), _vp, _vp]
 lib.w3d_backward_raw_lowrank.restype = ctypes.c_int
@@ -347,3 +349,30 @@ def sh_adam_lowrank(model, dcolor_all, campos_all, skip=(), rows=None):
                                       float(opt.lrs["f_dc"]),
                                       float(opt.lrs["f_rest"]), int("f_dc" in skip), int("f_rest" in skip), float(b1),
                                       float(b2), float(opt.eps), float(bc1), float(bc2), stream_ptr(dev)))
+
+
+def flash_reblend(pkg, gt_mask, num_obj):
+    """FlashSplat contribution counts of ANOTHER label image for a view already rendered by render_raw(..., flash=...):
+    only the blend runs again, on the state and per-tile lists of that forward (run_3d_seg.py renders every view once per
+    object mask — preprocessing, depth sort and binning do not depend on the mask).  Returns (used_count (num_obj+1, P),
+    contrib_num (H, W)); pkg["render"] / ["depth"] / ["alpha"] are rewritten with the same values."""
+    h = pkg["handle"]
+    view, P = h["view"], h["P"]
+    color = pkg["render"]
+    dev = color.device
+    H, W = int(color.shape[-2]), int(color.shape[-1])
+    num_obj = int(num_obj)
+    if num_obj < 1:
+        raise RuntimeError("num_obj must be >= 1")
+    if h.get("pending") is not None:
+        raise RuntimeError("finish() the forward before re-blending it")
+    gt = gt_mask.detach().to(device=dev, dtype=torch.float32).contiguous()
+    if tuple(gt.shape[-2:]) != (H, W) or gt.numel() != H * W:
+        raise RuntimeError("gt_mask must have dimensions (image_height, image_width)")
+    used_count = torch.zeros(num_obj + 1, P, dtype=torch.float32, device=dev)
+    contrib_num = torch.empty(H, W, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.w3d_flash_reblend(ctypes.byref(view.c), P, ptr(h["state"]), ptr(h["point_list"]),
+                                    ctypes.c_uint64(h["capacity"]), ptr(color), ptr(pkg["depth"]), ptr(pkg["alpha"]), ptr(gt),
+                                    num_obj, ptr(used_count), ptr(contrib_num), stream_ptr(dev)))
+    return used_count, contrib_num

@@ -94,3 +94,19 @@ def flashsplat_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "alpha": alpha, "depth": depth, "contrib_num": contrib_num, "used_count": used_count,
             "proj_xy": proj_xy, "gs_depth": gs_depth}
+
+
+def flashsplat_render_masks(viewpoint_camera, pc, pipe, bg_color, gt_masks, scaling_modifier=1.0, obj_num=2):
+    """All object masks of ONE view (the inner loop of reference run_3d_seg.py:88-97 calls flashsplat_render once per
+    mask with the same camera): preprocessing, depth sort and binning run once, only the blend is repeated per mask.
+    gt_masks: (K, H, W).  Returns used_count stacked to (K, obj_num+1, P) plus the view's render / alpha / depth."""
+    from .fused_step import flash_reblend, render_raw
+    if not (hasattr(pc, "flat") and pc.flat.is_cuda) or pipe.compute_cov3D_python or pipe.convert_SHs_python:
+        raise RuntimeError("flashsplat_render_masks needs the flat GaussianModel on the GPU and the default pipeline flags")
+    with torch.no_grad():
+        pkg = render_raw(viewpoint_camera, pc, bg_color, scaling_modifier, flash=dict(gt_mask=gt_masks[0], num_obj=obj_num))
+        counts = [pkg["used_count"]]
+        for k in range(1, int(gt_masks.shape[0])):
+            counts.append(flash_reblend(pkg, gt_masks[k], obj_num)[0])
+    return {"used_count": torch.stack(counts), "render": pkg["render"], "alpha": pkg["alpha"], "depth": pkg["depth"],
+            "radii": pkg["radii"], "visibility_filter": pkg["radii"] > 0}
