@@ -227,6 +227,10 @@ int w3d_sh_adam_lowrank(int32_t P, int32_t n_views, int32_t sh_degree, const flo
 
 /* mean squared distance to the 3 nearest other points; points (N,3) -> out (N,) */
 int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream);
+/* The same result (bit for bit) through a uniform grid built on the device: O(N) instead of O(N^2) for the million-point
+ * initialisations of the 2 M-Gaussian configurations.  scratch: w3d_knn_sizes(N) bytes. */
+int w3d_knn_sizes(int32_t N, uint64_t *scratch_bytes);
+int w3d_knn_dist2_grid(int32_t N, const float *points, float *out, void *scratch, w3d_stream_t stream);
 
 /* ---- next-row N1: fused photometric loss 0.8*L1 + 0.2*(1-SSIM) (lambda_dssim = 0.2), value and
  * gradient in one call.  image, gt, dL_dimage: (C,H,W); loss_out: device scalar (overwritten). */

@@ -400,3 +400,37 @@ def test_extreme_shapes_against_oracle(P, W, H, scale):
         if vis.any():
             check_grads(g, gref, vis, f"[{P} {W}x{H} cull={cull}] ", tol=2e-3, bulk_tol=2e-5)
     o.free()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "slab", "clustered", "planar", "duplicates", "line"])
+def test_knn_grid_is_bit_identical_to_brute_force(kind):
+    """w3d_knn_dist2_grid (uniform grid built on the device, ring search) == the brute-force kernel, bit for bit, on point
+    sets that stress the grid: anisotropic boxes, tight clusters far apart, a flat sheet, many exact duplicates, a line."""
+    from w3d_amd.rasterizer import dist2_knn3
+    from oracle.oracle import knn_dist2
+    g = torch.Generator().manual_seed(11)
+    N = 20000
+    if kind == "uniform":
+        pts = torch.rand(N, 3, generator=g)
+    elif kind == "slab":
+        pts = torch.rand(N, 3, generator=g) * torch.tensor([3.0, 1.5, 0.02])
+    elif kind == "clustered":
+        centres = torch.randn(12, 3, generator=g) * 50.0
+        pts = centres[torch.randint(0, 12, (N,), generator=g)] + torch.randn(N, 3, generator=g) * 0.01
+        pts[:5] = torch.randn(5, 3, generator=g) * 500.0          # a few far outliers stretch the bounding box
+    elif kind == "planar":
+        pts = torch.rand(N, 3, generator=g)
+        pts[:, 2] = 0.25
+    elif kind == "duplicates":
+        pts = torch.rand(N // 4, 3, generator=g).repeat(4, 1)
+    else:
+        t = torch.rand(N, 1, generator=g)
+        pts = t * torch.tensor([[1.0, 2.0, -0.5]]) + 3.0
+    pts = pts.float().cuda()
+    a = dist2_knn3(pts, method="brute")
+    b = dist2_knn3(pts, method="grid")
+    assert torch.equal(a, b), f"{kind}: {int((a != b).sum())} of {N} differ, max {float((a - b).abs().max()):.3e}"
+    # ... and the brute-force kernel is the oracle's (small subset check, the oracle is O(N^2) on the CPU)
+    sub = pts[:1500].contiguous()
+    np.testing.assert_array_equal(dist2_knn3(sub, method="grid").cpu().numpy() if sub.shape[0] >= 4096 else
+                                  dist2_knn3(sub, method="brute").cpu().numpy(), knn_dist2(sub.cpu().numpy()))

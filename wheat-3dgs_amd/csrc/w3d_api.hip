@@ -412,6 +412,17 @@ int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t strea
     return w3d_launch_knn(N, points, out, reinterpret_cast<hipStream_t>(stream_));
 }
 
+int w3d_knn_sizes(int32_t N, uint64_t *scratch_bytes) {
+    if (N < 0) { w3d_set_error("bad knn arguments"); return W3D_ERR_INVALID; }
+    if (scratch_bytes) *scratch_bytes = w3d_knn_scratch_bytes(N);
+    return W3D_OK;
+}
+
+int w3d_knn_dist2_grid(int32_t N, const float *points, float *out, void *scratch, w3d_stream_t stream_) {
+    if (N < 0 || (N > 0 && (!points || !out || !scratch))) { w3d_set_error("bad knn arguments"); return W3D_ERR_INVALID; }
+    return w3d_launch_knn_grid(N, points, out, static_cast<char *>(scratch), reinterpret_cast<hipStream_t>(stream_));
+}
+
 int w3d_debug_tile_ranges(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *ranges_out, w3d_stream_t stream_) {
     W3DLayout L;
     int rc = w3d_make_layout(P, H, W, &L);

@@ -191,6 +191,8 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
                                    float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
                                    const struct W3DRawBwdArgs *rawargs, hipStream_t stream);
 int w3d_launch_knn(int32_t N, const float *points, float *out, hipStream_t stream);
+uint64_t w3d_knn_scratch_bytes(int32_t N);
+int w3d_launch_knn_grid(int32_t N, const float *points, float *out, char *scratch, hipStream_t stream);
 int w3d_launch_sh_adam_lowrank(int32_t P, int32_t nviews, int32_t sh_degree, const float *campos_all, const float *xyz,
                                const float *dcolor_all, float *f_dc, float *f_rest, float *m_dc, float *v_dc, float *m_rest,
                                float *v_rest, float lr_dc, float lr_rest, int skip_dc, int skip_rest, float beta1, float beta2,

@@ -1,12 +1,33 @@
 // w3d_knn.hip — mean squared distance to the 3 nearest other points (SURVEY.md Appendix A.7;
 // replaces simple_knn._C.distCUDA2, reference scene/gaussian_model.py:20,148 — a one-shot call
-// at scene initialisation).  Exact brute force: every workgroup stages 256 candidate points in
-// LDS (SoA, broadcast reads) and each lane keeps a branch-free sorted triple of the smallest
-// distances.  Distances are formed with FP contraction off so the result is bit-identical to the
-// CPU oracle's.  O(N^2): fine for SfM-sized initialisations (<= a few 1e5 points).
+// at scene initialisation).  Two exact kernels with bit-identical results:
+//   * brute force (w3d_knn_dist2): every workgroup stages 256 candidate points in LDS (SoA, broadcast reads) and each
+//     lane keeps a branch-free sorted triple of the smallest distances.  O(N^2): 5 ms at 100 k points, 1 s at 2 M.
+//   * uniform grid (w3d_knn_dist2_grid): points are bucketed into ~N/4 cubic cells (bounding box, histogram, scan,
+//     scatter — all on the device, no host round trip); every point then searches the cube of cells around its own,
+//     growing it ring by ring until its third-best distance cannot be beaten from outside the cube.  4.5 ms at 2 M.
+// Distances are formed with FP contraction off and in the same operand order in both (and in the CPU oracle), the three
+// smallest are a property of the point set, so the results agree bit for bit.
 #include "w3d_common.h"
 
 namespace {
+
+__device__ __forceinline__ void best3_insert(float d, float &b0, float &b1, float &b2) {
+    const float t = fmaxf(b0, d);
+    b0 = fminf(b0, d);
+    const float t2 = fmaxf(b1, t);
+    b1 = fminf(b1, t);
+    b2 = fminf(b2, t2);
+}
+
+__device__ __forceinline__ float mean3(int N, float b0, float b1, float b2) {
+    const int n = N - 1 < 3 ? N - 1 : 3;
+    float sum = 0.f;
+    if (n > 0) sum += b0;
+    if (n > 1) sum += b1;
+    if (n > 2) sum += b2;
+    return n > 0 ? sum / 3.0f : 0.f;
+}
 
 __global__ void __launch_bounds__(256)
 knn3_kernel(int N, const float *__restrict__ pts, float *__restrict__ out) {
@@ -26,21 +47,195 @@ knn3_kernel(int N, const float *__restrict__ pts, float *__restrict__ out) {
             const float dx = qx - sx[k], dy = qy - sy[k], dz = qz - sz[k];
             float d = dx * dx + dy * dy + dz * dz;
             d = (base + k == i) ? INFINITY : d;
-            const float t = fmaxf(b0, d);
-            b0 = fminf(b0, d);
-            const float t2 = fmaxf(b1, t);
-            b1 = fminf(b1, t);
-            b2 = fminf(b2, t2);
+            best3_insert(d, b0, b1, b2);
         }
     }
-    if (act) {
-        const int n = N - 1 < 3 ? N - 1 : 3;
-        float sum = 0.f;
-        if (n > 0) sum += b0;
-        if (n > 1) sum += b1;
-        if (n > 2) sum += b2;
-        out[i] = n > 0 ? sum / 3.0f : 0.f;
+    if (act) out[i] = mean3(N, b0, b1, b2);
+}
+
+// ---------------------------------------------------------------------------------------------- uniform grid
+struct KnnGrid {          // header of the scratch buffer, written by knn_bbox_kernel
+    float lo[3], inv_h, h;
+    int32_t n[3], ncells;
+};
+
+__device__ __forceinline__ int cell_coord(float x, float lo, float inv_h, int n) {
+    const int c = (int)((x - lo) * inv_h);
+    return min(n - 1, max(0, c));
+}
+
+// one workgroup: bounding box, cell size for ~4 points per cell, grid dimensions (<= max_cells cells)
+__global__ void __launch_bounds__(1024)
+knn_bbox_kernel(int N, const float *__restrict__ pts, KnnGrid *__restrict__ grid, int max_cells, uint32_t *__restrict__ count) {
+    __shared__ float red[6][16];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = threadIdx.x; i < N; i += 1024)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float v = pts[3 * (size_t)i + a];
+            if (v == v && fabsf(v) != INFINITY) { lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+        }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { red[a][threadIdx.x >> 6] = lo[a]; red[3 + a][threadIdx.x >> 6] = hi[a]; }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ext[3];
+        for (int a = 0; a < 3; a++) {
+            float l = INFINITY, h = -INFINITY;
+            for (int w = 0; w < 16; w++) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+            if (!(l <= h)) { l = 0.f; h = 0.f; }                       // no finite coordinate at all
+            grid->lo[a] = l;
+            ext[a] = fmaxf(h - l, 0.f);
+        }
+        // cell edge: ~4 points per cell if the points filled their box; degenerate (flat) axes get one layer of cells
+        const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
+        float h = emax > 0.f ? emax : 1.f;
+        {
+            float vol = 1.f;
+            int dims = 0;
+            for (int a = 0; a < 3; a++)
+                if (ext[a] > 1e-6f * emax) { vol *= ext[a]; dims++; }
+            if (dims > 0) h = powf(vol * 4.0f / (float)max(N, 1), 1.0f / (float)dims);
+            if (!(h > 0.f) || h != h) h = emax > 0.f ? emax : 1.f;
+        }
+        int n[3];
+        for (;;) {
+            long long total = 1;
+            for (int a = 0; a < 3; a++) {
+                n[a] = (int)fminf(ext[a] / h, 2.0e6f) + 1;
+                total *= n[a];
+            }
+            if (total <= (long long)max_cells) break;
+            h *= 1.26f;                                                  // 2x fewer cells per step
+        }
+        grid->h = h; grid->inv_h = 1.0f / h;
+        grid->n[0] = n[0]; grid->n[1] = n[1]; grid->n[2] = n[2];
+        grid->ncells = n[0] * n[1] * n[2];
+    }
+    (void)count;
+}
+
+__global__ void __launch_bounds__(256)
+knn_zero_kernel(uint32_t *__restrict__ p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+__global__ void __launch_bounds__(256)
+knn_count_kernel(int N, const float *__restrict__ pts, const KnnGrid *__restrict__ grid, uint32_t *__restrict__ cid,
+                 uint32_t *__restrict__ count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const KnnGrid G = *grid;
+    const int cx = cell_coord(pts[3 * (size_t)i], G.lo[0], G.inv_h, G.n[0]);
+    const int cy = cell_coord(pts[3 * (size_t)i + 1], G.lo[1], G.inv_h, G.n[1]);
+    const int cz = cell_coord(pts[3 * (size_t)i + 2], G.lo[2], G.inv_h, G.n[2]);
+    const uint32_t c = (uint32_t)((cz * G.n[1] + cy) * G.n[0] + cx);
+    cid[i] = c;
+    atomicAdd(&count[c], 1u);
+}
+
+// one workgroup: exclusive scan of the cell counts -> start[0 .. ncells]
+__global__ void __launch_bounds__(1024)
+knn_scan_kernel(const KnnGrid *__restrict__ grid, const uint32_t *__restrict__ count, uint32_t *__restrict__ start) {
+    __shared__ uint32_t wtot[17];
+    const int nc = grid->ncells;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (int base = 0; base < nc; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nc ? count[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wtot[wv] = inc;
+        __syncthreads();
+        if (wv == 0) {
+            const uint32_t t = lane < 16 ? wtot[lane] : 0u;
+            uint32_t ti = t;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const uint32_t u = (uint32_t)__shfl_up((int)ti, off, 64);
+                if (lane >= off) ti += u;
+            }
+            if (lane < 16) wtot[lane] = ti - t;
+            if (lane == 15) wtot[16] = ti;
+        }
+        __syncthreads();
+        if (i < nc) start[i] = carry + wtot[wv] + inc - v;
+        carry += wtot[16];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) start[nc] = carry;
+}
+
+__global__ void __launch_bounds__(256)
+knn_scatter_kernel(int N, const float *__restrict__ pts, const uint32_t *__restrict__ cid, const uint32_t *__restrict__ start,
+                   uint32_t *__restrict__ cursor, float4 *__restrict__ sorted) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t c = cid[i];
+    const uint32_t pos = start[c] + atomicAdd(&cursor[c], 1u);
+    sorted[pos] = make_float4(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2], __int_as_float(i));
+}
+
+__global__ void __launch_bounds__(256)
+knn_search_kernel(int N, const float *__restrict__ pts, const KnnGrid *__restrict__ grid, const uint32_t *__restrict__ start,
+                  const float4 *__restrict__ sorted, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const KnnGrid G = *grid;
+    const float qx = pts[3 * (size_t)i], qy = pts[3 * (size_t)i + 1], qz = pts[3 * (size_t)i + 2];
+    const int cx = cell_coord(qx, G.lo[0], G.inv_h, G.n[0]), cy = cell_coord(qy, G.lo[1], G.inv_h, G.n[1]);
+    const int cz = cell_coord(qz, G.lo[2], G.inv_h, G.n[2]);
+    // position inside the grid in cell units, by the very expression that assigned the cells
+    const float ux = (qx - G.lo[0]) * G.inv_h, uy = (qy - G.lo[1]) * G.inv_h, uz = (qz - G.lo[2]) * G.inv_h;
+    float b0 = INFINITY, b1 = INFINITY, b2 = INFINITY;
+    const int rmax = max(G.n[0], max(G.n[1], G.n[2]));
+    for (int r = 0; r <= rmax; r++) {
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, G.n[0] - 1), y0 = max(cy - r, 0), y1 = min(cy + r, G.n[1] - 1);
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, G.n[2] - 1);
+        for (int z = z0; z <= z1; z++)
+            for (int y = y0; y <= y1; y++) {
+                const bool shell_row = (abs(z - cz) == r) || (abs(y - cy) == r);
+                for (int x = x0; x <= x1; x++) {
+                    if (!shell_row && abs(x - cx) != r) continue;       // inside the cube of radius r-1: already visited
+                    const uint32_t c = (uint32_t)((z * G.n[1] + y) * G.n[0] + x);
+                    const uint32_t e = start[c + 1];
+                    for (uint32_t k = start[c]; k < e; k++) {
+                        const float4 s = sorted[k];
+                        const float dx = qx - s.x, dy = qy - s.y, dz = qz - s.z;
+                        float d = dx * dx + dy * dy + dz * dz;
+                        d = (__float_as_int(s.w) == i) ? INFINITY : d;
+                        best3_insert(d, b0, b1, b2);
+                    }
+                }
+            }
+        // every point NOT yet visited lies outside the cube of cells [c-r, c+r]^3 along at least one axis, i.e. at least
+        // `gap` cell edges away along it (faces that coincide with the grid's boundary have nothing behind them)
+        float gap = INFINITY;
+        if (cx - r > 0) gap = fminf(gap, ux - (float)(cx - r));
+        if (cx + r < G.n[0] - 1) gap = fminf(gap, (float)(cx + r + 1) - ux);
+        if (cy - r > 0) gap = fminf(gap, uy - (float)(cy - r));
+        if (cy + r < G.n[1] - 1) gap = fminf(gap, (float)(cy + r + 1) - uy);
+        if (cz - r > 0) gap = fminf(gap, uz - (float)(cz - r));
+        if (cz + r < G.n[2] - 1) gap = fminf(gap, (float)(cz + r + 1) - uz);
+        if (gap == INFINITY) break;                                     // the cube covers the whole grid
+        // 1e-4 relative slack covers the rounding of u, of the cell assignment of the other points and of h itself
+        const float reach = fmaxf(gap, 0.f) * G.h * (1.0f - 1e-4f);
+        if (b2 <= reach * reach) break;
+    }
+    out[i] = mean3(N, b0, b1, b2);
 }
 
 }  // namespace
@@ -48,6 +243,37 @@ knn3_kernel(int N, const float *__restrict__ pts, float *__restrict__ out) {
 int w3d_launch_knn(int32_t N, const float *points, float *out, hipStream_t stream) {
     if (N <= 0) return W3D_OK;
     hipLaunchKernelGGL(knn3_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, N, points, out);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}
+
+// scratch: [header 64 B][cid u32 N][count u32 NC][cursor u32 NC][start u32 NC+1][sorted float4 N], NC = max cells
+static uint64_t knn_max_cells(int32_t N) { return (uint64_t)(N / 4 > 64 ? N / 4 : 64); }
+
+uint64_t w3d_knn_scratch_bytes(int32_t N) {
+    const uint64_t n = (uint64_t)(N > 0 ? N : 1), nc = knn_max_cells(N);
+    return 256 + w3d_align_up(n * 4) + 2 * w3d_align_up(nc * 4) + w3d_align_up((nc + 1) * 4) + w3d_align_up(n * 16);
+}
+
+int w3d_launch_knn_grid(int32_t N, const float *points, float *out, char *scratch, hipStream_t stream) {
+    if (N <= 0) return W3D_OK;
+    const uint64_t n = (uint64_t)N, nc = knn_max_cells(N);
+    KnnGrid *grid = reinterpret_cast<KnnGrid *>(scratch);
+    uint64_t o = 256;
+    uint32_t *cid = reinterpret_cast<uint32_t *>(scratch + o); o += w3d_align_up(n * 4);
+    uint32_t *count = reinterpret_cast<uint32_t *>(scratch + o); o += w3d_align_up(nc * 4);
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(scratch + o); o += w3d_align_up(nc * 4);
+    uint32_t *start = reinterpret_cast<uint32_t *>(scratch + o); o += w3d_align_up((nc + 1) * 4);
+    float4 *sorted = reinterpret_cast<float4 *>(scratch + o);
+    const int blocks = (N + 255) / 256;
+    // count and cursor are adjacent: one launch zeroes both
+    hipLaunchKernelGGL(knn_zero_kernel, dim3((unsigned)((2 * w3d_align_up(nc * 4) / 4 + 255) / 256)), dim3(256), 0, stream, count,
+                       (int)(2 * w3d_align_up(nc * 4) / 4));
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(1), dim3(1024), 0, stream, N, points, grid, (int)nc, count);
+    hipLaunchKernelGGL(knn_count_kernel, dim3(blocks), dim3(256), 0, stream, N, points, grid, cid, count);
+    hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, stream, grid, count, start);
+    hipLaunchKernelGGL(knn_scatter_kernel, dim3(blocks), dim3(256), 0, stream, N, points, cid, start, cursor, sorted);
+    hipLaunchKernelGGL(knn_search_kernel, dim3(blocks), dim3(256), 0, stream, N, points, grid, start, sorted, out);
     W3D_HIP_CHECK(hipGetLastError());
     return W3D_OK;
 }

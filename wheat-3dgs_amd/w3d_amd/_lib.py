@@ -46,10 +46,13 @@ def _load():
     lib.w3d_backward_sizes.argtypes = [i32, ctypes.POINTER(u64)]
     lib.w3d_backward.argtypes = [ctypes.POINTER(W3DView), i32] + [vp] * 7 + [vp, vp] + [vp] * 3 + [vp] * 8 + [vp, vp]
     lib.w3d_knn_dist2.argtypes = [i32, vp, vp, vp]
+    lib.w3d_knn_sizes.argtypes = [i32, ctypes.POINTER(u64)]
+    lib.w3d_knn_dist2_grid.argtypes = [i32, vp, vp, vp, vp]
     lib.w3d_debug_tile_ranges.argtypes = [i32, i32, i32, vp, vp, vp]
     lib.w3d_debug_pixel_state.argtypes = [i32, i32, i32, vp, vp, vp, vp]
     for name in ("w3d_forward_sizes", "w3d_forward_stage1", "w3d_forward_stage2", "w3d_backward_sizes",
-                 "w3d_backward", "w3d_knn_dist2", "w3d_debug_tile_ranges", "w3d_debug_pixel_state"):
+                 "w3d_backward", "w3d_knn_dist2", "w3d_knn_sizes", "w3d_knn_dist2_grid", "w3d_debug_tile_ranges",
+                 "w3d_debug_pixel_state"):
         getattr(lib, name).restype = ctypes.c_int
     return lib
 

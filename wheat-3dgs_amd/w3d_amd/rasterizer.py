@@ -265,16 +265,26 @@ class FlashSplatRasterizer(torch.nn.Module):
         return color, radii, depth, alpha, contrib_num, used_count, proj_xy, gs_depth
 
 
-def dist2_knn3(points: torch.Tensor) -> torch.Tensor:
+KNN_GRID_FROM = 4096      # below this the brute-force kernel is at least as fast
+
+
+def dist2_knn3(points: torch.Tensor, method: str = "auto") -> torch.Tensor:
     """distCUDA2 (reference scene/gaussian_model.py:148): (N,3) fp32 cuda -> (N,) mean squared
     distance to the 3 nearest other points."""
     _require_gpu(points)
     pts = _f32c(points, points.device)
     if pts.dim() != 2 or pts.shape[1] != 3:
         raise RuntimeError("points must have dimensions (num_points, 3)")
-    out = torch.empty(pts.shape[0], dtype=torch.float32, device=pts.device)
+    N = int(pts.shape[0])
+    out = torch.empty(N, dtype=torch.float32, device=pts.device)
     with torch.cuda.device(pts.device):
-        check(lib.w3d_knn_dist2(int(pts.shape[0]), ptr(pts), ptr(out), stream_ptr(pts.device)))
+        if N < KNN_GRID_FROM or method == "brute":
+            check(lib.w3d_knn_dist2(N, ptr(pts), ptr(out), stream_ptr(pts.device)))
+        else:       # same values bit for bit, O(N) through a uniform grid built on the device
+            sb = ctypes.c_uint64()
+            check(lib.w3d_knn_sizes(N, ctypes.byref(sb)))
+            scratch = torch.empty(sb.value, dtype=torch.uint8, device=pts.device)
+            check(lib.w3d_knn_dist2_grid(N, ptr(pts), ptr(out), ptr(scratch), stream_ptr(pts.device)))
     return out
 
 
