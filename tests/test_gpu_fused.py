@@ -470,3 +470,25 @@ def test_flashsplat_masks_of_one_view_reuse_the_forward():
     # every blended weight lands in exactly one of the two rows: the row sum does not depend on the mask
     tot = out["used_count"].sum(1)
     assert float((tot[0] - tot[1]).abs().max() / tot[0].abs().max()) <= 1e-5
+
+
+def test_render_under_no_grad_takes_the_raw_forward_and_matches():
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel
+    from w3d_amd.gaussian_renderer import render
+    from w3d_amd.train import PipelineParams
+    dev = torch.device("cuda:0")
+    cam = make_cameras(3, 176, 120)[0].to(dev)
+    sc = make_scene(4000, seed=23, scale_mean=0.03)
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    m.active_sh_degree = 2
+    bg = torch.tensor([0.3, 0.2, 0.1], device=dev)
+    slow = render(cam, m, PipelineParams(), bg, scaling_modifier=0.9)
+    assert slow["render"].requires_grad
+    with torch.no_grad():
+        fast = render(cam, m, PipelineParams(), bg, scaling_modifier=0.9)
+    assert set(fast.keys()) == set(slow.keys())
+    assert torch.equal(fast["radii"], slow["radii"])
+    for k in ("render", "depth", "alpha"):
+        assert float((fast[k] - slow[k].detach()).abs().max()) <= 5e-5 * max(1.0, float(slow[k].abs().max())), k

@@ -27,6 +27,14 @@ def _settings(cls, cam, pc, bg_color, scaling_modifier, debug, **extra):
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
     xyz = pc.get_xyz
+    if (not torch.is_grad_enabled() and override_color is None and hasattr(pc, "flat") and pc.flat.is_cuda and
+            not pipe.compute_cov3D_python and not pipe.convert_SHs_python and pc.max_sh_degree == 3):
+        # evaluation renders (reference render.py:24-35, eval loops: all under no_grad) on the flat model: the
+        # raw-parameter forward — no exp / sigmoid / normalize launches, no cat of the (P,16,3) features
+        from .fused_step import render_raw
+        r = render_raw(viewpoint_camera, pc, bg_color, scaling_modifier)
+        return {"render": r["render"], "viewspace_points": torch.zeros_like(xyz), "visibility_filter": r["radii"] > 0,
+                "radii": r["radii"], "depth": r["depth"], "alpha": r["alpha"]}
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
         screenspace_points.retain_grad()
