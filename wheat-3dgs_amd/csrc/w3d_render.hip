@@ -135,6 +135,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   const float *__restrict__ cut_in, float *__restrict__ cut_out) {
     __shared__ StagedLDS lds[4];
     __shared__ int s_labels[4][FLASH ? 256 : 1];
+    __shared__ float s_facc[4][FLASH ? 64 * 2 : 1];      // FlashSplat: per-entry weight sums of the current batch, <= 2 labels
     uint32_t tile;
     if (!wave_to_tile(T, tile)) return;
     if (LAYER == 2 && tile_open[tile] == 0) return;
@@ -180,7 +181,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         }
     }
     // distinct labels present in this tile (FlashSplat scatter loops over them)
-    int nlabels = 0;
+    int nlabels = 0, label_a = -1, label_b = -1;      // the first two labels also live in registers
     if (FLASH && gt_mask && used_count) {
         int cur = -1;
         for (;;) {
@@ -191,6 +192,8 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             m = wave_min_i32(m);
             if (m == 0x7fffffff) break;
             if (lane == 0) s_labels[wv][nlabels] = m;
+            if (nlabels == 0) label_a = m;
+            if (nlabels == 1) label_b = m;
             nlabels++;
             cur = m;
         }
@@ -205,6 +208,11 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         if ((w3d_ballot(hi[0] == 0.f) | w3d_ballot(hi[1] == 0.f) | w3d_ballot(hi[2] == 0.f) | w3d_ballot(hi[3] == 0.f)) == 0ull) break;
         const uint32_t n = min(64u, end - base);
         stage_entries(s, lane, n, point_list + base, xy, conic_op, rgbd, (float)tx0, (float)ty0);
+        // FlashSplat scatter, tiles with one or two labels (every tile of a binary mask): the weights of an entry are summed
+        // over each 16-lane row in registers (4 DPP stages), the four row leaders add into the entry's LDS slot, and the
+        // batch is flushed with ONE 64-lane atomic per label instead of one single-lane atomic per entry
+        const bool facc_path = FLASH && gt_mask && used_count && nlabels >= 1 && nlabels <= 2;
+        if (facc_path) { s_facc[wv][2 * lane] = 0.f; s_facc[wv][2 * lane + 1] = 0.f; }
         for (uint32_t j = 0; j < n; j++) {
             const uint32_t qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.q[j]);
             if (qm == 0u) continue;
@@ -235,7 +243,19 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 if (FLASH) { wk[k] = w; napplied[k] += apply ? 1 : 0; any_applied = any_applied || apply; }
             }
             if (FLASH && gt_mask && used_count) {
-                if (w3d_ballot(any_applied) != 0ull) {
+                if (w3d_ballot(any_applied) != 0ull && facc_path) {
+                    for (int li = 0; li < nlabels; li++) {
+                        const int L = (li == 0) ? label_a : label_b;
+                        float part = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) part += (label[k] == L) ? wk[k] : 0.f;
+                        part += dpp_mov<0xB1>(part);
+                        part += dpp_mov<0x4E>(part);
+                        part += dpp_mov<0x141>(part);
+                        part += dpp_mov<0x140>(part);
+                        if ((lane & 15u) == 0u) atomicAdd(&s_facc[wv][2 * j + li], part);
+                    }
+                } else if (w3d_ballot(any_applied) != 0ull) {
                     const uint32_t g = __float_as_uint(ea.w);
                     for (int li = 0; li < nlabels; li++) {
                         const int L = s_labels[wv][li];
@@ -247,6 +267,13 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                     }
                 }
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (facc_path && lane < n) {
+            const uint32_t g = __float_as_uint(s.a[lane].w);
+            const float va = s_facc[wv][2 * lane], vb = s_facc[wv][2 * lane + 1];
+            if (va != 0.f) atomicAdd(&used_count[(size_t)label_a * P + g], va);
+            if (nlabels == 2 && vb != 0.f) atomicAdd(&used_count[(size_t)label_b * P + g], vb);
         }
         __builtin_amdgcn_wave_barrier();
     }
