@@ -492,3 +492,54 @@ def test_render_under_no_grad_takes_the_raw_forward_and_matches():
     assert torch.equal(fast["radii"], slow["radii"])
     for k in ("render", "depth", "alpha"):
         assert float((fast[k] - slow[k].detach()).abs().max()) <= 5e-5 * max(1.0, float(slow[k].abs().max())), k
+
+
+def test_training_recovers_a_perturbed_scene():
+    """End to end: a scene rendered to 8 ground-truth views, its parameters perturbed, 300 fused steps (fused Adam, densification
+    every 50 iterations) — the PSNR must rise by >= 10 dB on the training views and >= 5 dB on a held-out view."""
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.train import Trainer, render_views
+    from util import psnr
+    dev = torch.device("cuda:0")
+    W, H = 320, 240
+    cams = [c.to(dev) for c in make_cameras(9, W, H)]
+    bg = torch.zeros(3, device=dev)
+    sc = make_scene(12000, seed=41, scale_mean=0.02)
+    gt = GaussianModel(3, device=dev)
+    gt.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    gt.active_sh_degree = 3
+    for cam, img in zip(cams, render_views(gt, cams, bg)):
+        cam.original_image = img.clamp(0, 1)
+    g = torch.Generator().manual_seed(5)
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz + 0.01 * torch.randn(sc.xyz.shape, generator=g), sc.features_dc + 0.4 * torch.randn(sc.features_dc.shape, generator=g),
+                          sc.features_rest * 0.0, sc.scaling + 0.15 * torch.randn(sc.scaling.shape, generator=g),
+                          sc.rotation + 0.1 * torch.randn(sc.rotation.shape, generator=g),
+                          sc.opacity + 0.5 * torch.randn(sc.opacity.shape, generator=g))
+    m.active_sh_degree = 3
+
+    class Opt(OptimizationParams):
+        densify_from_iter = 50
+        densification_interval = 50
+        opacity_reset_interval = 100000
+        densify_until_iter = 250
+        position_lr_init = 0.00016 * 5
+    opt = Opt()
+    m.training_setup(opt)
+    train, held_out = cams[:8], cams[8]
+    tr = Trainer(m, train, opt, bg, densify=True, cameras_extent=2.0)
+    assert tr.fused and tr.fused_adam
+
+    def quality():
+        imgs = render_views(m, cams, bg)
+        ps = [psnr(i.clamp(0, 1).cpu().numpy(), c.original_image.cpu().numpy()) for i, c in zip(imgs, cams)]
+        return float(np.mean(ps[:8])), float(ps[8])
+    p_train0, p_held0 = quality()
+    for it in range(1, 301):
+        tr.step(it)
+    p_train1, p_held1 = quality()
+    print(f"PSNR train {p_train0:.2f} -> {p_train1:.2f} dB, held-out {p_held0:.2f} -> {p_held1:.2f} dB, P {sc.xyz.shape[0]} -> {m.num_points}")
+    assert p_train1 >= p_train0 + 10.0, (p_train0, p_train1)      # measured: 19.1 -> 36.9 dB
+    assert p_held1 >= p_held0 + 5.0, (p_held0, p_held1)          # measured: 19.0 -> 27.9 dB
+    assert torch.isfinite(m.flat).all()
