@@ -27,12 +27,12 @@ void w3d_prof_begin(const char *name, hipStream_t stream) {
     ProfRec r;
     r.name = name;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    hipEventRecord(r.a, stream);
+    (void)hipEventRecord(r.a, stream);
     g_prof.push_back(r);
     g_prof_open = true;
 }
 void w3d_prof_end(hipStream_t stream) {
-    if (g_prof_open) hipEventRecord(g_prof.back().b, stream);
+    if (g_prof_open) (void)hipEventRecord(g_prof.back().b, stream);
     g_prof_open = false;
 }
 
@@ -110,8 +110,8 @@ int w3d_profile_collect(char *out, uint64_t cap) {
             agg[r.name].first += 1;
             agg[r.name].second += ms;
         }
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
     std::string txt;
