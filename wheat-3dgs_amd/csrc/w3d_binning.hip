@@ -5,17 +5,17 @@
 // MI355X-first formulation.  Instead of materialising R = sum(tiles touched) 64-bit
 // (tile|depth) keys and radix-sorting all of them through HBM, the order contract
 // "within a tile ascending depth bits, ties by ascending Gaussian index" is met in two steps:
-//   1. ONE stable LSD radix sort of the P (depth bits, index) pairs  — P << R, 16 B per Gaussian;
-//   2. a single-pass stable counting sort of the tile instances by tile id: the Gaussians are
-//      cut into C depth-contiguous chunks, one wave per chunk; a wave keeps a counter for EVERY
-//      tile of the image in LDS (2 B x T in the count pass, 4 B x T in the fill pass — 7500
-//      tiles at 1600x1200 = 15/30 KB per wave, which is what the 160 KB LDS of a CDNA4 CU buys)
-//      and walks its Gaussians in depth order, lanes <-> tiles of the current Gaussian's
-//      rectangle, so every list slot is written exactly once, already in its final position.
+//   1. ONE stable LSD radix sort of the (depth bits, index) pairs — P << R, 16 B per Gaussian; its first pass drops the
+//      culled Gaussians and publishes V, the later passes sort the V survivors;
+//   2. a single-pass stable counting sort of the tile instances by tile id: the depth order is cut into C chunks and the
+//      image into bands of tile rows; one wave per (chunk, band) keeps the band's per-tile counters (count pass) or
+//      cursors + 64-bit rank bitmaps (fill pass) in LDS and bins its records 64 at a time, one record per lane —
+//      the rank of a record among the batch's hits of a tile is a popcount of the tile's bitmap, so every list slot is
+//      written exactly once, already in its final position, without any serial walk (chunk_walk_kernel).
 // HBM traffic: 4 B per tile instance (the list itself) + the C x T counter matrices, instead
-// of >= 6 passes x 24 B per instance.  No atomics on the instance path.
+// of >= 6 passes x 24 B per instance.  No global atomics on the instance path.
 //
-// Everything here is wave-synchronous (wave64): the LDS counters of a wave are private to it,
+// Everything here is wave-synchronous (wave64): the LDS arrays of a wave are private to it,
 // so there is no __syncthreads() in the hot loops.
 #include "w3d_common.h"
 
@@ -163,17 +163,7 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
 }
 
 // ------------------------------------------------------------------------------ tile counting
-// One wave per depth-contiguous chunk.  MODE 0: count (u16 LDS counters, dumps the row of the
-// count matrix).  MODE 1: fill (u32 LDS cursors initialised from the offset matrix; writes list).
-//
-// The walk is serial in the Gaussians of the chunk (that is what makes the counting sort stable)
-// but everything that does not depend on the LDS cursors is hoisted: each lane first derives, for
-// ITS OWN Gaussian of the 64-batch, the rect base tile, width, tile count and a 16.16 reciprocal of
-// the width (so lane -> (tx,ty) is a multiply and a shift, no division in the serial part); the
-// serial loop then only broadcasts those with v_readlane.  Two consecutive Gaussians whose rects
-// hold <= 32 tiles each and do not overlap are handled by ONE iteration (lanes 0-31 / 32-63): with
-// disjoint tiles no ordering question arises between them.
-// Depth-ordered packed records {id, rect lo, rect hi, -} + tile mask, so that the (chunk, band) walkers —
+// Depth-ordered packed records {id, rect lo, rect hi, depth} + tile mask, so that the (chunk, band) walkers —
 // which re-read their chunk once per band and per pass — stream them coalesced instead of gathering.
 __global__ void __launch_bounds__(256)
 gather_sorted_kernel(const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ sorted_keys,
