@@ -545,9 +545,9 @@ __global__ void copy_ranges_kernel(const uint32_t *__restrict__ tile_start, uint
     if (t < T) { out[2 * t] = tile_start[t]; out[2 * t + 1] = tile_start[t + 1]; }
 }
 
-// Bands of tile rows for the chunk walk: each (chunk, band) pair is one wave.  Narrow bands cut the
-// serial work per wave and its LDS footprint (4 waves x Tband x 4 B per workgroup); every band adds a
-// redundant pass over the chunk's 20-B Gaussian records.  Keep the LDS of a workgroup <= 16 KB.
+// Bands of tile rows for the chunk walk: each (chunk, band) pair is one wave.  Narrow bands shrink the wave's LDS
+// footprint (more waves per CU behind the latency of the walk) and the share of a chunk's records that concern it;
+// every band adds a pass over the chunk's 24-B records.
 struct W3DBands { uint32_t rows, count, tbpad; };
 W3DBands w3d_pick_bands(const W3DLayout &L, int mode) {
     W3DBands b;

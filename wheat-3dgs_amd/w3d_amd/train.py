@@ -264,9 +264,10 @@ class Trainer:
 
     def step_fused(self, iteration):
         """The same step with everything between the parameter buffers and the image fused into
-        the HIP kernels (fused_step.py): raw-parameter forward, fused loss value+gradient,
-        raw-parameter backward writing the flat gradient bucket and — on one GPU — the
-        densification statistics.  No autograd graph is built."""
+        the HIP kernels (fused_step.py): raw-parameter forward, fused loss value+gradient, raw-parameter backward.
+        One GPU: the backward applies Adam and the densification statistics itself (backward_raw_adam); iterations that
+        densify / reset opacity write the gradient bucket and step separately.  Several ranks: low-rank or dense
+        exchange (exchange_lowrank / exchange).  No autograd graph is built."""
         from .fused import l1_ssim_fwd_bwd
         from .fused_step import backward_raw, backward_raw_adam, backward_raw_lowrank, finish, render_raw
         m, opt = self.model, self.opt
