@@ -278,9 +278,6 @@ class Trainer:
         with torch.no_grad():
             tracking = iteration < opt.densify_until_iter
             single = self.world == 1 and not self.force_exchange
-            # statistics are updated inside the backward kernel only when the list-capacity guess is known to
-            # hold (synchronous forward); with the speculative forward they are applied after finish()
-            fused_stats = False
             # per-camera depth cuts from the previous visit (speculative list truncation, verified by finish())
             key = id(cam)
             cut = self.depth_cuts.get(key) if self.use_depth_cuts else None
@@ -302,7 +299,8 @@ class Trainer:
                 elif lowrank:
                     gnorm, dcol = backward_raw_lowrank(m, pkg["handle"], dimg, want_norm=True)
                 else:
-                    gnorm, _ = backward_raw(m, pkg["handle"], dimg, update_stats=fused_stats, want_norm=True)
+                    # (statistics of this flavour are applied on the host after finish(): the forward was speculative)
+                    gnorm, _ = backward_raw(m, pkg["handle"], dimg, update_stats=False, want_norm=True)
                 if finish(pkg["handle"]):        # the only host wait of the step, with the backward already queued
                     break                        # (on overflow the fused-Adam kernel updated nothing: repeat the view)
                 if pkg["handle"]["suspect_tiles"]:
