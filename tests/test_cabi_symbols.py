@@ -61,3 +61,30 @@ def test_product_path_has_no_cpu_fallback():
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".sh")):
                 assert "oracle" not in open(os.path.join(dp, f)).read().replace("oracle's", "").replace("CPU oracle", ""), f
+
+
+def test_host_side_validation_of_the_training_step_entry_points():
+    """Argument errors of the newer entry points are reported before anything touches the device."""
+    from w3d_amd import _lib
+    lib = _lib.lib
+    i32, u64, vp, f = ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_float
+    lib.w3d_knn_dist2_grid.argtypes = [i32, vp, vp, vp, vp]
+    sb = u64()
+    assert lib.w3d_knn_sizes(2_000_000, ctypes.byref(sb)) == 0 and sb.value > 2_000_000 * 20
+    assert lib.w3d_knn_sizes(-1, ctypes.byref(sb)) != 0
+    assert lib.w3d_knn_dist2_grid(0, None, None, None, None) == 0            # nothing to do
+    assert lib.w3d_knn_dist2_grid(10, None, None, None, None) != 0 and b"knn" in lib.w3d_last_error()
+    lib.w3d_densify_compact.argtypes = [i32, ctypes.POINTER(i32), i32, i32, u64, u64, u64, u64] + [vp] * 10
+    dims = (i32 * 6)(3, 1, 3, 4, 3, 45)
+    assert lib.w3d_densify_compact(6, dims, 0, 2, 10, 0, 0, 0, *([None] * 10)) == 0          # P_new = 0: nothing to do
+    assert lib.w3d_densify_compact(9, dims, 0, 2, 10, 5, 5, 5, *([None] * 10)) != 0          # > 8 blocks
+    assert b"blocks" in lib.w3d_last_error()
+    assert lib.w3d_densify_compact(6, dims, 0, 2, 10, 5, 6, 5, *([None] * 10)) != 0          # NULL buffers / bad counts
+    lib.w3d_sh_adam_lowrank.argtypes = [i32, i32, i32] + [vp] * 9 + [f, f, i32, i32] + [f] * 5 + [vp]
+    args = [None] * 9 + [0.1, 0.1, 0, 0, 0.9, 0.999, 1e-15, 0.1, 0.001, None]
+    assert lib.w3d_sh_adam_lowrank(0, 2, 3, *args) == 0                                      # P = 0: nothing to do
+    assert lib.w3d_sh_adam_lowrank(10, 2, 4, *args) != 0 and b"sizes" in lib.w3d_last_error()  # degree 4 unsupported
+    assert lib.w3d_sh_adam_lowrank(10, 2, 3, *args) != 0 and b"NULL" in lib.w3d_last_error()
+    lib.w3d_adam_step.argtypes = [u64, vp, vp, vp, vp, f, f, f, f, f, f, i32, vp]
+    assert lib.w3d_adam_step(0, None, None, None, None, 0.1, 0.9, 0.999, 1e-15, 0.1, 0.001, 0, None) == 0
+    assert lib.w3d_adam_step(8, None, None, None, None, 0.1, 0.9, 0.999, 1e-15, 0.1, 0.001, 0, None) != 0
