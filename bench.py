@@ -260,7 +260,18 @@ def main():
         sync()
         f1 = time.perf_counter()
     flash_mps = world * 4 * n_m / (f1 - f0)
-    del uc, masks
+    # non-overlapping instance masks (8 vertical stripes): one blend over the merged label map
+    stripes = torch.stack([((xx >= k * args.width // n_m) & (xx < (k + 1) * args.width // n_m)).float() for k in range(n_m)])
+    with torch.no_grad():
+        flashsplat_render_masks(cams[0], model, PipelineParams(), bg, stripes, obj_num=1)
+        sync()
+        f0 = time.perf_counter()
+        for i in range(4):
+            uc = flashsplat_render_masks(cams[i % len(cams)], model, PipelineParams(), bg, stripes, obj_num=1)["used_count"]
+        sync()
+        f1 = time.perf_counter()
+    flash_mps_disjoint = world * 4 * n_m / (f1 - f0)
+    del uc, masks, stripes
 
     if rank == 0:
         ws = [workload_stats(model, cams[i], bg, dev) for i in (0, len(cams) // 2)]
@@ -294,6 +305,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "render_mpix_per_s": round(mpix, 1), "flashsplat_views_per_s": round(flash_vps, 1),
             "flashsplat_masks_per_s_8_per_view": round(flash_mps, 1),
+            "flashsplat_masks_per_s_8_disjoint_per_view": round(flash_mps_disjoint, 1),
             "config": {"workload": f"C3: plot-shaped synthetic scene, {P} Gaussians, SH degree 3, "
                                    f"{args.width}x{args.height}, {args.views} overhead cameras, depth+alpha channels",
                        "points": P, "image": [args.width, args.height], "views_per_step": world,

@@ -459,8 +459,14 @@ def test_flashsplat_masks_of_one_view_reuse_the_forward():
     bg = torch.zeros(3, device=dev)
     yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
     masks = torch.stack([(xx < 60).float(), ((xx - 100) ** 2 + (yy - 70) ** 2 < 900).float(), (yy > 100).float()])
+    # masks 0 and 1 overlap nowhere, mask 2 overlaps both: first the general path (one blend per mask) ...
     out = flashsplat_render_masks(cam, m, PipelineParams(), bg, masks, obj_num=1)
     assert out["used_count"].shape == (3, 2, m.num_points)
+    # ... then the disjoint pair through the single merged-label blend
+    pair = flashsplat_render_masks(cam, m, PipelineParams(), bg, masks[:2], obj_num=1)
+    assert pair["used_count"].shape == (2, 2, m.num_points)
+    err = float((pair["used_count"] - out["used_count"][:2]).abs().max() / out["used_count"].abs().max())
+    assert err <= 1e-5, err
     with torch.no_grad():
         for k in range(3):
             ref = flashsplat_render(cam, m, PipelineParams(), bg, gt_mask=masks[k], obj_num=1)

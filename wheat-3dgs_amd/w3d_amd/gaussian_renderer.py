@@ -107,14 +107,29 @@ def flashsplat_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0
 def flashsplat_render_masks(viewpoint_camera, pc, pipe, bg_color, gt_masks, scaling_modifier=1.0, obj_num=2):
     """All object masks of ONE view (the inner loop of reference run_3d_seg.py:88-97 calls flashsplat_render once per
     mask with the same camera): preprocessing, depth sort and binning run once, only the blend is repeated per mask.
-    gt_masks: (K, H, W).  Returns used_count stacked to (K, obj_num+1, P) plus the view's render / alpha / depth."""
+    gt_masks: (K, H, W).  Returns used_count stacked to (K, obj_num+1, P) plus the view's render / alpha / depth.
+    Non-overlapping binary masks take a single blend over their merged label map."""
     from .fused_step import flash_reblend, render_raw
     if not (hasattr(pc, "flat") and pc.flat.is_cuda) or pipe.compute_cov3D_python or pipe.convert_SHs_python:
         raise RuntimeError("flashsplat_render_masks needs the flat GaussianModel on the GPU and the default pipeline flags")
+    K = int(gt_masks.shape[0])
     with torch.no_grad():
-        pkg = render_raw(viewpoint_camera, pc, bg_color, scaling_modifier, flash=dict(gt_mask=gt_masks[0], num_obj=obj_num))
-        counts = [pkg["used_count"]]
-        for k in range(1, int(gt_masks.shape[0])):
-            counts.append(flash_reblend(pkg, gt_masks[k], obj_num)[0])
-    return {"used_count": torch.stack(counts), "render": pkg["render"], "alpha": pkg["alpha"], "depth": pkg["depth"],
+        binary = gt_masks.to(torch.float32)
+        inside = binary > 0
+        # binary masks that do not overlap (instance masks of one image): ONE blend over the merged label map gives every
+        # mask's row 1 directly and its row 0 as (total - row 1)
+        if obj_num == 1 and K > 1 and bool(((binary == 0) | (binary == 1)).all()) and int(inside.sum(0).max()) <= 1:
+            labels = (inside * torch.arange(1, K + 1, device=binary.device, dtype=torch.float32)[:, None, None]).sum(0)
+            pkg = render_raw(viewpoint_camera, pc, bg_color, scaling_modifier, flash=dict(gt_mask=labels, num_obj=K))
+            multi = pkg["used_count"]                        # (K + 1, P): row 0 = unlabelled pixels, row k = mask k - 1
+            total = multi.sum(0, keepdim=True)
+            ones = multi[1:]
+            used = torch.stack([total - ones, ones], dim=1)  # (K, 2, P)
+        else:
+            pkg = render_raw(viewpoint_camera, pc, bg_color, scaling_modifier, flash=dict(gt_mask=gt_masks[0], num_obj=obj_num))
+            counts = [pkg["used_count"]]
+            for k in range(1, K):
+                counts.append(flash_reblend(pkg, gt_masks[k], obj_num)[0])
+            used = torch.stack(counts)
+    return {"used_count": used, "render": pkg["render"], "alpha": pkg["alpha"], "depth": pkg["depth"],
             "radii": pkg["radii"], "visibility_filter": pkg["radii"] > 0}
