@@ -375,6 +375,9 @@ class Trainer:
         return loss.detach()
 
 
+RENDER_STREAMS = int(os.environ.get("W3D_RENDER_STREAMS", "2"))
+
+
 def render_views(model, cameras, background, pipe=None):
     """Forward-only rendering of a list of views (what reference render.py:24-35 times)."""
     pipe = pipe or PipelineParams()
@@ -389,16 +392,29 @@ def render_views(model, cameras, background, pipe=None):
         # are only inspected after frame i+1 has been enqueued; a frame whose buffer was too small is rendered again
         from .fused_step import finish, render_raw
         pending = []
+        # consecutive frames go to alternating streams: sort and binning are latency-bound kernels that leave most of the
+        # chip idle, so two independent frames in flight overlap them (frames do not depend on each other)
+        main = torch.cuda.current_stream(model.flat.device)
+        streams = [torch.cuda.Stream(device=model.flat.device) for _ in range(RENDER_STREAMS)] if RENDER_STREAMS > 1 else [main]
+        for st in streams:
+            st.wait_stream(main)
 
         def settle(i, pkg):
             if not finish(pkg["handle"]):
-                out[i] = render_raw(cameras[i], model, background)["render"]      # synchronous: exact buffer size
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    out[i] = render_raw(cameras[i], model, background)["render"]      # synchronous: exact buffer size
         for i, cam in enumerate(cameras):
-            pkg = render_raw(cam, model, background, sync=False)
+            with torch.cuda.stream(streams[i % len(streams)]):
+                pkg = render_raw(cam, model, background, sync=False)
             out.append(pkg["render"])
             pending.append((i, pkg))
-            if len(pending) > 1:
+            if len(pending) > len(streams):
                 settle(*pending.pop(0))
         for item in pending:
             settle(*item)
+        for st in streams:
+            main.wait_stream(st)
+        if len(streams) > 1:
+            for img in out:
+                img.record_stream(main)
     return out
