@@ -219,6 +219,12 @@ int w3d_backward_raw_lowrank(const w3d_view *view, int32_t P, const w3d_raw_para
                              const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth,
                              const float *dL_dalpha, const w3d_raw_grads *grads, float *dcolor_out,
                              const w3d_densify_stats *stats, void *scratch, w3d_stream_t stream);
+/* The same backward in two calls, so that the all-gather of dcolor_out can be issued between them and travel while the
+ * per-Gaussian backward runs: w3d_backward_blend_dcolor = blend backward + dcolor_out; then w3d_backward_raw_lowrank with
+ * dL_dcolor = NULL (blend already done into the same scratch) and dcolor_out = NULL. */
+int w3d_backward_blend_dcolor(const w3d_view *view, int32_t P, const void *state, const uint32_t *point_list,
+                              const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha, float *dcolor_out,
+                              void *scratch, w3d_stream_t stream);
 int w3d_sh_adam_lowrank(int32_t P, int32_t n_views, int32_t sh_degree, const float *campos_all, const float *xyz,
                         const float *dcolor_all, float *f_dc, float *f_rest, float *exp_avg_dc, float *exp_avg_sq_dc,
                         float *exp_avg_rest, float *exp_avg_sq_rest, float lr_dc, float lr_rest, int32_t skip_dc,

@@ -37,7 +37,7 @@ def test_exchange_paths_equal_single_gpu_step(one_rank_group):
     bg = torch.tensor([0.1, 0.1, 0.0], device=dev)
     sc = make_scene(6999, seed=13, scale_mean=0.02)      # odd: the SH blocks are not 16-B aligned (dword fallback paths)
     runs = {}
-    for name in ("single", "lowrank", "lowrank3", "dense"):
+    for name in ("single", "lowrank", "lowrank3", "lowrank_early", "dense"):
         m = GaussianModel(3, device=dev)
         m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
         m.active_sh_degree = 2
@@ -45,8 +45,9 @@ def test_exchange_paths_equal_single_gpu_step(one_rank_group):
         m.training_setup(opt)
         tr = Trainer(m, cams, opt, bg, densify=False, force_exchange=(name != "single"))
         tr.fused_adam = False
-        tr.exchange_mode = name.rstrip("3")
+        tr.exchange_mode = "lowrank" if name.startswith("lowrank") else name
         tr.lowrank_chunks = 3 if name == "lowrank3" else None      # colour gradients gathered in 3 row chunks
+        tr.early_gather = name == "lowrank_early"                  # ... issued between the two halves of the backward
         tr.step(1)
         one = (m.flat.clone(), m.optimizer.exp_avg.clone(), m.optimizer.exp_avg_sq.clone(), m.xyz_gradient_accum.clone(),
                m.denom.clone(), m.max_radii2D.clone())
@@ -57,7 +58,7 @@ def test_exchange_paths_equal_single_gpu_step(one_rank_group):
             tr.gather_moments()
         runs[name] = (one, m.flat.clone(), m)
     ref1, ref4, mref = runs["single"]
-    for name in ("lowrank", "lowrank3", "dense"):
+    for name in ("lowrank", "lowrank3", "lowrank_early", "dense"):
         one, four, m = runs[name]
         for k, tol in ((1, 2e-4), (2, 4e-4)):           # moments after one step are (1-b1) g and (1-b2) g^2
             for blk, (lo, hi) in m.block_slices().items():

@@ -370,8 +370,10 @@ int w3d_backward_raw_lowrank(const w3d_view *view, int32_t P, const w3d_raw_para
     rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
     if (rc) { w3d_set_error("bad sizes"); return rc; }
     if (P == 0) return W3D_OK;
-    if (!state || !scratch || !dL_dcolor || !prm || !grads || !grads->xyz || !grads->opacity || !grads->scaling ||
-        !grads->rotation || !dcolor_out) {
+    // dL_dcolor == NULL: the blend backward of this view already ran into `scratch` (w3d_backward_blend_dcolor); then
+    // dcolor_out may be NULL as well
+    if (!state || !scratch || !prm || !grads || !grads->xyz || !grads->opacity || !grads->scaling || !grads->rotation ||
+        (dL_dcolor && !dcolor_out)) {
         w3d_set_error("NULL buffer");
         return W3D_ERR_INVALID;
     }
@@ -381,14 +383,34 @@ int w3d_backward_raw_lowrank(const w3d_view *view, int32_t P, const w3d_raw_para
     }
     const char *st = static_cast<const char *>(state);
     float *grad2d = static_cast<float *>(scratch);
-    rc = w3d_launch_render_backward(L, *view, st, point_list, dL_dcolor, dL_ddepth, dL_dalpha, grad2d, stream);
-    if (rc) return rc;
+    if (dL_dcolor) {
+        rc = w3d_launch_render_backward(L, *view, st, point_list, dL_dcolor, dL_ddepth, dL_dalpha, grad2d, stream);
+        if (rc) return rc;
+    }
     W3DRawBwdArgs ra = {};
-    ra.f_rest = prm->f_rest; ra.opacity_logit = prm->opacity; ra.dcolor_out = dcolor_out;
+    ra.f_rest = prm->f_rest; ra.opacity_logit = prm->opacity; ra.dcolor_out = dcolor_out; ra.lowrank = 1;
     if (stats) { ra.gnorm_out = stats->grad2d_norm; ra.radii = stats->radii; }
     return w3d_launch_preprocess_backward(L, *view, prm->xyz, prm->f_dc, nullptr, prm->scaling, prm->rotation, nullptr, st,
                                           grad2d, grads->xyz, stats ? stats->dL_dmeans2D : nullptr, nullptr, nullptr,
                                           grads->opacity, grads->scaling, grads->rotation, nullptr, &ra, stream);
+}
+
+int w3d_backward_blend_dcolor(const w3d_view *view, int32_t P, const void *state, const uint32_t *point_list,
+                              const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha, float *dcolor_out,
+                              void *scratch, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    int rc = check_view(view);
+    if (rc) return rc;
+    W3DLayout L;
+    rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
+    if (rc) { w3d_set_error("bad sizes"); return rc; }
+    if (P == 0) return W3D_OK;
+    if (!state || !scratch || !dL_dcolor || !dcolor_out) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
+    const char *st = static_cast<const char *>(state);
+    float *grad2d = static_cast<float *>(scratch);
+    rc = w3d_launch_render_backward(L, *view, st, point_list, dL_dcolor, dL_ddepth, dL_dalpha, grad2d, stream);
+    if (rc) return rc;
+    return w3d_launch_dcolor_extract(L, st, grad2d, dcolor_out, stream);
 }
 
 int w3d_sh_adam_lowrank(int32_t P, int32_t n_views, int32_t sh_degree, const float *campos_all, const float *xyz,

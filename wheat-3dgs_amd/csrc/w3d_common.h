@@ -147,7 +147,8 @@ struct W3DRawBwdArgs {
     float *dL_df_rest, *gnorm_out;
     const int32_t *radii;
     float *accum, *denom, *max_radii;
-    float *dcolor_out;                // non-NULL: write the (P,3) clamp-masked dL/dRGB instead of the SH gradient blocks
+    int lowrank;                      // view-parallel flavour: geometry gradients only, the SH gradient stays implicit in dL/dRGB
+    float *dcolor_out;                // ... which is written here as (P,3) (NULL: already extracted by w3d_launch_dcolor_extract)
     const w3d_adam_fused *adam;       // non-NULL: apply Adam in place instead of writing gradients
     const w3d_raw_blocks *params_rw;  // ... to these parameter blocks
 };
@@ -193,6 +194,7 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
 int w3d_launch_knn(int32_t N, const float *points, float *out, hipStream_t stream);
 uint64_t w3d_knn_scratch_bytes(int32_t N);
 int w3d_launch_knn_grid(int32_t N, const float *points, float *out, char *scratch, hipStream_t stream);
+int w3d_launch_dcolor_extract(const W3DLayout &L, const char *state, const float *grad2d, float *dcolor_out, hipStream_t stream);
 int w3d_launch_sh_adam_lowrank(int32_t P, int32_t nviews, int32_t sh_degree, const float *campos_all, const float *xyz,
                                const float *dcolor_all, float *f_dc, float *f_rest, float *m_dc, float *v_dc, float *m_rest,
                                float *v_rest, float lr_dc, float lr_rest, int skip_dc, int skip_rest, float beta1, float beta2,

@@ -747,7 +747,7 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
         if (!(raw.skip_mask & 32u)) coop_adam<4, 1>(raw, 5, g0, rows, sh_stage, 15, 7);
         return;
     }
-    if (MODE == 2) {
+    if (MODE == 2 && raw.dcolor_out) {       // (NULL: dcolor_extract_kernel already produced it, see w3d_backward_blend_dcolor)
         raw.dcolor_out[3 * (size_t)g] = dRGB_out[0]; raw.dcolor_out[3 * (size_t)g + 1] = dRGB_out[1];
         raw.dcolor_out[3 * (size_t)g + 2] = dRGB_out[2];
     }
@@ -764,6 +764,24 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, cons
 #pragma unroll
         for (int i = 0; i < 6; i++) dL_dcov3D[6 * (size_t)g + i] = dcov[i];
     }
+}
+
+// The clamp-masked dL/dRGB per Gaussian straight from the blend backward's records (what MODE 2 of preprocess_bwd_kernel
+// writes as dcolor_out), so that the ranks' all-gather of it can start BEFORE the per-Gaussian backward runs.
+__global__ void __launch_bounds__(256)
+dcolor_extract_kernel(int P, const ushort4 *__restrict__ rect, const uint8_t *__restrict__ clamped,
+                      const float *__restrict__ grad2d, float *__restrict__ dcolor_out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    const ushort4 rc = rect[g];
+    const bool vis = ((int)rc.z - (int)rc.x) * ((int)rc.w - (int)rc.y) > 0;
+    float d[3] = {0.f, 0.f, 0.f};
+    if (vis) {
+        const float *rec = grad2d + (size_t)g * W3D_G2D_STRIDE;
+        const uint32_t cl = clamped[g];
+        d[0] = (cl & 1u) ? 0.f : rec[6]; d[1] = (cl & 2u) ? 0.f : rec[7]; d[2] = (cl & 4u) ? 0.f : rec[8];
+    }
+    dcolor_out[3 * (size_t)g] = d[0]; dcolor_out[3 * (size_t)g + 1] = d[1]; dcolor_out[3 * (size_t)g + 2] = d[2];
 }
 
 // View-parallel optimizer step of the SH blocks (f_dc, f_rest) from the EXCHANGED colour gradients: for every Gaussian
@@ -816,6 +834,15 @@ sh_adam_lowrank_kernel(int P, int nviews, int deg, const float *__restrict__ cam
 }
 
 }  // namespace
+
+int w3d_launch_dcolor_extract(const W3DLayout &L, const char *state, const float *grad2d, float *dcolor_out, hipStream_t stream) {
+    if (L.P == 0) return W3D_OK;
+    hipLaunchKernelGGL(dcolor_extract_kernel, dim3((L.P + 255) / 256), dim3(256), 0, stream, L.P,
+                       reinterpret_cast<const ushort4 *>(state + L.o_rect), reinterpret_cast<const uint8_t *>(state + L.o_clamped),
+                       grad2d, dcolor_out);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}
 
 int w3d_launch_sh_adam_lowrank(int32_t P, int32_t nviews, int32_t sh_degree, const float *campos_all, const float *xyz,
                                const float *dcolor_all, float *f_dc, float *f_rest, float *m_dc, float *v_dc, float *m_rest,
@@ -915,7 +942,7 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
                        reinterpret_cast<const uint8_t *>(state + L.o_clamped), grad2d, dL_dmeans3D, dL_dmeans2D,         \
                        dL_dcolors, dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
     W3D_PROF("preprocess_bwd", stream);
-    if (rawargs && rawargs->dcolor_out) {
+    if (rawargs && rawargs->lowrank) {
         if (v.sh_coeffs != 16) { w3d_set_error("low-rank colour-gradient output needs 16 SH coefficients"); return W3D_ERR_INVALID; }
         raw.dcolor_out = rawargs->dcolor_out;
         hipLaunchKernelGGL((preprocess_bwd_kernel<true, true, true, true, 2>), dim3(grid), dim3(block), 0, stream, v, L.P, means3D, shs,

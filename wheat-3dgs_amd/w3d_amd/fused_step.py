@@ -53,6 +53,8 @@ lib.w3d_flash_reblend.restype = ctypes.c_int
 lib.w3d_backward_raw_lowrank.argtypes = [ctypes.POINTER(W3DView), _i32, ctypes.POINTER(W3DRawParams), _vp, _vp, _vp, _vp, _vp,
                                          ctypes.POINTER(W3DRawGrads), _vp, ctypes.POINTER(W3DDensifyStats), _vp, _vp]
 lib.w3d_backward_raw_lowrank.restype = ctypes.c_int
+lib.w3d_backward_blend_dcolor.argtypes = [ctypes.POINTER(W3DView), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+lib.w3d_backward_blend_dcolor.restype = ctypes.c_int
 lib.w3d_sh_adam_lowrank.argtypes = [_i32, _i32, _i32] + [_vp] * 9 + [ctypes.c_float, ctypes.c_float, _i32, _i32] + \
     [ctypes.c_float] * 5 + [_vp]
 lib.w3d_sh_adam_lowrank.restype = ctypes.c_int
@@ -277,6 +279,25 @@ def backward_raw_adam(model, handle, dL_dimage, skip=(), want_norm=True, update_
     return gnorm
 
 
+def backward_blend_dcolor(model, handle, dL_dimage):
+    """First half of backward_raw_lowrank: the blend backward and the (P,3) clamp-masked dL/dRGB it implies — everything the
+    other ranks need for the SH gradient — so that its all-gather can be issued before the per-Gaussian backward is even
+    enqueued.  Call backward_raw_lowrank(model, handle, None) afterwards."""
+    dev = model.flat.device
+    P, view = handle["P"], handle["view"]
+    if P != model.num_points:
+        raise RuntimeError("model was resized between forward and backward")
+    dcol = torch.empty(P, 3, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        sb = ctypes.c_uint64()
+        check(lib.w3d_backward_sizes(P, ctypes.byref(sb)))
+        scratch = torch.empty(sb.value, dtype=torch.uint8, device=dev)
+        check(lib.w3d_backward_blend_dcolor(ctypes.byref(view.c), P, ptr(handle["state"]), ptr(handle["point_list"]),
+                                            ptr(dL_dimage.contiguous()), None, None, ptr(dcol), ptr(scratch), stream_ptr(dev)))
+    handle["bwd_scratch"] = scratch
+    return dcol
+
+
 def backward_raw_lowrank(model, handle, dL_dimage, want_norm=True):
     """Backward of the view-parallel step: gradients of the geometry blocks (xyz, opacity, scaling, rotation) into
     model.flat_grad, and instead of the 48-float SH gradient rows the (P,3) clamp-masked dL/dRGB per Gaussian — the SH
@@ -292,10 +313,17 @@ def backward_raw_lowrank(model, handle, dL_dimage, want_norm=True):
         setattr(g, n, model._p[n].grad.data_ptr())
     st = W3DDensifyStats()
     gnorm = torch.empty(P, dtype=torch.float32, device=dev) if want_norm else None
-    dcol = torch.empty(P, 3, dtype=torch.float32, device=dev)
     st.grad2d_norm = None if gnorm is None else gnorm.data_ptr()
     st.radii = handle["radii"].data_ptr()
     with torch.cuda.device(dev):
+        if dL_dimage is None:
+            # second half: backward_blend_dcolor already ran the blend backward into the handle's scratch
+            scratch = handle.pop("bwd_scratch")
+            check(lib.w3d_backward_raw_lowrank(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(handle["state"]),
+                                               ptr(handle["point_list"]), None, None, None, ctypes.byref(g), None,
+                                               ctypes.byref(st), ptr(scratch), stream_ptr(dev)))
+            return gnorm, None
+        dcol = torch.empty(P, 3, dtype=torch.float32, device=dev)
         sb = ctypes.c_uint64()
         check(lib.w3d_backward_sizes(P, ctypes.byref(sb)))
         scratch = torch.empty(sb.value, dtype=torch.uint8, device=dev)

@@ -68,6 +68,9 @@ class Trainer:
         # geometry gradients and replicates the optimizer; "dense" reduce-scatters the 59-float bucket, shards Adam and
         # all-gathers the parameters (also what the autograd step uses)
         self.exchange_mode = os.environ.get("W3D_EXCHANGE", "lowrank")
+        # lowrank only: issue the colour-gradient all-gather between the blend backward and the per-Gaussian backward (it
+        # then travels while that kernel runs).  OFF until measured on a multi-GPU node: it costs a 25 us extraction kernel
+        self.early_gather = os.environ.get("W3D_EARLY_GATHER", "0") == "1"
         self._d_chunks, self._geo_work = [], None
         self.lowrank_chunks = None          # row chunks of the colour-gradient all-gather (None: 4 above 256 k Gaussians)
         self.use_depth_cuts = os.environ.get("W3D_DEPTH_CUTS", "0") == "1"
@@ -139,17 +142,8 @@ class Trainer:
         rank applies the identical update (optimizer_step_lowrank).  Returns the reduced statistics."""
         m = self.model
         P = m.num_points
-        # the colour gradients travel in a few row chunks, so that the SH update of the first chunk starts while the
-        # later ones (and then the geometry all-reduce) are still on the wire
-        nchunk = self.lowrank_chunks or (4 if (dcolor.is_cuda and P >= (1 << 18)) else 1)
-        step = ((P + nchunk - 1) // nchunk + 255) // 256 * 256
-        dcolor = dcolor.contiguous()
-        self._d_chunks = []
-        for r0 in range(0, P, step):
-            r1 = min(P, r0 + step)
-            d_all = torch.empty(self.world, r1 - r0, 3, dtype=torch.float32, device=dcolor.device)
-            work = dist.all_gather_into_tensor(d_all.view(-1), dcolor[r0:r1].view(-1), async_op=True)
-            self._d_chunks.append([(r0, r1), d_all, work])
+        if dcolor is not None:           # (None: gather_colors() was called early, between the two halves of the backward)
+            self.gather_colors(dcolor)
         sl = m.block_slices()
         a, b = sl["xyz"][0], sl["rotation"][1]                # xyz | opacity | scaling | rotation: one contiguous span
         assert b - a == 11 * P and sl["xyz"][1] == sl["opacity"][0] and sl["opacity"][1] == sl["scaling"][0] and \
@@ -163,6 +157,20 @@ class Trainer:
         w2 = dist.all_reduce(r, op=dist.ReduceOp.MAX, async_op=True)
         self._stat_work = (w1, w2)
         return stats[0], stats[1], r
+
+    def gather_colors(self, dcolor):
+        """Asynchronous all-gather of the (P,3) colour gradients, in a few row chunks so that the SH update of the first
+        chunk starts while the later ones (and then the geometry all-reduce) are still on the wire."""
+        P = self.model.num_points
+        nchunk = self.lowrank_chunks or (4 if (dcolor.is_cuda and P >= (1 << 18)) else 1)
+        step = ((P + nchunk - 1) // nchunk + 255) // 256 * 256
+        dcolor = dcolor.contiguous()
+        self._d_chunks = []
+        for r0 in range(0, P, step):
+            r1 = min(P, r0 + step)
+            d_all = torch.empty(self.world, r1 - r0, 3, dtype=torch.float32, device=dcolor.device)
+            work = dist.all_gather_into_tensor(d_all.view(-1), dcolor[r0:r1].view(-1), async_op=True)
+            self._d_chunks.append([(r0, r1), d_all, work])
 
     def optimizer_step_lowrank(self, iteration, skip):
         """Replicated optimizer step after exchange_lowrank: SH blocks from the gathered colour gradients (needs the
@@ -269,7 +277,8 @@ class Trainer:
         densify / reset opacity write the gradient bucket and step separately.  Several ranks: low-rank or dense
         exchange (exchange_lowrank / exchange).  No autograd graph is built."""
         from .fused import l1_ssim_fwd_bwd
-        from .fused_step import backward_raw, backward_raw_adam, backward_raw_lowrank, finish, render_raw
+        from .fused_step import (backward_blend_dcolor, backward_raw, backward_raw_adam, backward_raw_lowrank, finish,
+                                 render_raw)
         m, opt = self.model, self.opt
         m.update_learning_rate(iteration)
         if iteration % 1000 == 0:
@@ -296,6 +305,15 @@ class Trainer:
                     dimg.mul_(1.0 / self.world)      # the bucket then holds grad/world: reduce-scatter(SUM) = mean
                 if use_adam:
                     gnorm = backward_raw_adam(m, pkg["handle"], dimg, want_norm=False, update_stats=tracking)
+                elif lowrank and self.early_gather:
+                    # blend backward + dL/dRGB; make sure this forward is final BEFORE a collective is issued (a rank that
+                    # repeats its view must not issue it twice); then gather, then the per-Gaussian backward
+                    early = backward_blend_dcolor(m, pkg["handle"], dimg)
+                    if not finish(pkg["handle"]):
+                        continue
+                    self.gather_colors(early)
+                    gnorm, _ = backward_raw_lowrank(m, pkg["handle"], None, want_norm=True)
+                    dcol = None
                 elif lowrank:
                     gnorm, dcol = backward_raw_lowrank(m, pkg["handle"], dimg, want_norm=True)
                 else:
