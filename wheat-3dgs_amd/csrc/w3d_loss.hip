@@ -78,13 +78,18 @@ ssim_pass_a(int H, int W, const float *__restrict__ img, const float *__restrict
         float xv[LSEG + 10], yv[LSEG + 10];
 #pragma unroll
         for (int j = 0; j < LSEG + 10; j++) { xv[j] = sx[ly][seg + j]; yv[j] = sy[ly][seg + j]; }
+        // products once per input (as the reference filters img*img), not once per tap: 5 instead of 7 VALU per tap — this
+        // pass is VALU-issue-bound (profiles/r01/sq_counters.csv)
+        float xx[LSEG + 10], yy[LSEG + 10], xy[LSEG + 10];
+#pragma unroll
+        for (int j = 0; j < LSEG + 10; j++) { xx[j] = xv[j] * xv[j]; yy[j] = yv[j] * yv[j]; xy[j] = xv[j] * yv[j]; }
 #pragma unroll
         for (int o = 0; o < LSEG; o++) {
             float a = 0, b = 0, aa = 0, bb = 0, ab = 0;
 #pragma unroll
             for (int k = 0; k < 11; k++) {
-                const float x = xv[o + k], y = yv[o + k], wk = w[k];
-                a += wk * x; b += wk * y; aa += wk * x * x; bb += wk * y * y; ab += wk * x * y;
+                const float wk = w[k];
+                a += wk * xv[o + k]; b += wk * yv[o + k]; aa += wk * xx[o + k]; bb += wk * yy[o + k]; ab += wk * xy[o + k];
             }
             h[0][ly][seg + o] = a; h[1][ly][seg + o] = b; h[2][ly][seg + o] = aa; h[3][ly][seg + o] = bb; h[4][ly][seg + o] = ab;
         }
