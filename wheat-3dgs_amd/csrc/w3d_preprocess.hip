@@ -208,18 +208,19 @@ __device__ __forceinline__ uint64_t footprint_tile_mask(float mx, float my, floa
     if (tau < 0.f) return 0ull;                       // o <= 1/255: alpha >= 1/255 is unreachable anywhere
     const float det = A * C - B * B;
     if (!(A > 0.f && C > 0.f && det > 0.f)) return ~0ull;
-    const float T2 = 2.f * tau, idet = 1.0f / det, iA = 1.0f / A;
+    // (hardware rcp / sqrt, ~1 ulp: this mask only has to be conservative, and the 0.01-px / 1e-3 margins dwarf that)
+    const float T2 = 2.f * tau, idet = __builtin_amdgcn_rcpf(det), iA = __builtin_amdgcn_rcpf(A);
     const float pad = 0.01f;
-    const float wmax = sqrtf(T2 * A * idet) + pad;    // the ellipse's half height
-    const float xext = sqrtf(T2 * C * idet) + pad;    // ... and half width
-    const float wstar = B * sqrtf(T2 * idet / C);     // l is extremal at +wstar, r at -wstar
+    const float wmax = __builtin_amdgcn_sqrtf(T2 * A * idet) + pad;    // the ellipse's half height
+    const float xext = __builtin_amdgcn_sqrtf(T2 * C * idet) + pad;    // ... and half width
+    const float wstar = B * __builtin_amdgcn_sqrtf(T2 * idet * __builtin_amdgcn_rcpf(C));     // l is extremal at +wstar, r at -wstar
     const int rw = maxx - minx;
     uint64_t m = 0ull;
     for (int ty = miny; ty < maxy; ty++) {
         const float w0 = (float)(ty * W3D_TILE) - my, w1 = w0 + (float)(W3D_TILE - 1);
         const float a = fmaxf(w0, -wmax), b = fminf(w1, wmax);
         if (a > b) continue;                          // the strip misses the ellipse
-        const float sa = sqrtf(fmaxf(T2 * A - det * a * a, 0.f)), sb = sqrtf(fmaxf(T2 * A - det * b * b, 0.f));
+        const float sa = __builtin_amdgcn_sqrtf(fmaxf(T2 * A - det * a * a, 0.f)), sb = __builtin_amdgcn_sqrtf(fmaxf(T2 * A - det * b * b, 0.f));
         const float ra = (-B * a + sa) * iA, rb = (-B * b + sb) * iA;
         const float la = (-B * a - sa) * iA, lb = (-B * b - sb) * iA;
         const float xr = ((-wstar >= a && -wstar <= b) ? xext : fmaxf(ra, rb) + pad) + mx;
