@@ -325,6 +325,9 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         for (int i = 0; i < W3D_WALK_SMALL; i++) tls[i] = NONE;
         {
             uint64_t m = (lane < nq && kind == 0u) ? rm : 0ull;
+            // tile of rect slot k (row ty = k / w): (miny + ty - y0) * gx + minx + k - ty * w = base + k + ty * (gx - w);
+            // base may wrap below zero for a rect that starts above the band — the sum is taken modulo 2^32
+            const uint32_t base = (miny - y0) * gx + minx, rowskip = gx - w;
 #pragma unroll
             for (int i = 0; i < W3D_WALK_SMALL; i++) {
                 const bool v = m != 0ull;
@@ -333,7 +336,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                 const uint32_t k = (uint32_t)__ffsll((unsigned long long)m) - 1u;
                 m &= m - 1ull;
                 const uint32_t ty = __umul24(k, magic) >> 16;
-                const uint32_t tl = __umul24(miny + ty - y0, gx) + minx + (k - __umul24(ty, w));
+                const uint32_t tl = base + k + __umul24(ty, rowskip);
                 tls[i] = (v && tile_ok(v ? tl : 0u, depth)) ? tl : NONE;
             }
         }
