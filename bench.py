@@ -5,18 +5,27 @@
 A step is the loop body of reference train_vanilla_3dgs.py:55-115 (render, 0.8*L1+0.2*(1-SSIM),
 backward, densification statistics, Adam step, zero_grad) at fixed P (no densify/prune inside the
 timed region).  With N>1 GPUs every rank renders a different camera per step (view-parallel,
-weak scaling) and the 59xP gradient bucket is all-reduced over RCCL; `value` counts views/sec.
+weak scaling) and the ranks exchange gradients over RCCL; `value` counts views/sec of the whole job.
 
   python bench.py --gpus N --steps K --warmup W
+      N > 1 without a torch.distributed environment: this process starts N ranks itself
+      (python -m torch.distributed.run, one per GPU) BEFORE touching the GPU and relays their output.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+      the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  `value` is the fused raw-parameter step (the repo's own trainer);
+`dropin_iters_per_s` is the UNMODIFIED reference loop body (train_vanilla_3dgs.py:55-115 statement by
+statement: render() -> l1_loss / ssim -> loss.backward() -> loss.item() -> max_radii2D / add_densification_stats
+-> optimizer.step() -> zero_grad(set_to_none=True)) on this package's render / GaussianModel / loss_utils
+drop-ins; `trained_scene` repeats the headline measurement after 3000 more training steps (fixed P).
 """
 import argparse
 import ctypes
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +38,12 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+# fp32 vector peak of the chip: 256 CUs x 4 SIMD-32 x 2.4 GHz x 2 flop (MI355X_MICROARCH.md 'Peak FP32 (vector)')
+# = one wave64 VALU instruction per 2 cycles per SIMD.  The VALU roofline of the blend kernels prices every issued
+# wave64 VALU instruction as 128 flop-equivalents against it (the measured sustainable rate is in
+# profiles/r02/valu_microbench.json and replaces the spec figure when present).
+VALU_SPEC_TFLOPS = 157.3
+FLOP_PER_VALU_INSTR = 128.0
 
 
 def parse():
@@ -45,10 +60,92 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-loss", action="store_true", help="use the PyTorch conv2d SSIM instead of the fused kernel")
     ap.add_argument("--autograd-path", action="store_true",
-                    help="run the drop-in render()+autograd step instead of the fused raw-parameter step")
+                    help="headline loop = Trainer.step through render()+autograd instead of the fused raw-parameter step")
+    ap.add_argument("--exchange", default="lowrank", choices=("lowrank", "dense"), help="view-parallel exchange (N > 1)")
+    ap.add_argument("--dropin-steps", type=int, default=-1, help="steps of the reference-loop measurement (-1: = --steps, 0: skip)")
+    ap.add_argument("--trained-steps", type=int, default=3000,
+                    help="extra training steps before the second (trained-scene) measurement; 0: skip")
+    ap.add_argument("--no-extras", action="store_true", help="skip render / FlashSplat / drop-in / trained-scene measurements")
+    ap.add_argument("--force-dist", action="store_true", help="1-rank RCCL group: exercises the exchange path on one GPU")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / reporting test on CPU over gloo with a stub step (no kernels, no GPU); "
+                         "the line says so in `data`")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------ launch
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """--gpus N > 1 outside a torch.distributed environment: start the N ranks as a fresh child BEFORE anything here
+    has touched the GPU (device_count() does not initialise it) and exit with the child's status."""
+    if not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible", file=sys.stderr)
+            sys.exit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dist_env(args):
+    """(world, rank, local) from the torch.distributed environment; launches the ranks first if there is none."""
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            launch_ranks(args)
+        return 1, 0, 0
+    world = int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU", file=sys.stderr)
+        sys.exit(2)
+    return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def dry_run(args, world, rank):
+    """The launch / rendezvous / max-over-ranks / one-line protocol with a stub step on CPU tensors over gloo."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    bucket = torch.ones(1 << 16)
+
+    def step():
+        if world > 1:
+            dist.all_reduce(bucket)
+        bucket.mul_(1.0 / max(world, 1))
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "train iters/sec (DRY RUN: stub step, no kernels)", "value": round(world * args.steps / float(el), 3),
+                          "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * float(el) / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "dry-run (launcher test on CPU/gloo, nothing measured)",
+                          "config": {"workload": "stub", "views_per_step": world}, "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ scene
 def build_scene(args, dev):
     from w3d_amd.synth import make_scene, make_cameras
     from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
@@ -98,21 +195,53 @@ def workload_stats(model, cam, bg, dev):
                     mean_contrib=float(nc.float().mean()))
 
 
+def _newest(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", pattern)))
+    return files[-1] if files else None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
     (profiles/rNN/pmc_hbm_traffic.csv: FETCH_SIZE x2 + WRITE_SIZE, collected in separate --pmc passes);
     None when no summary exists.  The counters cannot be read live from inside the process."""
     import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_hbm_traffic.csv")))
-    if not files:
+    f = _newest("pmc_hbm_traffic.csv")
+    if not f:
         return None
     best = None
-    for r in csv.DictReader(open(files[-1])):
+    for r in csv.DictReader(open(f)):
         if kernel in r["kernel"] and "<true>" not in r["kernel"].replace("<true, true>", ""):
             mib = float(r["hbm_read_MiB_corrected_x2"]) + float(r["hbm_write_MiB"])
             best = max(best or 0.0, mib)
     return None if best is None else int(best * 1024 * 1024)
+
+
+def valu_instructions(kernel):
+    """wave64 VALU instructions one launch of `kernel` issues (SQ_INSTS_VALU of the newest committed
+    profiles/rNN/sq_counters.csv, mean over the benchmark's full-size dispatches); (count, file) or (None, None)."""
+    import csv
+    f = _newest("sq_counters.csv")
+    if not f:
+        return None, None
+    for r in csv.DictReader(open(f)):
+        if r["kernel"].startswith(kernel) and "<true>" not in r["kernel"]:
+            return float(r["SQ_INSTS_VALU"]), os.path.relpath(f, ROOT)
+    return None, None
+
+
+def valu_peak():
+    """Sustainable wave64 VALU issue rate of the chip measured by profiles/valu_microbench.hip (v_fma_f32, best over the
+    waves-per-SIMD settings), as TFLOP/s-equivalents (x128); falls back to the spec fp32 vector peak."""
+    f = _newest("valu_microbench.json")
+    if f:
+        try:
+            res = json.load(open(f))["results"]
+            rate = max(r["wave_instr_per_s"] for r in res if r["op"] == "v_fma_f32")
+            return rate * FLOP_PER_VALU_INSTR / 1e12, os.path.relpath(f, ROOT)
+        except Exception:
+            pass
+    return VALU_SPEC_TFLOPS, "spec (MI355X_MICROARCH.md, Peak FP32 vector)"
 
 
 def cpu_baseline(args):
@@ -139,16 +268,111 @@ def cpu_baseline(args):
             "render_mpix_per_s": round(args.width * args.height / 1e6 / (t1 - t0), 4)}
 
 
+# ------------------------------------------------------------------------------------------------ drop-in loop
+def reference_loop(model, opt, cams, bg, pipe, first_iter, n_steps, perm):
+    """The loop body of reference train_vanilla_3dgs.py:55-115, statement by statement (logging, saving and the
+    densification branch — not due in these iterations — left out; cameras cycled instead of randint), on this package's
+    drop-ins for the names that script imports: render (gaussian_renderer), GaussianModel (scene), l1_loss / ssim
+    (utils.loss_utils).  Returns the last loss value."""
+    from w3d_amd.gaussian_renderer import render
+    from w3d_amd.loss import l1_loss, ssim
+    gaussians, background = model, bg
+    ema_loss_for_log = 0.0
+    for iteration in range(first_iter, first_iter + n_steps):
+        gaussians.update_learning_rate(iteration)
+        if iteration % 1000 == 0:
+            gaussians.oneupSHdegree()
+        viewpoint_cam = cams[perm[(iteration - 1) % len(cams)]]
+        render_pkg = render(viewpoint_cam, gaussians, pipe, background)
+        image, viewspace_point_tensor, visibility_filter, radii = (render_pkg["render"], render_pkg["viewspace_points"],
+                                                                   render_pkg["visibility_filter"], render_pkg["radii"])
+        gt_image = viewpoint_cam.original_image.cuda()
+        Ll1 = l1_loss(image, gt_image)
+        loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, gt_image))
+        loss.backward()
+        with torch.no_grad():
+            ema_loss_for_log = 0.4 * loss.item() + 0.6 * ema_loss_for_log
+            if iteration < opt.densify_until_iter:
+                gaussians.max_radii2D[visibility_filter] = torch.max(gaussians.max_radii2D[visibility_filter],
+                                                                     radii[visibility_filter])
+                gaussians.add_densification_stats(viewspace_point_tensor, visibility_filter)
+            if iteration < opt.iterations:
+                gaussians.optimizer.step()
+                gaussians.optimizer.zero_grad(set_to_none=True)
+    return ema_loss_for_log
+
+
+def time_dropin(args, sc, cams, bg, dev, perm):
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.train import PipelineParams
+    n = args.steps if args.dropin_steps < 0 else args.dropin_steps
+    if n <= 0:
+        return None
+    model = GaussianModel(3, device=dev)
+    model.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    model.active_sh_degree = 3
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    pipe = PipelineParams()
+    w = max(3, min(args.warmup, 10))
+    reference_loop(model, opt, cams, bg, pipe, 1, w, perm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reference_loop(model, opt, cams, bg, pipe, 1 + w, n, perm)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del model
+    torch.cuda.empty_cache()
+    return {"iters_per_s": round(n / dt, 2), "ms_per_step": round(1e3 * dt / n, 4), "steps": n}
+
+
+# ------------------------------------------------------------------------------------------------ exchange
+def exchange_bandwidth(model, world, dev):
+    """The step's two gradient collectives alone (N > 1): achieved bus bandwidth per GPU.
+    all-gather of the (P,3) colour gradients: every rank receives (world-1)*12P bytes;
+    all-reduce of the 11-float geometry span: ring model 2*(world-1)/world * 44P bytes per rank."""
+    P = model.num_points
+    d = torch.randn(P, 3, device=dev)
+    d_all = torch.empty(world, P, 3, device=dev)
+    geo = torch.randn(11 * P, device=dev)
+    out = {}
+    for name, fn, nbytes in (("all_gather_dcolor", lambda: dist.all_gather_into_tensor(d_all.view(-1), d.view(-1)),
+                              (world - 1) * 12.0 * P),
+                             ("all_reduce_geometry", lambda: dist.all_reduce(geo), 2.0 * (world - 1) / world * 44.0 * P)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        dt = torch.tensor([(time.perf_counter() - t0) / 10], device=dev, dtype=torch.float64)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        out[name] = {"ms": round(1e3 * float(dt), 4), "bus_GBps_per_gpu": round(nbytes / float(dt) / 1e9, 1)}
+    return out
+
+
+def replicas_identical(model, world, dev):
+    """Every rank must hold bit-identical parameters (nothing re-synchronises them): compare a checksum of the bits."""
+    bits = model.flat.detach().view(torch.int32).to(torch.int64)
+    s = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=dev) % 8191 + 1)).sum()])
+    allsums = [torch.zeros_like(s) for _ in range(world)]
+    dist.all_gather(allsums, s)
+    return all(bool(torch.equal(allsums[0], x)) for x in allsums)
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local = dist_env(args)
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    force_dist = os.environ.get("W3D_FORCE_DIST", "0") == "1"      # 1-rank RCCL group: exercises the exchange path
+    force_dist = args.force_dist or os.environ.get("W3D_FORCE_DIST", "0") == "1"
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -162,125 +386,155 @@ def main():
     make_ground_truth(args, cams, dev, bg)
     loss_fn = photometric_loss_torch if args.torch_loss else photometric_loss
     trainer = Trainer(model, cams, opt, bg, densify=False, loss_fn=loss_fn, fused=False if args.autograd_path else None,
-                      force_exchange=force_dist)
+                      force_exchange=force_dist, exchange=args.exchange)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    _lib.lib.w3d_profile_enable.argtypes = [ctypes.c_char_p]
+    _lib.lib.w3d_profile_collect.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
+
+    def timed(n_steps, it, prof_sel):
+        """n_steps trainer steps between barrier + synchronize brackets; max over ranks.  Returns (seconds, it, stages)."""
+        sync()
+        _lib.lib.w3d_profile_enable(prof_sel)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            it += 1
+            trainer.step(it)
+        sync()
+        t1 = time.perf_counter()
+        _lib.lib.w3d_profile_enable(None)
+        buf = ctypes.create_string_buffer(1 << 16)
+        _lib.lib.w3d_profile_collect(buf, len(buf))
+        stages = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            stages[name] = (int(cnt), float(ms))
+        el = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el), it, stages
+
     it = 0
     for _ in range(args.warmup):
         it += 1
         trainer.step(it)
-    _lib.lib.w3d_profile_enable.argtypes = [ctypes.c_char_p]
-    _lib.lib.w3d_profile_collect.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
     prof_sel = b"*" if args.all_stages else args.profile.encode()
-    sync()
-    _lib.lib.w3d_profile_enable(prof_sel)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        it += 1
-        trainer.step(it)
-    sync()
-    t1 = time.perf_counter()
-    _lib.lib.w3d_profile_enable(None)
-    buf = ctypes.create_string_buffer(1 << 16)
-    _lib.lib.w3d_profile_collect(buf, len(buf))
-    stages = {}
-    for line in buf.value.decode().splitlines():
-        name, cnt, ms = line.split()
-        stages[name] = (int(cnt), float(ms))
-    elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed)
+    elapsed, it, stages = timed(args.steps, it, prof_sel)
     final_loss = float(trainer.last["loss"])
 
     # per-stage times, OUTSIDE the timed region (an event pair around every stage costs ~4 % of the step): 20 more steps
-    stage_ms = {}
     if not args.all_stages:
-        sync()
-        _lib.lib.w3d_profile_enable(b"*")
-        for _ in range(20):
-            it += 1
-            trainer.step(it)
-        sync()
-        _lib.lib.w3d_profile_enable(None)
-        buf2 = ctypes.create_string_buffer(1 << 16)
-        _lib.lib.w3d_profile_collect(buf2, len(buf2))
-        for line in buf2.value.decode().splitlines():
-            name, cnt, ms = line.split()
-            if int(cnt) > 0:
-                stage_ms[name] = round(float(ms) / int(cnt), 4)
+        _, it, st2 = timed(20, it, b"*")
+        stage_ms = {k: round(ms / c, 4) for k, (c, ms) in st2.items() if c > 0}
     else:
         stage_ms = {k: round(ms / c, 4) for k, (c, ms) in stages.items() if c > 0}
 
-    # forward-only render throughput (reference render.py's use), same scene, views cycled
-    n_r = max(4, min(args.steps, 36))
-    render_views(model, cams[:2], bg)
-    sync()
-    r0 = time.perf_counter()
-    render_views(model, [cams[i % len(cams)] for i in range(n_r)], bg)
-    sync()
-    r1 = time.perf_counter()
-    r_el = torch.tensor([r1 - r0], device=dev, dtype=torch.float64)
+    extras = {}
+    exchange = None
     if world > 1:
-        dist.all_reduce(r_el, op=dist.ReduceOp.MAX)
-    mpix = world * n_r * args.width * args.height / 1e6 / float(r_el)
+        exchange = exchange_bandwidth(model, world, dev)
+        exchange["mode"] = trainer.exchange_mode if trainer.fused else "dense"
+        exchange["replicas_identical_after_timed_steps"] = replicas_identical(model, world, dev)
+    if not args.no_extras:
+        # forward-only render throughput (reference render.py's use), same scene, views cycled
+        n_r = max(4, min(args.steps, 36))
+        render_views(model, cams[:2], bg)
+        sync()
+        r0 = time.perf_counter()
+        render_views(model, [cams[i % len(cams)] for i in range(n_r)], bg)
+        sync()
+        r_el = torch.tensor([time.perf_counter() - r0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(r_el, op=dist.ReduceOp.MAX)
+        extras["render_mpix_per_s"] = round(world * n_r * args.width * args.height / 1e6 / float(r_el), 1)
 
-    # config C4: FlashSplat per-mask contribution render (run_3d_seg.py's inner call), binary mask, same scene
-    from w3d_amd.gaussian_renderer import flashsplat_render
-    from w3d_amd.train import PipelineParams
-    yy, xx = torch.meshgrid(torch.arange(args.height, device=dev), torch.arange(args.width, device=dev), indexing="ij")
-    mask = (((xx - args.width // 2) ** 2 + (yy - args.height // 2) ** 2) < (args.height // 3) ** 2).float()
-    n_f = 8
-    with torch.no_grad():
-        flashsplat_render(cams[0], model, PipelineParams(), bg, gt_mask=mask, obj_num=1)
-        sync()
-        f0 = time.perf_counter()
-        counts = None
-        for i in range(n_f):
-            uc = flashsplat_render(cams[i % len(cams)], model, PipelineParams(), bg, gt_mask=mask, obj_num=1)["used_count"]
-            counts = uc if counts is None else counts + uc
-        sync()
-        f1 = time.perf_counter()
-    flash_vps = world * n_f / (f1 - f0)
-    del counts
-    # ... and run_3d_seg.py's real loop shape: several object masks per view — one forward, the blend repeated per mask
-    from w3d_amd.gaussian_renderer import flashsplat_render_masks
-    n_m = 8
-    masks = torch.stack([torch.roll(mask, shifts=40 * k, dims=1) for k in range(n_m)])
-    with torch.no_grad():
-        flashsplat_render_masks(cams[0], model, PipelineParams(), bg, masks[:2], obj_num=1)
-        sync()
-        f0 = time.perf_counter()
-        for i in range(4):
-            uc = flashsplat_render_masks(cams[i % len(cams)], model, PipelineParams(), bg, masks, obj_num=1)["used_count"]
-        sync()
-        f1 = time.perf_counter()
-    flash_mps = world * 4 * n_m / (f1 - f0)
-    # non-overlapping instance masks (8 vertical stripes): one blend over the merged label map
-    stripes = torch.stack([((xx >= k * args.width // n_m) & (xx < (k + 1) * args.width // n_m)).float() for k in range(n_m)])
-    with torch.no_grad():
-        flashsplat_render_masks(cams[0], model, PipelineParams(), bg, stripes, obj_num=1)
-        sync()
-        f0 = time.perf_counter()
-        for i in range(4):
-            uc = flashsplat_render_masks(cams[i % len(cams)], model, PipelineParams(), bg, stripes, obj_num=1)["used_count"]
-        sync()
-        f1 = time.perf_counter()
-    flash_mps_disjoint = world * 4 * n_m / (f1 - f0)
-    del uc, masks, stripes
+        # config C4: FlashSplat per-mask contribution render (run_3d_seg.py's inner call), binary mask, same scene
+        from w3d_amd.gaussian_renderer import flashsplat_render, flashsplat_render_masks
+        from w3d_amd.train import PipelineParams
+        yy, xx = torch.meshgrid(torch.arange(args.height, device=dev), torch.arange(args.width, device=dev), indexing="ij")
+        mask = (((xx - args.width // 2) ** 2 + (yy - args.height // 2) ** 2) < (args.height // 3) ** 2).float()
+        n_f = 8
+        with torch.no_grad():
+            flashsplat_render(cams[0], model, PipelineParams(), bg, gt_mask=mask, obj_num=1)
+            sync()
+            f0 = time.perf_counter()
+            counts = None
+            for i in range(n_f):
+                uc = flashsplat_render(cams[i % len(cams)], model, PipelineParams(), bg, gt_mask=mask, obj_num=1)["used_count"]
+                counts = uc if counts is None else counts + uc
+            sync()
+            extras["flashsplat_views_per_s"] = round(world * n_f / (time.perf_counter() - f0), 1)
+        del counts
+        # ... and run_3d_seg.py's real loop shape: several object masks per view — one forward, the blend repeated per mask
+        n_m = 8
+        masks = torch.stack([torch.roll(mask, shifts=40 * k, dims=1) for k in range(n_m)])
+        with torch.no_grad():
+            flashsplat_render_masks(cams[0], model, PipelineParams(), bg, masks[:2], obj_num=1)
+            sync()
+            f0 = time.perf_counter()
+            for i in range(4):
+                uc = flashsplat_render_masks(cams[i % len(cams)], model, PipelineParams(), bg, masks, obj_num=1)["used_count"]
+            sync()
+            extras["flashsplat_masks_per_s_8_per_view"] = round(world * 4 * n_m / (time.perf_counter() - f0), 1)
+        # non-overlapping instance masks (8 vertical stripes): one blend over the merged label map
+        stripes = torch.stack([((xx >= k * args.width // n_m) & (xx < (k + 1) * args.width // n_m)).float() for k in range(n_m)])
+        with torch.no_grad():
+            flashsplat_render_masks(cams[0], model, PipelineParams(), bg, stripes, obj_num=1)
+            sync()
+            f0 = time.perf_counter()
+            for i in range(4):
+                uc = flashsplat_render_masks(cams[i % len(cams)], model, PipelineParams(), bg, stripes, obj_num=1)["used_count"]
+            sync()
+            extras["flashsplat_masks_per_s_8_disjoint_per_view"] = round(world * 4 * n_m / (time.perf_counter() - f0), 1)
+        # eval_wheatgs.py's shape: ONE label image with hundreds of object ids (obj_num = max label)
+        K = 300
+        # (40-pixel cells: label boundaries cut through the 16x16 tiles, up to four labels per tile)
+        labels = ((xx // 40) + (args.width // 40 + 1) * (yy // 40)).remainder(K + 1).float()
+        with torch.no_grad():
+            flashsplat_render(cams[0], model, PipelineParams(), bg, gt_mask=labels, obj_num=K)
+            sync()
+            f0 = time.perf_counter()
+            for i in range(4):
+                uc = flashsplat_render(cams[i % len(cams)], model, PipelineParams(), bg, gt_mask=labels, obj_num=K)["used_count"]
+            sync()
+            extras["flashsplat_views_per_s_300_labels"] = round(world * 4 / (time.perf_counter() - f0), 1)
+        del uc, masks, stripes, labels
+        torch.cuda.empty_cache()
 
+    ws = None
     if rank == 0:
         ws = [workload_stats(model, cams[i], bg, dev) for i in (0, len(cams) // 2)]
+
+    # the UNMODIFIED reference loop body on the drop-in modules (single GPU: the reference is single-GPU)
+    dropin = None
+    if not args.no_extras and world == 1 and not force_dist:
+        dropin = time_dropin(args, sc, cams, bg, dev, trainer.perm)
+
+    # the same measurement on a TRAINED scene: the fit lowers opacities and lengthens the per-tile walks
+    trained = None
+    if not args.no_extras and args.trained_steps > 0 and trainer.fused:
+        for _ in range(args.trained_steps):
+            it += 1
+            trainer.step(it)
+        t_el, it, _ = timed(args.steps, it, None)
+        trained = {"value": round(world * args.steps / t_el, 3), "ms_per_step": round(1e3 * t_el / args.steps, 4),
+                   "after_steps": it - args.steps, "final_loss": round(float(trainer.last["loss"]), 6)}
+        if rank == 0:
+            w2 = [workload_stats(model, cams[i], bg, dev) for i in (0, len(cams) // 2)]
+            trained["walked_instances_per_view"] = int(sum(w["R_walk"] for w in w2) / len(w2))
+            trained["tile_instances_per_view"] = int(sum(w["R"] for w in w2) / len(w2))
+
+    if rank == 0:
         V = sum(w["V"] for w in ws) / len(ws)
         R = sum(w["R"] for w in ws) / len(ws)
         Rw = sum(w["R_walk"] for w in ws) / len(ws)
         HW = args.width * args.height
         P = args.points
-        # algorithmic bytes per launch of the dominant kernel:
+        # algorithmic bytes per launch (DESIGN.md §5):
         #   blend backward: 84 B per tile instance the reverse walk visits (44 B gather + 40 B record update)
         #                   + 20 B per pixel (dL/dpixel 12 + final_T 4 + n_contrib 4)
         algo = {"render_bwd": 84.0 * Rw + 20.0 * HW, "render_fwd": 48.0 * Rw + 36.0 * HW,
@@ -290,11 +544,27 @@ def main():
         if args.profile in stages and stages[args.profile][0] > 0:
             cnt, ms = stages[args.profile]
             avg_ms = ms / cnt
-            ach = algo.get(args.profile, 0.0) / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": args.profile, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.profile + "_kernel"),
-                    "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
-                    "algorithmic_bytes_per_launch": int(algo.get(args.profile, 0.0))}
+            hbm_ach = algo.get(args.profile, 0.0) / (avg_ms * 1e-3) / 1e9
+            n_valu, src = valu_instructions(args.profile + "_kernel")
+            if args.profile.startswith("render") and n_valu:
+                # the blend kernels are VALU-issue bound (no MFMA shape, HBM traffic ~= algorithmic): price the wave64 VALU
+                # instructions one launch issues (SQ_INSTS_VALU, committed PMC summary of this kernel) against the chip's
+                # fp32 vector issue rate, one instruction = 64 lanes x 2 flop
+                peak, peak_src = valu_peak()
+                ach = n_valu * FLOP_PER_VALU_INSTR / (avg_ms * 1e-3) / 1e12
+                roof = {"bound": "valu", "kernel": args.profile, "achieved": round(ach, 2), "peak": round(peak, 1),
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(args.profile + "_kernel"),
+                        "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
+                        "valu_wave_instr_per_launch": int(n_valu), "valu_instr_source": src, "peak_source": peak_src,
+                        "flop_equiv_per_wave_instr": FLOP_PER_VALU_INSTR,
+                        "valu_instr_per_walked_instance": round(n_valu / max(Rw, 1.0), 1),
+                        "algorithmic_bytes_per_launch": int(algo.get(args.profile, 0.0)),
+                        "hbm_achieved_GBps": round(hbm_ach, 1), "hbm_frac": round(hbm_ach / HBM_PEAK_GBS, 5)}
+            else:
+                roof = {"bound": "hbm", "kernel": args.profile, "achieved": round(hbm_ach, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(hbm_ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.profile + "_kernel"),
+                        "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
+                        "algorithmic_bytes_per_launch": int(algo.get(args.profile, 0.0))}
         if args.all_stages:
             for k, (c, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1]):
                 print(f"[stage] {k:18s} {c:5d} launches  avg {ms / c:8.4f} ms", file=sys.stderr)
@@ -303,20 +573,27 @@ def main():
             "value": round(world * args.steps / elapsed, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "render_mpix_per_s": round(mpix, 1), "flashsplat_views_per_s": round(flash_vps, 1),
-            "flashsplat_masks_per_s_8_per_view": round(flash_mps, 1),
-            "flashsplat_masks_per_s_8_disjoint_per_view": round(flash_mps_disjoint, 1),
+            "dropin_iters_per_s": None if dropin is None else dropin["iters_per_s"],
             "config": {"workload": f"C3: plot-shaped synthetic scene, {P} Gaussians, SH degree 3, "
                                    f"{args.width}x{args.height}, {args.views} overhead cameras, depth+alpha channels",
                        "points": P, "image": [args.width, args.height], "views_per_step": world,
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
                        "visible_per_view": int(V), "tile_instances_per_view": int(R), "walked_instances_per_view": int(Rw),
                        "loss": "torch conv2d" if args.torch_loss else "fused HIP L1+SSIM",
-                       "step": "fused raw-parameter kernels (no autograd)" if trainer.fused else "drop-in render() + autograd",
+                       "step": "fused raw-parameter kernels (no autograd)" if trainer.fused else "render() + autograd (Trainer.step)",
                        "final_loss": round(final_loss, 6)},
             "roofline": roof,
             "stage_ms": stage_ms,
         }
+        out.update(extras)
+        if dropin is not None:
+            out["dropin"] = dict(dropin, loop="reference train_vanilla_3dgs.py:55-115 body on the drop-in render / "
+                                              "GaussianModel / l1_loss / ssim; loss.item() and the boolean-mask statistics "
+                                              "lines (host syncs of the reference loop) included")
+        if trained is not None:
+            out["trained_scene"] = trained
+        if exchange is not None:
+            out["exchange"] = exchange
         # the HBM-bound kernel of the step next to the (VALU-bound) dominant one: per-Gaussian backward + Adam + statistics
         fused_adam = trainer.fused and trainer.fused_adam and world == 1 and not force_dist
         if fused_adam and "preprocess_bwd" in stage_ms:

@@ -79,22 +79,6 @@ typedef struct w3d_view {
                               * 1: additionally drop (Gaussian, tile) instances whose footprint provably
                               * cannot reach alpha >= 1/255 on any pixel of the tile — identical images and
                               * gradients, about half the list entries */
-    int32_t depth_layers;    /* 0/1: bin every visible Gaussian, blend in one pass.  2: bin and blend the front
-                              * ~28 % of the depth-ordered Gaussians first, then bin the rest only into tiles
-                              * that are still open (not every pixel saturated) and resume them — identical
-                              * outputs; since saturated tiles are the norm in dense scenes most of the binning
-                              * work disappears.  Needs the asynchronous forward (counts_host == NULL): the total
-                              * list length is only known after the front layer has been blended. */
-    /* Speculative per-tile list truncation for training loops that revisit cameras.  tile_depth_cut (device,
-     * one float per tile, nullable): instances deeper than their tile's cut are not binned — the kept
-     * entries are a PREFIX of the tile's depth-ordered list, so outputs are unchanged as long as every pixel
-     * of the tile saturates inside it.  tile_depth_cut_out (device, nullable) receives the cuts for the next
-     * visit of this camera: depth of the last entry the tile walked + a margin, or +inf for tiles that did
-     * not saturate.  A tile that had a finite cut and did NOT saturate may have lost contributors: it is
-     * counted in the third counter of the state (uint32 at byte 32, see w3d_forward_stage1); the caller
-     * must then repeat the view without cuts.  Single-pass mode only (depth_layers <= 1). */
-    const float *tile_depth_cut;
-    float *tile_depth_cut_out;
 } w3d_view;
 
 int w3d_version(void);
@@ -116,7 +100,7 @@ int w3d_forward_stage1(const w3d_view *view, int32_t P, const float *means3D, co
 /* Stage 2: fill the per-tile depth-ordered lists (point_list, capacity in entries) and blend
  * front-to-back.  The capacity must be >= num_rendered for correct output; if it is smaller (a caller
  * that sized the buffer speculatively to avoid stage 1's host sync) nothing is written or read beyond
- * it, the outputs of that view are incomplete, and the caller must repeat the view with a larger list
+ * it, the outputs of that view are incomplete, and the caller must repeat the stage with a larger list
  * once it has seen num_rendered (the counters are the first two uint32 of `state`).  out_color (3,H,W), out_depth (1,H,W), out_alpha
  * (1,H,W).  FlashSplat extras are all nullable: gt_mask (H,W) fp32 labels in [0,num_obj],
  * used_count (num_obj+1,P) is ACCUMULATED into (caller zero-fills), contrib_num (H,W) int32,
@@ -200,7 +184,9 @@ typedef struct w3d_adam_fused {
     w3d_raw_blocks exp_avg, exp_avg_sq;
     float lr[6];
     int32_t skip[6];
-    float beta1, beta2, eps, bias_correction1, bias_correction2;
+    float beta1, beta2, eps;
+    float bias_correction1[6], bias_correction2[6]; /* per block: torch.optim.Adam keeps one step counter per parameter,
+                                                     * and a parameter whose update was skipped does not advance */
 } w3d_adam_fused;
 int w3d_backward_raw_adam(const w3d_view *view, int32_t P, const w3d_raw_blocks *params, const void *state,
                           const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth,

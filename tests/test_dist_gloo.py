@@ -15,6 +15,11 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _tensors(item):
+    import numpy as np
+    return tuple(torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in item)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -79,7 +84,8 @@ def _worker(rank, world, port, out):
     moments = m.optimizer.exp_avg.clone()
     torch.manual_seed(1234)
     m.densify_and_prune(2e-4, 0.005, 10.0, None)
-    out.put((rank, bool(ok), cams, m.num_points, m.flat.detach().clone(), moments))
+    # (numpy payloads: a torch tensor travels as a shared-memory file that vanishes if this process exits first)
+    out.put((rank, bool(ok), cams, m.num_points, m.flat.detach().numpy().copy(), moments.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,7 +98,7 @@ def test_view_parallel_exchange_two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    res = sorted((_tensors(q.get(timeout=180)) for _ in range(world)), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -145,7 +151,8 @@ def _lowrank_worker(rank, world, port, out):
         tr.exchange_lowrank(dcol / world, gnorm, vis, radii)
         tr.wait_stats()
         tr.optimizer_step_lowrank(step, skip=({"opacity"} if step == 2 else ()))
-    out.put((rank, m.flat.detach().clone(), m.optimizer.exp_avg.clone(), m.optimizer.exp_avg_sq.clone(), m.optimizer.step_count))
+    out.put((rank, m.flat.detach().numpy().copy(), m.optimizer.exp_avg.numpy().copy(), m.optimizer.exp_avg_sq.numpy().copy(),
+             m.optimizer.step_count))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -161,7 +168,7 @@ def test_lowrank_exchange_two_ranks():
     procs = [ctx.Process(target=_lowrank_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    res = sorted((_tensors(q.get(timeout=180)) for _ in range(world)), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -1,0 +1,310 @@
+"""-m gpu: BASELINE.json's configurations at FULL size, the benchmarked raw-parameter path against the CPU oracle in ONE hop.
+
+  C3  2,000,000 Gaussians @1600x1200 (the bench.py workload, same scene / camera): render_raw + w3d_backward_raw, and the
+      fused backward+Adam kernel (w3d_backward_raw_adam) through the moments its first step leaves behind;
+  C2    500,000 Gaussians @1600x1200, same checks;
+  C4  FlashSplat contribution render @1600x1200 — a binary mask and a 300-label map — against the oracle's scatter,
+      summed over 36 views as run_3d_seg.py:91-97 does, and the labels multi_instance_opt derives from the sums.
+(C1 runs on the CPU: tests/test_c1_cpu_plumbing.py.  C5 needs eight GPUs: the driver's SCALE run.)
+
+Bars (north_star): images |dPSNR| <= 1e-3 dB; radii / visibility exact; gradients PER GAUSSIAN: p99.9 of the relative
+error <= 1e-4, and every Gaussian beyond that bound must be explained by a contributor-set flip — a (pixel, Gaussian)
+pair whose alpha sits on the 1/255 threshold (or a pixel whose transmittance sits on 1e-4) under the fast exp; those are
+counted from the images, not assumed.  The oracle accumulates per-Gaussian sums in double; reference-CUDA parity itself is
+UNPINNED (sources absent).
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import view_inputs, make_oracle, np_inputs, psnr
+from w3d_amd.synth import make_scene, make_cameras
+
+pytestmark = pytest.mark.gpu
+W, H = 1600, 1200
+NTHREADS = os.cpu_count() or 8
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fullsize_parity.jsonl")
+
+
+def _report(**kw):
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+
+
+def _model(sc, dev):
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    m.active_sh_degree = 3
+    m.training_setup(OptimizationParams())
+    return m
+
+
+def raw_grads_from_oracle(gref, sc):
+    """Chain the oracle's gradients w.r.t. the ACTIVATED inputs through the activations of reference
+    scene/gaussian_model.py:33-41 (exp, sigmoid, normalize, cat(dc, rest)) — float64 torch formulas."""
+    t = lambda a: torch.from_numpy(np.asarray(a)).double()  # noqa: E731
+    out = {"xyz": t(gref["means3D"])}
+    shs = t(gref["shs"])
+    out["f_dc"], out["f_rest"] = shs[:, :1], shs[:, 1:]
+    o = torch.sigmoid(sc.opacity.double())
+    out["opacity"] = t(gref["opacities"]).reshape(-1, 1) * o * (1 - o)
+    out["scaling"] = t(gref["scales"]) * torch.exp(sc.scaling.double())
+    r = sc.rotation.double()
+    n = r.norm(dim=1, keepdim=True)
+    q = r / n
+    gq = t(gref["rotations"])
+    out["rotation"] = (gq - q * (q * gq).sum(1, keepdim=True)) / n
+    return {k: v.numpy() for k, v in out.items()}
+
+
+def per_gaussian_error(got, ref):
+    """max_d |got - ref| / (max_d |ref| + floor) per Gaussian; floor = 1e-3 x the median magnitude over the Gaussians that
+    have a gradient at all (a relative error against a value ~0 means nothing)."""
+    got, ref = np.asarray(got, np.float64).reshape(len(ref), -1), np.asarray(ref, np.float64).reshape(len(ref), -1)
+    mag = np.abs(ref).max(1)
+    nz = mag[mag > 0]
+    floor = 1e-3 * (np.median(nz) if nz.size else 1.0)
+    return np.abs(got - ref).max(1) / (mag + floor)
+
+
+def flip_pixels(out, ref, nc_own, nc_ref):
+    """Pixels whose contributor set evidently differs between the two implementations: another last contributor, or a
+    colour / alpha difference far above fp32 noise (5e-5; rounding noise of the blend is ~1e-6)."""
+    d = np.abs(out["color"] - ref["color"]).max(0) > 5e-5
+    d |= np.abs(out["alpha"][0] - ref["alpha"][0]) > 5e-5
+    d |= nc_own != nc_ref
+    return int(d.sum())
+
+
+def check_images_fullsize(out, ref, tag):
+    rng = np.random.RandomState(0)
+    stats = {}
+    for k in ("color", "depth", "alpha"):
+        a, b = out[k], ref[k]
+        scale = max(1.0, float(np.abs(b).max()))
+        gt = np.clip(b / scale + 0.05 * rng.randn(*b.shape).astype(np.float32), 0, 1)
+        dp = abs(psnr(a / scale, gt) - psnr(b / scale, gt))
+        diff = np.abs(a - b)
+        stats[k] = dict(dpsnr=dp, max=float(diff.max()), frac_gt_2e4=float((diff > 2e-4 * scale).mean()))
+        assert dp <= 1e-3, f"{tag}{k}: PSNR differs by {dp:.2e} dB"
+        assert stats[k]["frac_gt_2e4"] <= 1e-4, f"{tag}{k}: {stats[k]['frac_gt_2e4']:.2e} of the pixels differ by more than 2e-4"
+    return stats
+
+
+def check_gradients_per_gaussian(got, want, vis, n_flip, tag, bulk=1e-4):
+    """got / want: dict block -> (P, ...) arrays.  p99.9 of the per-Gaussian relative error over the visible set <= bulk;
+    Gaussians beyond it at most a few per flip pixel (a flip moves the flipped Gaussian by a whole pixel's worth and the
+    ones behind it at that pixel by a 1/255-th); culled Gaussians exactly zero."""
+    stats = {}
+    for k, ref in want.items():
+        g = np.asarray(got[k]).reshape(ref.shape)
+        e = per_gaussian_error(g, ref)[vis]
+        n_out = int((e > bulk).sum())
+        stats[k] = dict(p50=float(np.percentile(e, 50)), p99=float(np.percentile(e, 99)), p999=float(np.percentile(e, 99.9)),
+                        max=float(e.max()), outliers=n_out)
+        assert stats[k]["p999"] <= bulk, f"{tag}grad {k}: p99.9 per-Gaussian rel err {stats[k]['p999']:.2e}"
+        assert n_out <= 4 * n_flip + 8, f"{tag}grad {k}: {n_out} Gaussians beyond {bulk:g} but only {n_flip} flip pixels"
+        assert np.all(g.reshape(len(ref), -1)[~vis] == 0), f"{tag}grad {k}: non-zero gradient on a culled Gaussian"
+    return stats
+
+
+def test_c1_size_through_the_dropin_module():
+    """C1's shape (10 k Gaussians, 400x300) through diff_gaussian_rasterization.GaussianRasterizer against the oracle (the
+    CPU side of C1 — the oracle alone, no GPU — is tests/test_c1_cpu_plumbing.py)."""
+    from test_gpu_parity import run_hip, check_images, check_integers, check_grads
+    sc = make_scene(10_000, seed=4, scale_mean=0.012)
+    cam = make_cameras(36, 400, 300)[3]
+    bg = (0.0, 0.0, 0.0)
+    d = view_inputs(sc, cam)
+    gc = np.random.RandomState(1).randn(3, 300, 400).astype(np.float32)
+    o = make_oracle(cam, bg, nthreads=NTHREADS)
+    ref = o.forward(**np_inputs(d))
+    gref = o.backward(gc, None, None)
+    out, g = run_hip(d, cam, bg, grads=(gc, None, None), tile_cull=False)
+    check_integers(out, o, ref)
+    check_images(out, ref, "[C1 size] ")
+    out, g = run_hip(d, cam, bg, grads=(gc, None, None), tile_cull=True)
+    check_images(out, ref, "[C1 size, culled] ")
+    check_grads(g, gref, ref["radii"] > 0, "[C1 size] ")
+    o.free()
+
+
+_cache = {}
+
+
+def oracle_view(P, cam_index, seed=0):
+    """Scene, camera, oracle forward + backward (random dL/dcolor) of one full-size view — computed once per configuration."""
+    key = (P, cam_index, seed)
+    if key not in _cache:
+        sc = make_scene(P, seed=seed)
+        cam = make_cameras(36, W, H)[cam_index]
+        bg = (0.0, 0.0, 0.0)
+        o = make_oracle(cam, bg, nthreads=NTHREADS)
+        ref = o.forward(**np_inputs(view_inputs(sc, cam)))
+        gc = np.random.RandomState(3).randn(3, H, W).astype(np.float32)
+        gref = o.backward(gc, None, None)
+        ft, nc = o.pixel_state()
+        o.free()
+        _cache[key] = dict(sc=sc, cam=cam, bg=bg, ref=ref, gc=gc, gref=gref, nc=nc, want=raw_grads_from_oracle(gref, sc))
+    return _cache[key]
+
+
+@pytest.mark.parametrize("P,cam_index,name", [(2_000_000, 0, "C3"), (500_000, 5, "C2")])
+def test_raw_path_full_size_against_oracle(P, cam_index, name):
+    from w3d_amd.fused_step import render_raw, backward_raw
+    from w3d_amd.rasterizer import debug_pixel_state
+    dev = torch.device("cuda:0")
+    c = oracle_view(P, cam_index)
+    sc, cam, ref, want = c["sc"], c["cam"].to(dev), c["ref"], c["want"]
+    m = _model(sc, dev)
+    pkg = render_raw(cam, m, torch.zeros(3, device=dev), sync=True)
+    gnorm, m2d = backward_raw(m, pkg["handle"], torch.as_tensor(c["gc"], device=dev), want_norm=True, want_means2D=True)
+    out = dict(color=pkg["render"].cpu().numpy(), depth=pkg["depth"].cpu().numpy(), alpha=pkg["alpha"].cpu().numpy())
+    radii = pkg["radii"].cpu().numpy()
+    np.testing.assert_array_equal(radii, ref["radii"])                      # integer work: exact
+    vis = ref["radii"] > 0
+    assert 0.3 * P < vis.sum() < P
+    tag = f"[{name} P={P}] "
+    img_stats = check_images_fullsize(out, ref, tag)
+    _, nc_own = debug_pixel_state({"view": pkg["handle"]["view"], "P": P, "state": pkg["handle"]["state"]})
+    n_flip = flip_pixels(out, ref, nc_own.cpu().numpy().astype(np.uint32), c["nc"])
+    assert n_flip <= 2e-4 * W * H, f"{tag}{n_flip} pixels with a different contributor set"
+    got = {k: m.grad_view(k).detach().cpu().numpy() for k in want}
+    g_stats = check_gradients_per_gaussian(got, want, vis, n_flip, tag)
+    # the densification statistic itself (scene/gaussian_model.py:462): ||means2D.grad[:, :2]|| per visible Gaussian
+    n_ref = np.linalg.norm(c["gref"]["means2D"][:, :2].astype(np.float64), axis=1)
+    n_own = gnorm.cpu().numpy().astype(np.float64)
+    assert np.array_equal(m2d.cpu().numpy()[:, 2], np.zeros(P, np.float32)) and np.all(n_own[~vis] == 0)
+    e = (np.abs(n_own - n_ref) / (n_ref + 1e-3 * np.median(n_ref[vis])))[vis]
+    d_stats = dict(p50=float(np.percentile(e, 50)), p999=float(np.percentile(e, 99.9)), max=float(e.max()),
+                   outliers=int((e > 1e-4).sum()))
+    assert d_stats["p999"] <= 1e-4 and d_stats["outliers"] <= 4 * n_flip + 8, f"{tag}densification norms {d_stats}"
+    _report(test="raw_vs_oracle", config=name, P=P, visible=int(vis.sum()), num_rendered=pkg["handle"]["num_rendered"],
+            flip_pixels=n_flip, images=img_stats, grads=g_stats, densify_norm=d_stats)
+
+
+@pytest.mark.parametrize("P,cam_index,name", [(2_000_000, 0, "C3"), (500_000, 5, "C2")])
+def test_fused_backward_adam_full_size_against_oracle(P, cam_index, name):
+    """w3d_backward_raw_adam writes no gradients: its FIRST step from zero moments leaves exp_avg = (1 - beta1) * g, so the
+    gradient the kernel applied is read back from the moment buffer and held against the oracle; the parameter update is
+    checked against torch.optim.Adam's formula on the oracle gradient."""
+    from w3d_amd.fused_step import render_raw, backward_raw_adam, finish
+    dev = torch.device("cuda:0")
+    c = oracle_view(P, cam_index)
+    sc, cam, ref, want = c["sc"], c["cam"].to(dev), c["ref"], c["want"]
+    m = _model(sc, dev)
+    m.update_learning_rate(1)
+    before = m.flat.detach().clone()
+    pkg = render_raw(cam, m, torch.zeros(3, device=dev), sync=True)
+    backward_raw_adam(m, pkg["handle"], torch.as_tensor(c["gc"], device=dev), want_norm=False, update_stats=True)
+    assert finish(pkg["handle"])
+    m.optimizer.note_fused_step()
+    vis = ref["radii"] > 0
+    b1, b2 = m.optimizer.betas
+    mom = m.optimizer.moments()
+    got = {k: (mom[k][0] / (1.0 - b1)).cpu().numpy() for k in want}
+    out = dict(color=pkg["render"].cpu().numpy(), alpha=pkg["alpha"].cpu().numpy())
+    n_flip = flip_pixels(out, ref, c["nc"], c["nc"])
+    tag = f"[{name} P={P} fused Adam] "
+    g_stats = check_gradients_per_gaussian(got, want, vis, n_flip, tag)
+    # Adam's first step moves every parameter with a non-zero gradient by lr * g / (|g| + eps): +-lr
+    sl = m.block_slices()
+    after = m.flat.detach()
+    vis_dev = torch.from_numpy(vis).to(dev)
+    for k, (a, b) in sl.items():
+        g = torch.from_numpy(want[k]).reshape(P, -1).to(dev)
+        step = (before[a:b] - after[a:b]).double().reshape(P, -1)
+        lr = m.optimizer.lrs[k]
+        big = g.abs() > 1e-2 * g.abs()[vis_dev].median()          # (the sign of a near-zero sum is noise on both sides)
+        bad = ((step - lr * torch.sign(g)).abs() > 1e-3 * lr) & big
+        assert float(bad.double().mean()) <= 1e-4, f"{tag}{k}: {int(bad.sum())} parameters moved by something else than lr*sign(g)"
+        assert float(step[~vis_dev].abs().max()) == 0.0, f"{tag}{k}: a culled Gaussian's parameters moved"
+    # the fused statistics (add_densification_stats + max_radii2D, train_vanilla_3dgs.py:102-103)
+    assert torch.equal(m.denom.reshape(-1).cpu(), torch.from_numpy(vis.astype(np.float32)))
+    assert torch.equal(m.max_radii2D.cpu(), torch.from_numpy(ref["radii"].astype(np.float32)))
+    _report(test="raw_adam_vs_oracle", config=name, P=P, flip_pixels=n_flip, grads=g_stats)
+
+
+def _wheat_head_labels(K, seed=5):
+    """A (H, W) label image shaped like a plot's instance masks: K discs of 14-34 px radius (label k) over background 0;
+    later discs overwrite earlier ones, so label boundaries cut tiles and three labels may meet in one."""
+    rng = np.random.RandomState(seed)
+    lab = np.zeros((H, W), np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for k in range(1, K + 1):
+        cx, cy, r = rng.randint(0, W), rng.randint(0, H), rng.randint(14, 35)
+        y0, y1, x0, x1 = max(0, cy - r), min(H, cy + r + 1), max(0, cx - r), min(W, cx + r + 1)
+        sub = (xx[y0:y1, x0:x1] - cx) ** 2 + (yy[y0:y1, x0:x1] - cy) ** 2 <= r * r
+        lab[y0:y1, x0:x1][sub] = k
+    return lab
+
+
+@pytest.mark.parametrize("K", [1, 300])
+def test_c4_flashsplat_counts_full_size(K):
+    """run_3d_seg.py:88-97 / eval_wheatgs.py:57-64 at full resolution: used_count (K+1, P) of flashsplat_render summed over
+    the 36 views against the oracle's scatter, then the labels multi_instance_opt derives from both sums."""
+    from w3d_amd.gaussian_renderer import flashsplat_render
+    from w3d_amd.segmentation import multi_instance_opt
+    from w3d_amd.train import PipelineParams
+    dev = torch.device("cuda:0")
+    P, n_views = 500_000, 36
+    sc = make_scene(P, seed=2)
+    cams = make_cameras(n_views, W, H)
+    m = _model(sc, dev)
+    bg = torch.zeros(3, device=dev)
+    if K == 1:
+        yy, xx = np.mgrid[0:H, 0:W]
+        labels = (((xx - 700) ** 2 + (yy - 500) ** 2) < 300 ** 2).astype(np.float32)
+    else:
+        labels = _wheat_head_labels(K)
+    lab_dev = torch.as_tensor(labels, device=dev)
+    total = torch.zeros(K + 1, P, device=dev, dtype=torch.float64)
+    total_ref = np.zeros((K + 1, P), np.float64)
+    worst_view = 0.0
+    for vi, cam in enumerate(cams):
+        with torch.no_grad():
+            pkg = flashsplat_render(cam.to(dev), m, PipelineParams(), bg, gt_mask=lab_dev, obj_num=K)
+        uc = pkg["used_count"]
+        assert tuple(uc.shape) == (K + 1, P)
+        total += uc.double()
+        if vi % 6 == 0:                       # six of the 36 views also individually, and completely, against the oracle
+            o = make_oracle(cam, (0.0, 0.0, 0.0), nthreads=NTHREADS)
+            ref = o.forward(**np_inputs(view_inputs(sc, cam)), gt_mask=labels, num_obj=K)
+            o.free()
+            np.testing.assert_array_equal(pkg["radii"].cpu().numpy(), ref["radii"])
+            u = uc.cpu().numpy()
+            err = float(np.abs(u - ref["used_count"]).max() / ref["used_count"].max())
+            worst_view = max(worst_view, err)
+            assert err <= 1e-4, f"view {vi}: used_count rel err {err:.2e}"
+            # per (label, Gaussian) entries: relative where the count is significant
+            sig = ref["used_count"] > 1e-2
+            assert float((np.abs(u - ref["used_count"])[sig] / ref["used_count"][sig]).max()) <= 1e-3
+            # the weights of all labels of a Gaussian add up to its total blending weight, and over the image to alpha
+            a_sum = float(pkg["alpha"].double().sum())
+            assert abs(float(uc.double().sum()) - a_sum) <= 1e-4 * a_sum
+            assert (pkg["contrib_num"].cpu().numpy() != ref["contrib_num"]).mean() <= 1e-4
+            total_ref += ref["used_count"].astype(np.float64)
+    # sum over the oracle-checked views: the additive counts and the labels derived from them
+    sub_total = torch.zeros_like(total)
+    for vi in range(0, n_views, 6):
+        with torch.no_grad():
+            sub_total += flashsplat_render(cams[vi].to(dev), m, PipelineParams(), bg, gt_mask=lab_dev, obj_num=K)["used_count"].double()
+    got, want = sub_total.cpu().numpy(), total_ref
+    err = float(np.abs(got - want).max() / want.max())
+    assert err <= 1e-4, f"summed used_count rel err {err:.2e}"
+    la = multi_instance_opt(torch.from_numpy(got).float()).numpy()
+    lb = multi_instance_opt(torch.from_numpy(want).float()).numpy()
+    # a label can only differ where own and rest scores tie to within the count error
+    n_diff = int((la != lb).sum())
+    assert n_diff <= 1e-5 * la.size, f"{n_diff} of {la.size} labels differ"
+    assert float(total.sum()) > 0
+    _report(test="c4_flashsplat", K=K, P=P, views=n_views, worst_view_rel_err=worst_view, summed_rel_err=err, labels_differ=n_diff)

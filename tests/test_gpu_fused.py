@@ -107,6 +107,8 @@ def test_fused_raw_step_equals_autograd_step(deg, W, H):
         cam.original_image = torch.rand(3, H, W, generator=g).to(dev)
     bg = torch.tensor([0.1, 0.0, 0.2], device=dev)
     sc = make_scene(6000, seed=9, scale_mean=0.02)
+    import w3d_amd.gaussian_renderer as gr
+    gr.RAW_AUTOGRAD = False              # the drop-in side marshals activated tensors, as the reference's render() does
     models, grads, images = [], [], []
     for fused in (False, True):
         m = GaussianModel(3, device=dev)
@@ -131,6 +133,7 @@ def test_fused_raw_step_equals_autograd_step(deg, W, H):
         for it in range(2, 6):
             tr.step(it)
         models.append((m, l0, stats1))
+    gr.RAW_AUTOGRAD = True
     (ma, la, sa), (mb, lb, sb) = models
     assert abs(la - lb) <= 1e-6
     assert float((images[0] - images[1]).abs().max()) <= 2e-5       # torch vs in-kernel exp/sigmoid/normalize
@@ -183,7 +186,7 @@ def test_speculative_list_capacity_overflow_is_repeated(fused_adam):
         fused_step.render_raw = counting
         try:
             for it in range(1, 5):
-                fused_step._capacity.known = 100 if sabotage else 10_000_000      # far too small / generous
+                fused_step.list_capacity(dev, H, W).known = 100 if sabotage else 10_000_000      # far too small / generous
                 tr.step(it)
         finally:
             fused_step.render_raw = orig
@@ -195,79 +198,6 @@ def test_speculative_list_capacity_overflow_is_repeated(fused_adam):
     diff = (finals[0] - finals[1]).abs()
     assert float((diff > 1e-5).float().mean()) <= 1e-3 and float(diff.max()) <= 0.2
     assert float(m.denom.max()) > 0
-
-
-def test_depth_layered_forward_is_bit_identical_and_backward_matches():
-    """depth_layers = 2 (front layer, then only the still-open tiles) against the single-pass forward:
-    same bits in every output image and in the per-pixel state, same gradients up to atomic ordering."""
-    from w3d_amd import fused_step
-    from w3d_amd.fused_step import render_raw, backward_raw, finish
-    from w3d_amd.synth import make_scene, make_cameras
-    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
-    dev = torch.device("cuda:0")
-    for (P, W, H, scale) in ((40_000, 320, 240, 0.012), (3000, 200, 152, 0.05), (300_000, 800, 600, 0.006)):
-        cams = [c.to(dev) for c in make_cameras(3, W, H)]
-        sc = make_scene(P, seed=P, scale_mean=scale)
-        m = GaussianModel(3, device=dev)
-        m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
-        m.active_sh_degree = 3
-        m.training_setup(OptimizationParams())
-        bg = torch.tensor([0.2, 0.1, 0.0], device=dev)
-        g = torch.Generator().manual_seed(P)
-        dimg = torch.randn(3, H, W, generator=g).to(dev)
-        for cam in cams[:2]:
-            ref = render_raw(cam, m, bg, sync=True)                       # single pass, exact list size
-            backward_raw(m, ref["handle"], dimg)
-            gref = m.flat_grad.clone()
-            fused_step._capacity.known = ref["handle"]["num_rendered"]   # generous guess -> async + layered
-            fused_step.DEPTH_LAYERS = True
-            try:
-                lay = render_raw(cam, m, bg, sync=False)
-            finally:
-                fused_step.DEPTH_LAYERS = False
-            assert lay["handle"]["view"].c.depth_layers == 2
-            backward_raw(m, lay["handle"], dimg)
-            assert finish(lay["handle"])
-            glay = m.flat_grad.clone()
-            for k in ("render", "depth", "alpha", "radii"):
-                assert torch.equal(ref[k], lay[k]), k
-            # the layered forward bins fewer instances (closed tiles drop out of the back layer)
-            assert lay["handle"]["num_rendered"] <= ref["handle"]["num_rendered"]
-            err = float((glay - gref).abs().max() / gref.abs().max())
-            assert err <= 1e-4, err
-
-
-def test_depth_cuts_are_exact_or_repeated():
-    """Speculative per-tile list truncation (w3d_view.tile_depth_cut): with cuts from an earlier visit the
-    outputs are bit-identical to the uncut render; a cut that is too shallow is detected (suspect tiles)."""
-    from w3d_amd import fused_step
-    from w3d_amd.fused_step import render_raw, finish
-    from w3d_amd.synth import make_scene, make_cameras
-    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
-    dev = torch.device("cuda:0")
-    P, W, H = 400_000, 480, 360
-    cam = make_cameras(3, W, H)[1].to(dev)
-    sc = make_scene(P, seed=7, scale_mean=0.012)
-    m = GaussianModel(3, device=dev)
-    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
-    m.active_sh_degree = 3
-    m.training_setup(OptimizationParams())
-    bg = torch.zeros(3, device=dev)
-    fused_step.DEPTH_LAYERS = False
-    ref = render_raw(cam, m, bg, sync=True)
-    fused_step._capacity.known = ref["handle"]["num_rendered"]
-    first = render_raw(cam, m, bg, sync=False, want_cut=True)
-    assert finish(first["handle"])
-    cuts = first["handle"]["depth_cut_out"]
-    assert torch.isfinite(cuts).float().mean() > 0.5            # most tiles saturate in this dense scene
-    second = render_raw(cam, m, bg, sync=False, depth_cut=cuts, want_cut=True)
-    assert finish(second["handle"]) and second["handle"]["suspect_tiles"] == 0
-    assert second["handle"]["num_rendered"] < 0.99 * first["handle"]["num_rendered"]    # lists really were truncated
-    for k in ("render", "depth", "alpha", "radii"):
-        assert torch.equal(ref[k], second[k]), k
-    # cuts that are far too shallow must be reported, not silently rendered
-    bad = render_raw(cam, m, bg, sync=False, depth_cut=torch.full_like(cuts, 0.5))
-    assert not finish(bad["handle"]) and bad["handle"]["suspect_tiles"] > 0
 
 
 def test_training_with_densification_prune_and_opacity_reset():

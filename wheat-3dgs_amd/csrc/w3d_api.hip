@@ -75,13 +75,9 @@ static int check_variants(const w3d_view *v, const float *shs, const float *colo
 
 // depth sort, tile counting of the first (or only) layer, optional host read-back of the counters
 static int finish_stage1(const W3DLayout &L, const w3d_view &view, char *st, char *sc, uint32_t *counts_host, hipStream_t stream) {
-    if (view.depth_layers == 2 && counts_host) {
-        w3d_set_error("depth_layers = 2 needs the asynchronous forward (counts_host must be NULL)");
-        return W3D_ERR_INVALID;
-    }
     int rc = w3d_launch_depth_sort(L, view, st, sc, stream);
     if (rc) return rc;
-    rc = w3d_launch_tile_count(L, view, st, sc, view.depth_layers == 2 ? 1 : 0, stream);
+    rc = w3d_launch_tile_count(L, view, st, sc, stream);
     if (rc) return rc;
     if (counts_host) {
         W3D_HIP_CHECK(hipMemcpyAsync(counts_host, st + L.o_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -175,27 +171,10 @@ int w3d_forward_stage2(const w3d_view *view, int32_t P, void *state, void *scrat
     if (list_capacity > 0 && !point_list) { w3d_set_error("point_list is NULL"); return W3D_ERR_INVALID; }
     if (gt_mask && used_count && num_obj < 0) { w3d_set_error("num_obj must be >= 0"); return W3D_ERR_INVALID; }
     char *st = static_cast<char *>(state), *sc = static_cast<char *>(scratch);
-    const bool flash = gt_mask || used_count || contrib_num || proj_xy || gs_depth;
-    if (view->depth_layers == 2 && !flash) {
-        // front layer, then only the tiles it left open
-        for (int layer = 1; layer <= 2; layer++) {
-            if (layer == 2) {
-                rc = w3d_launch_tile_count(L, *view, st, sc, 2, stream);
-                if (rc) return rc;
-            }
-            rc = w3d_launch_fill_lists(L, *view, st, sc, point_list, list_capacity, layer, stream);
-            if (rc) return rc;
-            rc = w3d_launch_render(L, *view, st, point_list, list_capacity, out_color, out_depth, out_alpha, nullptr, 0,
-                                   nullptr, nullptr, layer, stream);
-            if (rc) return rc;
-        }
-        return W3D_OK;
-    }
-    if (view->depth_layers == 2) { w3d_set_error("depth_layers = 2 is not available for the FlashSplat outputs"); return W3D_ERR_UNSUPPORTED; }
-    rc = w3d_launch_fill_lists(L, *view, st, sc, point_list, list_capacity, 0, stream);
+    rc = w3d_launch_fill_lists(L, *view, st, sc, point_list, list_capacity, stream);
     if (rc) return rc;
     rc = w3d_launch_render(L, *view, st, point_list, list_capacity, out_color, out_depth, out_alpha, gt_mask, num_obj,
-                           used_count, contrib_num, 0, stream);
+                           used_count, contrib_num, stream);
     if (rc) return rc;
     if (proj_xy || gs_depth) {
         // radii are not kept in the state; visibility is re-derived from the tile rectangle
@@ -217,9 +196,8 @@ int w3d_flash_reblend(const w3d_view *view, int32_t P, void *state, const uint32
     if (!state || !out_color || !out_depth || !out_alpha) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
     if (list_capacity > 0 && !point_list) { w3d_set_error("point_list is NULL"); return W3D_ERR_INVALID; }
     if (gt_mask && used_count && num_obj < 0) { w3d_set_error("num_obj must be >= 0"); return W3D_ERR_INVALID; }
-    if (view->depth_layers == 2 || view->tile_depth_cut) { w3d_set_error("reblend needs the plain single-pass lists"); return W3D_ERR_UNSUPPORTED; }
     return w3d_launch_render(L, *view, static_cast<char *>(state), point_list, list_capacity, out_color, out_depth, out_alpha,
-                             gt_mask, num_obj, used_count, contrib_num, 0, stream);
+                             gt_mask, num_obj, used_count, contrib_num, stream);
 }
 
 int w3d_backward_sizes(int32_t P, uint64_t *scratch_bytes) {
@@ -334,9 +312,11 @@ int w3d_backward_raw_adam(const w3d_view *view, int32_t P, const w3d_raw_blocks 
     if (rc) { w3d_set_error("bad sizes"); return rc; }
     if (P == 0) return W3D_OK;
     if (!state || !scratch || !dL_dcolor || !prm || !adam) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
-    if (!(adam->bias_correction1 > 0.f) || !(adam->bias_correction2 > 0.f)) {
-        w3d_set_error("fused Adam: bias corrections must be positive (step >= 1)");
-        return W3D_ERR_INVALID;
+    for (int i = 0; i < 6; i++) {
+        if (!adam->skip[i] && (!(adam->bias_correction1[i] > 0.f) || !(adam->bias_correction2[i] > 0.f))) {
+            w3d_set_error("fused Adam: bias corrections must be positive (step >= 1)");
+            return W3D_ERR_INVALID;
+        }
     }
     if (stats && stats->xyz_gradient_accum && (!stats->denom || !stats->max_radii2D || !stats->radii)) {
         w3d_set_error("fused statistics need accum, denom, max_radii2D and radii together");

@@ -185,10 +185,6 @@ gather_sorted_kernel(const uint32_t *__restrict__ sorted_ids, const uint32_t *__
     }
 }
 
-// LAYER 0: all chunks.  LAYER 1 / 2: front / back depth layer (chunk ranges in counters[4..7], see
-// layer_split_kernel); the back layer only bins into tiles that are still open after the front layer was
-// blended (tile_open).
-//
 // One wave per (chunk, band of tile rows).  The wave streams the chunk's depth-ordered records, keeps the
 // ones whose rect reaches into its band (about one in eight) in a 128-entry LDS ring, and whenever 64 are
 // queued it bins all 64 AT ONCE, one record per lane:
@@ -209,14 +205,13 @@ gather_sorted_kernel(const uint32_t *__restrict__ sorted_ids, const uint32_t *__
 #define W3D_WW 4          // (chunk, band) waves per workgroup of the walk: the 4 band-waves of a chunk share its records in L1
                           // (measured fill: 1 wave 0.255 ms, 2 -> 0.198, 4 -> 0.172, 8 -> 0.202, 16 -> 0.234)
 #endif
-template <int MODE, bool CULL, int LAYER>
+template <int MODE, bool CULL>
 __global__ void __launch_bounds__(64 * W3D_WW)
 chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_mask,
                   const uint32_t *__restrict__ counters,
                   uint32_t chunk, uint32_t C, uint32_t T, uint32_t gx, uint32_t gy, uint32_t band_rows,
                   uint16_t *__restrict__ cnt, const uint32_t *__restrict__ off, uint32_t *__restrict__ point_list,
-                  uint64_t capacity, const uint8_t *__restrict__ tile_open, const float *__restrict__ depth_cut,
-                  uint32_t wave_bytes) {
+                  uint64_t capacity, uint32_t wave_bytes) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // the 4 waves of a workgroup walk the SAME chunk for 4 neighbouring bands: they stream the same records at
@@ -224,13 +219,12 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
     const uint32_t c = blockIdx.x;
     const uint32_t band = blockIdx.y * W3D_WW + wv;
     if (c >= C || band * band_rows >= gy) return;
-    if (LAYER != 0 && (c < counters[2 + 2 * LAYER] || c >= counters[3 + 2 * LAYER])) return;
     const uint32_t y0 = band * band_rows, y1 = min(gy, y0 + band_rows);
     const uint32_t tb0 = y0 * gx, Tb = (y1 - y0) * gx;           // first tile / tile count of the band
     const uint32_t Tbpad = (band_rows * gx + 63u) & ~63u;
     const uint32_t V = counters[0];
     (void)T;
-    // per-wave LDS: [ring 128 x 24 B][MODE 1: bitmap 8 B x Tbpad][counters / cursors][open bytes][depth cuts]
+    // per-wave LDS: [ring 128 x 24 B][MODE 1: bitmap 8 B x Tbpad][counters / cursors]
     unsigned char *base_w = smem + (size_t)wv * wave_bytes;
     uint4 *qa = reinterpret_cast<uint4 *>(base_w);               // raw records {id, rect lo, rect hi, depth}
     uint2 *qb = reinterpret_cast<uint2 *>(qa + W3D_WALK_QUEUE);   // their tile masks
@@ -238,19 +232,9 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
     unsigned long long *bm = reinterpret_cast<unsigned long long *>(p);
     if (MODE == 1) p += (size_t)Tbpad * 8;
     uint32_t *h32 = reinterpret_cast<uint32_t *>(p);             // MODE 0: Tbpad/2 words of two u16 counters; MODE 1: cursors
-    p += (size_t)Tbpad * (MODE == 0 ? 2 : 4);
-    uint8_t *open8 = p;
-    if (LAYER == 2) p += Tbpad;
-    float *cut32 = reinterpret_cast<float *>(p);
-    const bool has_cut = depth_cut != nullptr;
-    if (LAYER == 2)
-        for (uint32_t t = lane; t < Tb; t += 64) open8[t] = tile_open[tb0 + t];
-    if (has_cut)
-        for (uint32_t t = lane; t < Tb; t += 64) cut32[t] = depth_cut[tb0 + t];
-    // LAYER 0: the chunks partition the V VISIBLE records evenly (V is only known on the device), not the P slots the
-    // host sized the matrices for — all C chunk-waves of a band get work, each a 1/C-th of it.  (The layered mode keeps
-    // the host's chunk size: its layer boundaries are chunk indices computed from it.)
-    if (LAYER == 0) chunk = min(chunk, max(64u, ((V + C - 1u) / C + 63u) & ~63u));
+    // the chunks partition the V VISIBLE records evenly (V is only known on the device), not the P slots the host sized
+    // the matrices for — all C chunk-waves of a band get work, each a 1/C-th of it
+    chunk = min(chunk, max(64u, ((V + C - 1u) / C + 63u) & ~63u));
     const uint32_t s_beg = min(V, c * chunk), s_end = min(V, s_beg + chunk);
     // the first records are requested before the LDS set-up below, which hides their latency; NB 64-record
     // batches are kept in flight (rotating registers, so the loop body — and process() — exists once)
@@ -308,15 +292,8 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         // floor(k / w) == (k * magic) >> 16 for k < 64, w <= 64 with magic = floor(65536 / w) + 1; through the float
         // reciprocal (65536 / w is either an integer, where rcp is exact enough, or >= 1/64 away from one)
         const uint32_t magic = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)max(w, 1u)) + 0.004f) + 1u;
-        const float depth = __uint_as_float(er.w);
         const uint4 eb = make_uint4((uint32_t)rm, (uint32_t)(rm >> 32), er.w, er.z);     // (layout the whole-wave part reads)
         const uint64_t coop = w3d_ballot(lane < nq && kind != 0u);
-        auto tile_ok = [&](uint32_t tl, float d) -> bool {
-            bool ok = true;
-            if (LAYER == 2) ok = open8[tl] != 0;
-            if (has_cut) ok = ok && d <= cut32[tl];
-            return ok;
-        };
         // lane-parallel part: the (at most W3D_WALK_SMALL) tiles of this lane's record, derived once and kept in registers
         constexpr uint32_t NONE = 0xFFFFFFFFu;
         uint32_t tls[W3D_WALK_SMALL];
@@ -337,7 +314,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                 m &= m - 1ull;
                 const uint32_t ty = __umul24(k, magic) >> 16;
                 const uint32_t tl = base + k + __umul24(ty, rowskip);
-                tls[i] = (v && tile_ok(v ? tl : 0u, depth)) ? tl : NONE;
+                tls[i] = v ? tl : NONE;
             }
         }
         // whole-wave part: records with many tiles, one at a time, lanes <-> tiles.  op(tile index in band, ring position, id)
@@ -347,12 +324,11 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                 const uint32_t j = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
                 todo &= todo - 1ull;
                 const uint32_t jg = RL(g, j), jw = RL(w, j), jminx = RL(minx, j), jminy = RL(miny, j);
-                const float jd = __uint_as_float(RL(eb.z, j));
                 if (RL(kind, j) == 1u) {
                     const uint64_t jm = (uint64_t)RL(eb.x, j) | ((uint64_t)RL(eb.y, j) << 32);
                     const uint32_t ty = __umul24(lane, RL(magic, j)) >> 16;
                     const uint32_t tl = __umul24(jminy + ty - y0, gx) + jminx + (lane - __umul24(ty, jw));
-                    if (((jm >> lane) & 1ull) && tile_ok(tl, jd)) op(tl, j, jg);
+                    if ((jm >> lane) & 1ull) op(tl, j, jg);
                 } else {
                     // rect of more than 64 tiles (never culled): rows of the band only, generic division
                     const uint32_t hi = RL(eb.w, j), jmaxx = hi & 0xFFFFu, jmaxy = hi >> 16;
@@ -361,7 +337,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                     for (uint32_t kb = 0; kb < n; kb += 64) {
                         const uint32_t k = kb + lane;
                         const uint32_t ty = k / ww, tl = (r0 + ty - y0) * gx + jminx + (k - ty * ww);
-                        if (k < n && tile_ok(tl, jd)) op(tl, j, jg);
+                        if (k < n) op(tl, j, jg);
                     }
                 }
             }
@@ -455,36 +431,24 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
 }
 
 // ------------------------------------------------------------------------------ offset scan
-// The three scan kernels work on the chunk range [lo, hi) of one depth layer (counters[rng], counters[rng+1];
-// rng = 0xFFFFFFFF: all chunks).
-__device__ __forceinline__ void layer_range(const uint32_t *counters, uint32_t rng, uint32_t C, uint32_t &lo, uint32_t &hi) {
-    lo = 0; hi = C;
-    if (rng != 0xFFFFFFFFu) { lo = counters[rng]; hi = min(C, counters[rng + 1]); }
-}
-
 // part[sg][t] = sum over the chunks of segment sg of cnt[c][t]
 __global__ void __launch_bounds__(256)
-seg_sum_kernel(const uint16_t *__restrict__ cnt, uint32_t C, uint32_t T, uint32_t seg, uint32_t *__restrict__ part,
-               const uint32_t *__restrict__ counters, uint32_t rng) {
+seg_sum_kernel(const uint16_t *__restrict__ cnt, uint32_t C, uint32_t T, uint32_t seg, uint32_t *__restrict__ part) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, sg = blockIdx.y;
     if (t >= T) return;
-    uint32_t lo, hi;
-    layer_range(counters, rng, C, lo, hi);
-    const uint32_t c0 = max(sg * seg, lo), c1 = min(min(C, sg * seg + seg), hi);
+    const uint32_t c0 = sg * seg, c1 = min(C, sg * seg + seg);
     uint32_t s = 0;
 #pragma unroll 16
     for (uint32_t c = c0; c < c1; c++) s += cnt[(size_t)c * T + t];      // independent loads: keep many in flight
     part[(size_t)sg * T + t] = s;
 }
 
-// one block: totals per tile (coalesced over tiles) -> exclusive scan -> tile_start[T+1] (absolute list
-// positions, starting at `base_from` ? counters[1] : 0); counters[1] = end of the lists so far.
+// one block: totals per tile (coalesced over tiles) -> exclusive scan -> tile_start[T+1]; counters[1] = total list length
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, uint32_t *__restrict__ tile_start,
-                 uint32_t *__restrict__ counters, int append) {
+                 uint32_t *__restrict__ counters) {
     __shared__ uint32_t wave_tot[17];
-    uint32_t carry = append ? counters[1] : 0u;
-    __syncthreads();
+    uint32_t carry = 0u;
     for (uint32_t base = 0; base < T; base += 1024) {
         const uint32_t t = base + threadIdx.x;
         uint32_t v = 0;
@@ -499,10 +463,6 @@ tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, u
     }
     if (threadIdx.x == 0) {
         tile_start[T] = carry;
-        if (!append) {
-            counters[2] = carry;                // length of the front layer's lists
-            counters[8] = 0;                    // tiles whose truncated list ended unsaturated (render_fwd, depth cuts)
-        }
         counters[1] = carry;
     }
 }
@@ -510,13 +470,10 @@ tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, u
 // off[c][t] = start of chunk c's entries inside tile t's list
 __global__ void __launch_bounds__(256)
 chunk_off_kernel(const uint16_t *__restrict__ cnt, const uint32_t *__restrict__ part, const uint32_t *__restrict__ tile_start,
-                 uint32_t C, uint32_t T, uint32_t seg, uint32_t *__restrict__ off, const uint32_t *__restrict__ counters,
-                 uint32_t rng) {
+                 uint32_t C, uint32_t T, uint32_t seg, uint32_t *__restrict__ off) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, sg = blockIdx.y;
     if (t >= T) return;
-    uint32_t lo, hi;
-    layer_range(counters, rng, C, lo, hi);
-    const uint32_t c0 = max(sg * seg, lo), c1 = min(min(C, sg * seg + seg), hi);
+    const uint32_t c0 = sg * seg, c1 = min(C, sg * seg + seg);
     uint32_t run = tile_start[t];
     for (uint32_t s = 0; s < sg; s++) run += part[(size_t)s * T + t];
     uint32_t c = c0;
@@ -533,20 +490,6 @@ chunk_off_kernel(const uint16_t *__restrict__ cnt, const uint32_t *__restrict__ 
     }
 }
 
-// Split of the depth-ordered chunks into a front layer [0, cA) and a back layer [cA, nact):
-// counters[4..5] = front range, counters[6..7] = back range.  The front layer takes `front_256`/256 of the
-// chunks that hold visible Gaussians (at least one).
-__global__ void layer_split_kernel(uint32_t *__restrict__ counters, uint32_t chunk, uint32_t front_256) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const uint32_t V = counters[0];
-        const uint32_t nact = (V + chunk - 1) / chunk;
-        uint32_t cA = (nact * front_256 + 255u) >> 8;
-        if (cA > nact) cA = nact;
-        counters[4] = 0; counters[5] = cA; counters[6] = cA; counters[7] = nact;
-        counters[8] = 0;      // tiles whose truncated list ended unsaturated (render_fwd, depth cuts)
-    }
-}
-
 __global__ void copy_ranges_kernel(const uint32_t *__restrict__ tile_start, uint32_t T, uint32_t *__restrict__ out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < T) { out[2 * t] = tile_start[t]; out[2 * t + 1] = tile_start[t + 1]; }
@@ -560,8 +503,6 @@ W3DBands w3d_pick_bands(const W3DLayout &L, int mode) {
     W3DBands b;
     uint32_t band_tiles = mode == 0 ? 1024u : 320u;  // tiles per band (the fill pass holds 12 B of LDS per tile, the count pass 2 B;
                                                      // measured fill at 1600x1200: 200 -> 0.188 ms, 300 -> 0.171, 500 -> 0.179, 700 -> 0.193)
-    if (const char *e = getenv(mode == 0 ? "W3D_TUNE_BAND_TILES" : "W3D_TUNE_BAND_TILES_FILL"))
-        band_tiles = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : band_tiles;
     uint32_t rows = band_tiles / (uint32_t)L.gx;
     if (rows < 1) rows = 1;
     if (rows > (uint32_t)L.gy) rows = (uint32_t)L.gy;
@@ -572,9 +513,7 @@ W3DBands w3d_pick_bands(const W3DLayout &L, int mode) {
 }
 }  // namespace
 
-#define W3D_FRONT_LAYER_256 72   // front depth layer = 72/256 of the chunks that hold visible Gaussians
-
-// stable depth sort of the Gaussians + depth-ordered packed records (+ the layer split)
+// stable depth sort of the Gaussians + depth-ordered packed records
 int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream) {
     uint32_t *counters = reinterpret_cast<uint32_t *>(state + L.o_counters);
     uint32_t *keys[2] = {reinterpret_cast<uint32_t *>(scratch + L.s_keys0), reinterpret_cast<uint32_t *>(scratch + L.s_keys1)};
@@ -612,68 +551,54 @@ int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, ch
                        reinterpret_cast<uint4 *>(scratch + L.s_rec),
                        reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);
     W3D_LAUNCH_CHECK(v.debug, stream);
-    if (v.depth_layers == 2) {       // chunk ranges of the two depth layers (opt-in layered binning only)
-        hipLaunchKernelGGL(layer_split_kernel, dim3(1), dim3(64), 0, stream, counters, L.chunk, (uint32_t)W3D_FRONT_LAYER_256);
-        W3D_LAUNCH_CHECK(v.debug, stream);
-    }
     return W3D_OK;
 }
 
-template <int MODE, int LAYER>
+template <int MODE>
 static void launch_walk(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
                         uint64_t capacity, hipStream_t stream) {
     const W3DBands bands = w3d_pick_bands(L, MODE);
     const dim3 grid(L.C, (bands.count + W3D_WW - 1) / W3D_WW);
-    const float *cut = (LAYER == 0) ? v.tile_depth_cut : nullptr;      // depth cuts only in the single-pass mode
-    const uint32_t wave_bytes = W3D_WALK_QUEUE * 24u + bands.tbpad * (MODE == 0 ? 2u : 12u) +
-                                (LAYER == 2 ? bands.tbpad : 0u) + (cut ? bands.tbpad * 4u : 0u);
+    const uint32_t wave_bytes = W3D_WALK_QUEUE * 24u + bands.tbpad * (MODE == 0 ? 2u : 12u);
     const size_t lds = (size_t)wave_bytes * W3D_WW;
     const uint4 *rec = reinterpret_cast<const uint4 *>(scratch + L.s_rec);
     const uint2 *rmask = reinterpret_cast<const uint2 *>(scratch + L.s_rec_mask);
     const uint32_t *counters = reinterpret_cast<const uint32_t *>(state + L.o_counters);
     uint16_t *cnt = reinterpret_cast<uint16_t *>(scratch + L.s_cnt);
     const uint32_t *off = reinterpret_cast<const uint32_t *>(scratch + L.s_off);
-    const uint8_t *open = reinterpret_cast<const uint8_t *>(state + L.o_tile_open);
     if (v.tile_cull)
-        hipLaunchKernelGGL((chunk_walk_kernel<MODE, true, LAYER>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C,
-                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, open, cut, wave_bytes);
+        hipLaunchKernelGGL((chunk_walk_kernel<MODE, true>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C,
+                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, wave_bytes);
     else
-        hipLaunchKernelGGL((chunk_walk_kernel<MODE, false, LAYER>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C,
-                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, open, cut, wave_bytes);
+        hipLaunchKernelGGL((chunk_walk_kernel<MODE, false>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C,
+                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, wave_bytes);
 }
 
-// per-chunk per-tile counts of one layer (0 = all chunks, 1 = front, 2 = back/open tiles) and the list offsets
-int w3d_launch_tile_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, int layer, hipStream_t stream) {
+// per-chunk per-tile counts and the list offsets
+int w3d_launch_tile_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream) {
     uint32_t *counters = reinterpret_cast<uint32_t *>(state + L.o_counters);
-    uint32_t *tile_start = reinterpret_cast<uint32_t *>(state + (layer == 2 ? L.o_tile_startB : L.o_tile_start));
+    uint32_t *tile_start = reinterpret_cast<uint32_t *>(state + L.o_tile_start);
     uint16_t *cnt = reinterpret_cast<uint16_t *>(scratch + L.s_cnt);
     uint32_t *part = reinterpret_cast<uint32_t *>(scratch + L.s_part);
     uint32_t *off = reinterpret_cast<uint32_t *>(scratch + L.s_off);
     const uint32_t T = (uint32_t)L.T;
-    const uint32_t rng = layer == 0 ? 0xFFFFFFFFu : (uint32_t)(2 + 2 * layer);
     W3D_PROF("tile_count_scan", stream);
-    if (layer == 0) launch_walk<0, 0>(L, v, state, scratch, nullptr, 0, stream);
-    else if (layer == 1) launch_walk<0, 1>(L, v, state, scratch, nullptr, 0, stream);
-    else launch_walk<0, 2>(L, v, state, scratch, nullptr, 0, stream);
+    launch_walk<0>(L, v, state, scratch, nullptr, 0, stream);
     W3D_LAUNCH_CHECK(v.debug, stream);
     const uint32_t tb = (T + 255) / 256;
-    hipLaunchKernelGGL(seg_sum_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, L.C, T, L.seg, part, counters, rng);
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, L.C, T, L.seg, part);
     W3D_LAUNCH_CHECK(v.debug, stream);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, part, T, (uint32_t)W3D_SCAN_SEGS, tile_start, counters,
-                       layer == 2 ? 1 : 0);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, part, T, (uint32_t)W3D_SCAN_SEGS, tile_start, counters);
     W3D_LAUNCH_CHECK(v.debug, stream);
-    hipLaunchKernelGGL(chunk_off_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, part, tile_start, L.C, T, L.seg, off,
-                       counters, rng);
+    hipLaunchKernelGGL(chunk_off_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, part, tile_start, L.C, T, L.seg, off);
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;
 }
 
 int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
-                          uint64_t list_capacity, int layer, hipStream_t stream) {
+                          uint64_t list_capacity, hipStream_t stream) {
     W3D_PROF("fill_lists", stream);
-    if (layer == 0) launch_walk<1, 0>(L, v, state, scratch, point_list, list_capacity, stream);
-    else if (layer == 1) launch_walk<1, 1>(L, v, state, scratch, point_list, list_capacity, stream);
-    else launch_walk<1, 2>(L, v, state, scratch, point_list, list_capacity, stream);
+    launch_walk<1>(L, v, state, scratch, point_list, list_capacity, stream);
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;
 }

@@ -29,9 +29,7 @@ struct W3DLayout {
     uint32_t C;       // number of chunks
     uint32_t seg;     // chunks per scan segment
     // ---- state buffer (kept until backward)
-    uint64_t o_counters;   // u32[16]: [0]=num_visible [1]=num_rendered [2]=front-layer list length
-                           //          [3]=capacity of the list buffer given to stage 2 [4..7]=layer chunk ranges
-                           //          [8]=tiles whose depth-cut list ended unsaturated
+    uint64_t o_counters;   // u32[16]: [0]=num_visible [1]=num_rendered [3]=capacity of the list buffer given to stage 2
     uint64_t o_xy;         // float2[P]
     uint64_t o_conic_op;   // float4[P]
     uint64_t o_rgbd;       // float4[P]  (r,g,b,depth)
@@ -39,9 +37,7 @@ struct W3DLayout {
     uint64_t o_clamped;    // u8[P] bit c set: SH colour channel c clamped at 0
     uint64_t o_tile_mask;  // uint4[P] {rect lo, rect hi, mask lo, mask hi}; mask bit k: k-th tile of the rect (row-major) is
                            // reachable (tile_cull) — rect and mask in ONE 16-B record so that the depth-order gather reads one line
-    uint64_t o_tile_start; // u32[T+1]  (front layer, or the only layer)
-    uint64_t o_tile_startB; // u32[T+1] back layer (absolute list positions)
-    uint64_t o_tile_open;  // u8[T]     1 = tile still open after the front layer
+    uint64_t o_tile_start; // u32[T+1]
     uint64_t o_final_T;    // float[HW]
     uint64_t o_n_contrib;  // u32[HW]
     uint64_t state_bytes;
@@ -66,8 +62,7 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->T = L->gx * L->gy;
     if (L->gx > 65535 || L->gy > 65535) return W3D_ERR_UNSUPPORTED;
     uint64_t Pp = P > 0 ? (uint64_t)P : 1;
-    uint64_t max_chunks = W3D_MAX_CHUNKS;
-    if (const char *e = getenv("W3D_TUNE_CHUNKS")) max_chunks = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : max_chunks;
+    const uint64_t max_chunks = W3D_MAX_CHUNKS;
     uint64_t chunk = (Pp + max_chunks - 1) / max_chunks;
     chunk = (chunk + 63) / 64 * 64;
     if (chunk < 64) chunk = 64;
@@ -85,14 +80,11 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->o_clamped = o;    o += w3d_align_up(Pp);
     L->o_tile_mask = o;  o += w3d_align_up(Pp * 16);
     L->o_tile_start = o; o += w3d_align_up((T + 1) * 4);
-    L->o_tile_startB = o; o += w3d_align_up((T + 1) * 4);
-    L->o_tile_open = o;  o += w3d_align_up(T);
     L->o_final_T = o;    o += w3d_align_up(HW * 4);
     L->o_n_contrib = o;  o += w3d_align_up(HW * 4);
     L->state_bytes = o;
     // radix sort geometry: one wave per contiguous run of sort_items keys
-    uint64_t max_runs = 1024;                    // one wave per SIMD (measured at P = 2 M: 512 runs 0.216 ms, 1024 0.161, 2048 0.177, 4096 0.214)
-    if (const char *e = getenv("W3D_TUNE_SORT_RUNS")) max_runs = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : max_runs;
+    const uint64_t max_runs = 1024;              // one wave per SIMD (measured at P = 2 M: 512 runs 0.216 ms, 1024 0.161, 2048 0.177, 4096 0.214)
     uint64_t items = (Pp + max_runs - 1) / max_runs;
     items = (items + 63) / 64 * 64;
     if (items < 1024) items = 1024;
@@ -174,12 +166,12 @@ int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *me
                           const float *rotations, const float *cov3D_precomp, int32_t *radii, char *state,
                           char *scratch, const float *f_rest_raw, hipStream_t stream);
 int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream);
-int w3d_launch_tile_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, int layer, hipStream_t stream);
+int w3d_launch_tile_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream);
 int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,
-                          uint64_t list_capacity, int layer, hipStream_t stream);
+                          uint64_t list_capacity, hipStream_t stream);
 int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const uint32_t *point_list, uint64_t list_capacity,
                       float *out_color, float *out_depth, float *out_alpha, const float *gt_mask, int32_t num_obj,
-                      float *used_count, int32_t *contrib_num, int layer, hipStream_t stream);
+                      float *used_count, int32_t *contrib_num, hipStream_t stream);
 int w3d_launch_flash_extras(const W3DLayout &L, const w3d_view &v, const int32_t *radii_unused, char *state,
                             float *proj_xy, float *gs_depth, hipStream_t stream);
 int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char *state, const uint32_t *point_list,

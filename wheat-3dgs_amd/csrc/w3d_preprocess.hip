@@ -395,7 +395,8 @@ struct RawBwd {
     float *pw[6], *m[6], *v[6];
     float step_size[6];                 // lr / bias_correction1 per block
     uint32_t skip_mask;                 // bit i: leave block i untouched
-    float b1, b2, eps, inv_sqrt_bc2;
+    float b1, b2, eps;
+    float inv_sqrt_bc2[6];              // per block
     const uint32_t *counters;           // forward counters: [1] = list length needed, [3] = list capacity used
     float *dcolor_out;                  // MODE 2: (P,3) clamp-masked dL/dRGB per Gaussian (zeros for culled)
 };
@@ -430,7 +431,7 @@ __device__ __forceinline__ void coop_adam(const RawBwd &raw, int b, size_t g0, i
                 for (int c = 0; c < 4; c++) {
                     const int e = 4 * q + c;
                     float a = pp[u][c], cm = mm[u][c], cv = vv[u][c];
-                    w3d_adam1(a, stage[(e / DIM) * rstride + coff + e % DIM], cm, cv, step, raw.b1, raw.b2, raw.eps, raw.inv_sqrt_bc2);
+                    w3d_adam1(a, stage[(e / DIM) * rstride + coff + e % DIM], cm, cv, step, raw.b1, raw.b2, raw.eps, raw.inv_sqrt_bc2[b]);
                     pp[u][c] = a; mm[u][c] = cm; vv[u][c] = cv;
                 }
                 __builtin_nontemporal_store(pp[u], reinterpret_cast<f4 *>(pb) + q);
@@ -441,7 +442,7 @@ __device__ __forceinline__ void coop_adam(const RawBwd &raw, int b, size_t g0, i
     }
     for (int e = 4 * nv + threadIdx.x; e < n; e += 256) {
         float pp = pb[e], mm = mb[e], vv = vb[e];
-        w3d_adam1(pp, stage[(e / DIM) * rstride + coff + e % DIM], mm, vv, step, raw.b1, raw.b2, raw.eps, raw.inv_sqrt_bc2);
+        w3d_adam1(pp, stage[(e / DIM) * rstride + coff + e % DIM], mm, vv, step, raw.b1, raw.b2, raw.eps, raw.inv_sqrt_bc2[b]);
         pb[e] = pp; mb[e] = mm; vb[e] = vv;
     }
 }
@@ -854,7 +855,7 @@ int w3d_launch_sh_adam_lowrank(int32_t P, int32_t nviews, int32_t sh_degree, con
     raw.pw[1] = f_dc; raw.m[1] = m_dc; raw.v[1] = v_dc; raw.step_size[1] = lr_dc / bc1;
     raw.pw[2] = f_rest; raw.m[2] = m_rest; raw.v[2] = v_rest; raw.step_size[2] = lr_rest / bc1;
     raw.skip_mask = (skip_dc ? 2u : 0u) | (skip_rest ? 4u : 0u);
-    raw.b1 = beta1; raw.b2 = beta2; raw.eps = eps; raw.inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    raw.b1 = beta1; raw.b2 = beta2; raw.eps = eps; raw.inv_sqrt_bc2[1] = raw.inv_sqrt_bc2[2] = 1.0f / sqrtf(bc2);
     W3D_PROF("sh_adam_lowrank", stream);
     hipLaunchKernelGGL(sh_adam_lowrank_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, nviews, sh_degree, campos_all, xyz,
                        dcolor_all, raw);
@@ -926,10 +927,11 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
         for (int i = 0; i < 6; i++) {
             if (!pws[i] || !ms[i] || !vs[i]) { w3d_set_error("fused Adam: NULL parameter / moment block"); return W3D_ERR_INVALID; }
             raw.pw[i] = pws[i]; raw.m[i] = ms[i]; raw.v[i] = vs[i];
-            raw.step_size[i] = a.lr[i] / a.bias_correction1;
+            raw.step_size[i] = a.lr[i] / a.bias_correction1[i];
+            raw.inv_sqrt_bc2[i] = 1.0f / sqrtf(a.bias_correction2[i]);
             if (a.skip[i]) raw.skip_mask |= 1u << i;
         }
-        raw.b1 = a.beta1; raw.b2 = a.beta2; raw.eps = a.eps; raw.inv_sqrt_bc2 = 1.0f / sqrtf(a.bias_correction2);
+        raw.b1 = a.beta1; raw.b2 = a.beta2; raw.eps = a.eps;
         raw.counters = reinterpret_cast<const uint32_t *>(state + L.o_counters);
     }
 #define LAUNCH(A, B, C)                                                                                                  \

@@ -12,8 +12,8 @@
 //     first, then ONE wave reduction (DPP row ops + row_bcast, no LDS traffic) per tile instance
 //     and ONE 40-B atomic record update per tile instance — instead of 9 atomics per
 //     (pixel, Gaussian) pair.
-// Workgroups are 256 threads = 4 independent tiles; the wave -> tile map keeps the tiles of one
-// XCD contiguous so neighbouring tiles (which share Gaussians) hit the same L2.
+// One tile-wave per workgroup (W3D_RW); the wave -> tile map keeps the tiles of one XCD contiguous so
+// neighbouring tiles (which share Gaussians) hit the same L2.
 #include "w3d_common.h"
 
 namespace {
@@ -121,12 +121,7 @@ __device__ __forceinline__ void stage_entries(StagedLDS &s, uint32_t lane, uint3
 }
 
 // ------------------------------------------------------------------------------ forward
-// LAYER 0: the whole list in one pass.  LAYER 1: front depth layer — a tile whose pixels are not all
-// saturated when its front list ends is left OPEN: its running state (C, D, A, T, last) is parked in the
-// output / state images and tile_open[tile] = 1.  LAYER 2: back layer, open tiles only: resumes the
-// parked state, walks the back list (binned for open tiles only) and writes the final values.  The
-// arithmetic per pixel is the same sequence as in one pass, so the outputs are bit-identical.
-template <bool FLASH, int LAYER>
+template <bool FLASH>
 __global__ void __launch_bounds__(64 * W3D_RW)
 render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restrict__ tile_start,
                   const uint32_t *__restrict__ point_list, const float2 *__restrict__ xy,
@@ -134,15 +129,12 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_alpha,
                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                   const float *__restrict__ gt_mask, int num_obj, int P, float *__restrict__ used_count,
-                  int32_t *__restrict__ contrib_num, uint32_t list_cap, uint32_t *__restrict__ counters,
-                  const uint32_t *__restrict__ tile_startA, uint8_t *__restrict__ tile_open,
-                  const float *__restrict__ cut_in, float *__restrict__ cut_out) {
+                  int32_t *__restrict__ contrib_num, uint32_t list_cap, uint32_t *__restrict__ counters) {
     __shared__ StagedLDS lds[W3D_RW];
     __shared__ int s_labels[W3D_RW][FLASH ? 256 : 1];
     __shared__ float s_facc[W3D_RW][FLASH ? 64 * 2 : 1];      // FlashSplat: per-entry weight sums of the current batch, <= 2 labels
     uint32_t tile;
     if (!wave_to_tile(T, tile)) return;
-    if (LAYER == 2 && tile_open[tile] == 0) return;
     // the list buffer may be smaller than the lists (speculative sizing, see w3d_forward_stage2): never read
     // past it; the capacity is published for the backward pass
     if (tile == 0 && (threadIdx.x & 63) == 0) counters[3] = list_cap;
@@ -156,7 +148,6 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     // (a bool array would be decoded from a 0/1 VGPR and re-encoded for every ballot).
     bool inside[4];
     float hi[4];
-#define W3D_DONE(k) (hi[k] < 0.f)
     float Tr[4], C0[4], C1[4], C2[4], D[4], A[4];
     uint32_t last[4];
     int napplied[4];
@@ -169,15 +160,6 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         hi[k] = inside[k] ? 0.f : -INFINITY;
         Tr[k] = 1.f; C0[k] = C1[k] = C2[k] = D[k] = A[k] = 0.f;
         last[k] = 0; napplied[k] = 0;
-        if (LAYER == 2 && inside[k]) {
-            // resume the state parked by the front-layer pass
-            const size_t pix = (size_t)py * W + px, HWp = (size_t)H * W;
-            C0[k] = out_color[pix]; C1[k] = out_color[HWp + pix]; C2[k] = out_color[2 * HWp + pix];
-            D[k] = out_depth[pix]; A[k] = out_alpha[pix];
-            Tr[k] = final_T[pix]; last[k] = n_contrib[pix];
-            hi[k] = (Tr[k] < 0.f) ? -INFINITY : 0.f;     // a saturated pixel was parked with its sign bit set
-            Tr[k] = fabsf(Tr[k]);
-        }
         label[k] = -1;
         if (FLASH && gt_mask && inside[k]) {
             const int l = (int)gt_mask[(size_t)py * W + px];
@@ -204,10 +186,6 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         __builtin_amdgcn_wave_barrier();
     }
     const uint32_t start = min(tile_start[tile], list_cap), end = min(tile_start[tile + 1], list_cap);
-    // contributor numbers continue across layers: the back list follows the tile's front list
-    const uint32_t first = (LAYER == 2) ? (tile_startA[tile + 1] - tile_startA[tile]) : 0u;
-    uint32_t deepest = 0;        // 1-based position of the deepest entry that changed any pixel's state
-    const bool track_cut = (cut_in != nullptr) || (cut_out != nullptr);
     for (uint32_t base = start; base < end; base += 64) {
         if ((w3d_ballot(hi[0] == 0.f) | w3d_ballot(hi[1] == 0.f) | w3d_ballot(hi[2] == 0.f) | w3d_ballot(hi[3] == 0.f)) == 0ull) break;
         const uint32_t n = min(64u, end - base);
@@ -221,7 +199,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             const uint32_t qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.q[j]);
             if (qm == 0u) continue;
             const float4 ea = s.a[j], ed = s.d[j], ec = s.c[j];
-            const uint32_t contributor = first + base - start + j + 1;
+            const uint32_t contributor = base - start + j + 1;
             float wk[4] = {0.f, 0.f, 0.f, 0.f};
             bool any_applied = false;
 #pragma unroll
@@ -243,7 +221,6 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 Tr[k] = apply ? test_T : Tr[k];
                 last[k] = apply ? contributor : last[k];
                 hi[k] = stop ? -INFINITY : hi[k];
-                if (LAYER == 0 && track_cut && w3d_ballot(apply || stop) != 0ull) deepest = contributor;
                 if (FLASH) { wk[k] = w; napplied[k] += apply ? 1 : 0; any_applied = any_applied || apply; }
             }
             if (FLASH && gt_mask && used_count) {
@@ -283,40 +260,6 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     }
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t HW = (size_t)H * W;
-    if (LAYER == 0 && (cut_in || cut_out)) {
-        // speculative list truncation (w3d_view.tile_depth_cut): verify this visit, prepare the next one
-        const bool saturated = (w3d_ballot(hi[0] == 0.f) | w3d_ballot(hi[1] == 0.f) | w3d_ballot(hi[2] == 0.f) | w3d_ballot(hi[3] == 0.f)) == 0ull;
-        if (lane == 0) {
-            if (cut_out) {
-                float c = __builtin_inff();
-                if (saturated && deepest > 0) {
-                    const float d = rgbd[point_list[start + deepest - 1]].w;
-                    c = d + fmaxf(0.03f * d, 1e-3f);
-                }
-                cut_out[tile] = c;
-            }
-            // a truncated list that ended before every pixel saturated may have lost contributors
-            if (cut_in && !saturated && cut_in[tile] < __builtin_inff()) atomicAdd(&counters[8], 1u);
-        }
-    }
-    if (LAYER == 1) {
-        const bool open = (w3d_ballot(hi[0] == 0.f) | w3d_ballot(hi[1] == 0.f) | w3d_ballot(hi[2] == 0.f) | w3d_ballot(hi[3] == 0.f)) != 0ull;
-        if (lane == 0) tile_open[tile] = open ? 1 : 0;
-        if (open) {
-            // park the running state; saturated pixels carry their "done" flag in the sign of T
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (inside[k]) {
-                    const size_t pix = (size_t)(uint32_t)pyf[k] * W + (uint32_t)pxf[k];
-                    out_color[pix] = C0[k]; out_color[HW + pix] = C1[k]; out_color[2 * HW + pix] = C2[k];
-                    out_depth[pix] = D[k]; out_alpha[pix] = A[k];
-                    final_T[pix] = W3D_DONE(k) ? -Tr[k] : Tr[k];
-                    n_contrib[pix] = last[k];
-                }
-            }
-            return;
-        }
-    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (inside[k]) {
@@ -387,7 +330,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                   const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
                   const float *__restrict__ dL_dalpha_px, float *__restrict__ grad2d,
-                  const uint32_t *__restrict__ counters, const uint32_t *__restrict__ tile_startB) {
+                  const uint32_t *__restrict__ counters) {
     __shared__ StagedLDS lds[W3D_RW];
     __shared__ __align__(16) float acc_all[W3D_RW][64 * W3D_ACC_STRIDE];   // per-entry sums of the current batch
     constexpr int NV = HAS_DA ? 10 : 9;
@@ -430,9 +373,6 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     if (maxc == 0) return;
     const uint32_t cap = counters[3];
     const uint32_t start = min(tile_start[tile], cap);
-    // layered forward: positions [0, lenA) live in the front list, the rest in the back list
-    const uint32_t lenA = tile_startB ? (min(tile_start[tile + 1], cap) - start) : 0xFFFFFFFFu;
-    const uint32_t startB = tile_startB ? min(tile_startB[tile], cap) : 0u;
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const bool has_bg = (bg0 != 0.f) || (bg1 != 0.f) || (bg2 != 0.f);     // wave-uniform: black background skips the term
     const int nb = (int)((maxc + 63) / 64);
@@ -441,7 +381,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     auto batch_id = [&](int b) -> uint32_t {
         const uint32_t i = (uint32_t)b * 64u + lane;
         if (!(b >= 0 && i < maxc)) return 0xFFFFFFFFu;
-        return i < lenA ? point_list[start + i] : point_list[min(startB + (i - lenA), cap - 1u)];
+        return point_list[min(start + i, cap - 1u)];
     };
     Staged nxt;
     {
@@ -576,27 +516,23 @@ __global__ void copy_pixel_state_kernel(const float *__restrict__ fT, const uint
 
 int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const uint32_t *point_list, uint64_t list_capacity,
                       float *out_color, float *out_depth, float *out_alpha, const float *gt_mask, int32_t num_obj,
-                      float *used_count, int32_t *contrib_num, int layer, hipStream_t stream) {
+                      float *used_count, int32_t *contrib_num, hipStream_t stream) {
     const uint32_t T = (uint32_t)L.T;
     uint32_t blocks = (T + W3D_RW - 1) / W3D_RW;
     blocks = (blocks + 7) / 8 * 8;   // the XCD-contiguous map needs a multiple of 8 blocks
     const bool flash = (gt_mask != nullptr) || (used_count != nullptr) || (contrib_num != nullptr);
-    const uint32_t *tsA = reinterpret_cast<const uint32_t *>(state + L.o_tile_start);
-    const uint32_t *ts = layer == 2 ? reinterpret_cast<const uint32_t *>(state + L.o_tile_startB) : tsA;
+    const uint32_t *ts = reinterpret_cast<const uint32_t *>(state + L.o_tile_start);
 #define ARGS                                                                                                          \
     T, (uint32_t)L.gx, L.W, L.H, ts, point_list,                                                                      \
         reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_conic_op),     \
         reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg, out_color, out_depth, out_alpha,                    \
         reinterpret_cast<float *>(state + L.o_final_T), reinterpret_cast<uint32_t *>(state + L.o_n_contrib), gt_mask, \
         num_obj, L.P, used_count, contrib_num, (uint32_t)(list_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : list_capacity),      \
-        reinterpret_cast<uint32_t *>(state + L.o_counters), tsA, reinterpret_cast<uint8_t *>(state + L.o_tile_open), \
-        (layer == 0 ? v.tile_depth_cut : nullptr), (layer == 0 ? v.tile_depth_cut_out : nullptr)
+        reinterpret_cast<uint32_t *>(state + L.o_counters)
     {
         W3D_PROF("render_fwd", stream);
-        if (flash) hipLaunchKernelGGL((render_fwd_kernel<true, 0>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
-        else if (layer == 1) hipLaunchKernelGGL((render_fwd_kernel<false, 1>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
-        else if (layer == 2) hipLaunchKernelGGL((render_fwd_kernel<false, 2>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
-        else hipLaunchKernelGGL((render_fwd_kernel<false, 0>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
+        if (flash) hipLaunchKernelGGL((render_fwd_kernel<true>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
+        else hipLaunchKernelGGL((render_fwd_kernel<false>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
     }
 #undef ARGS
     W3D_LAUNCH_CHECK(v.debug, stream);
@@ -606,7 +542,6 @@ int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const 
 int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char *state, const uint32_t *point_list,
                                const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha, float *grad2d,
                                hipStream_t stream) {
-    const uint32_t *tsB = v.depth_layers == 2 ? reinterpret_cast<const uint32_t *>(state + L.o_tile_startB) : nullptr;
     const uint32_t T = (uint32_t)L.T;
     uint32_t blocks = (T + W3D_RW - 1) / W3D_RW;
     blocks = (blocks + 7) / 8 * 8;
@@ -620,7 +555,7 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
         reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_conic_op), \
         reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg,                                                 \
         reinterpret_cast<const float *>(state + L.o_final_T), reinterpret_cast<const uint32_t *>(state + L.o_n_contrib), \
-        dL_dcolor, dL_ddepth, dL_dalpha, grad2d, reinterpret_cast<const uint32_t *>(state + L.o_counters), tsB
+        dL_dcolor, dL_ddepth, dL_dalpha, grad2d, reinterpret_cast<const uint32_t *>(state + L.o_counters)
     {
         W3D_PROF("render_bwd", stream);
         if (dL_ddepth || dL_dalpha) hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);

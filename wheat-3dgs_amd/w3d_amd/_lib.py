@@ -26,8 +26,7 @@ class W3DView(ctypes.Structure):
                 ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
                 ("bg", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
                 ("projmatrix", ctypes.c_void_p), ("campos", ctypes.c_void_p),
-                ("tile_cull", ctypes.c_int32), ("depth_layers", ctypes.c_int32),
-                ("tile_depth_cut", ctypes.c_void_p), ("tile_depth_cut_out", ctypes.c_void_p)]
+                ("tile_cull", ctypes.c_int32)]
 
 
 def _load():

@@ -9,12 +9,11 @@ tests/test_gpu_fused.py checks the two paths against each other.
 """
 import ctypes
 import math
-import os
 
 import torch
 
 from ._lib import W3DView, check, lib, ptr, stream_ptr
-from .rasterizer import GaussianRasterizationSettings, _View
+from .rasterizer import GaussianRasterizationSettings, _View, list_capacity
 
 _vp, _i32 = ctypes.c_void_p, ctypes.c_int32
 
@@ -41,7 +40,7 @@ lib.w3d_backward_raw.restype = ctypes.c_int
 class W3DAdamFused(ctypes.Structure):
     _fields_ = [("exp_avg", W3DRawGrads), ("exp_avg_sq", W3DRawGrads), ("lr", ctypes.c_float * 6), ("skip", _i32 * 6),
                 ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
-                ("bias_correction1", ctypes.c_float), ("bias_correction2", ctypes.c_float)]
+                ("bias_correction1", ctypes.c_float * 6), ("bias_correction2", ctypes.c_float * 6)]
 
 
 lib.w3d_backward_raw_adam.argtypes = [ctypes.POINTER(W3DView), _i32, ctypes.POINTER(W3DRawGrads), _vp, _vp, _vp, _vp, _vp,
@@ -69,38 +68,6 @@ def _raw_params(model):
     return p
 
 
-class ListCapacity:
-    """Speculative sizing of the per-tile list buffer so that the forward needs NO host sync.
-
-    The list length R (= num_rendered) is only known on the device after stage 1.  The synchronous path
-    copies it to the host and waits (one pipeline bubble per view).  Here the list is allocated from the
-    largest R seen so far (x `slack`); stage 2 is enqueued immediately; R travels to pinned host memory
-    with an async copy + event, and `finish()` — called after the backward has been enqueued, so the GPU
-    always has work queued — reports whether the guess held.  The fill kernel never writes past the
-    capacity it was given; on overflow the caller grows the capacity and repeats the view."""
-
-    def __init__(self, slack=1.25):
-        self.slack = slack
-        self.known = 0          # largest R observed
-
-    def guess(self):
-        return int(self.known * self.slack) + 1024 if self.known else 0
-
-    def observe(self, R):
-        self.known = max(self.known, int(R))
-
-
-_capacity = ListCapacity()
-
-# Depth-layered binning (w3d_view.depth_layers = 2) in the asynchronous forward: bin and blend the front
-# ~28 % of the depth-ordered Gaussians, then only the tiles that are still open.  Identical outputs.
-# OFF by default: it only pays when the global depth order follows the per-tile order (fronto-parallel
-# views).  On the benchmark's tilted overhead cameras the depth gradient across the image is as large as
-# the slab is thick, the front layer closes only the near side of the image, and the second pass costs
-# more than it saves (measured 269 vs 319 iters/s).
-DEPTH_LAYERS = os.environ.get("W3D_DEPTH_LAYERS", "0") == "2"
-
-
 def finish(handle):
     """Wait for the counters of an asynchronous forward; True if the list capacity sufficed."""
     pend = handle.get("pending")
@@ -108,23 +75,16 @@ def finish(handle):
         return True
     pinned, ev = pend
     ev.synchronize()
-    handle["num_visible"], handle["num_rendered"] = int(pinned[0]), int(pinned[1])
-    handle["suspect_tiles"] = int(pinned[8])      # tiles whose depth-cut list ended before they saturated
+    handle["num_visible"], handle["num_rendered"] = int(pinned[0]) & 0xFFFFFFFF, int(pinned[1]) & 0xFFFFFFFF
     handle["pending"] = None
-    if handle["suspect_tiles"] == 0 or handle["depth_cut"] is None:
-        _capacity.observe(handle["num_rendered"])
-    return handle["num_rendered"] <= handle["capacity"] and handle["suspect_tiles"] == 0
+    handle["cap"].observe(handle["num_rendered"])
+    return handle["num_rendered"] <= handle["capacity"]
 
 
-def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, depth_cut=None, want_cut=False, flash=None):
+def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, flash=None):
     """Forward on the raw parameters.  Returns the dict of render() (minus viewspace_points) plus a
-    `handle` for backward_raw().  sync=False: no host synchronisation (see ListCapacity); the caller
-    must call finish(handle) before trusting the outputs.
-
-    depth_cut (T,) float tensor from an earlier visit of this camera: per-tile depth beyond which
-    nothing is binned (w3d_view.tile_depth_cut) — finish() is False when a tile turned out to need more
-    (repeat the view with depth_cut=None).  want_cut: handle["depth_cut_out"] receives the cuts for the
-    next visit."""
+    `handle` for backward_raw().  sync=False: no host synchronisation (rasterizer.ListCapacity); the caller
+    must call finish(handle) before trusting the outputs, and repeat the view when it returns False."""
     dev = model.flat.device
     if not model.flat.is_cuda:
         raise RuntimeError("the fused step needs the model on the GPU; there is no CPU path")
@@ -134,16 +94,6 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, depth_cut=
                                       scaling_modifier, cam.world_view_transform, cam.full_proj_transform,
                                       model.active_sh_degree, cam.camera_center, False, False)
     view = _View(s, (model.max_sh_degree + 1) ** 2, dev)
-    T = ((W + 15) // 16) * ((H + 15) // 16)
-    cut_out = None
-    if depth_cut is not None:
-        if sync:
-            raise ValueError("depth cuts need the asynchronous forward (sync=False)")
-        assert depth_cut.numel() == T and depth_cut.dtype == torch.float32 and depth_cut.is_cuda
-        view.c.tile_depth_cut = depth_cut.data_ptr()
-    if want_cut:
-        cut_out = torch.empty(T, dtype=torch.float32, device=dev)
-        view.c.tile_depth_cut_out = cut_out.data_ptr()
     prm = _raw_params(model)
     with torch.cuda.device(dev):
         stream = stream_ptr(dev)
@@ -152,19 +102,26 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, depth_cut=
         state = torch.empty(sb.value, dtype=torch.uint8, device=dev)
         scratch = torch.empty(tb.value, dtype=torch.uint8, device=dev)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
-        guess = 0 if sync else _capacity.guess()
+        cap = list_capacity(dev, H, W)
+        guess = 0 if sync else cap.guess()
         pending = None
         if guess == 0:
             counts = (ctypes.c_uint32 * 2)()
             check(lib.w3d_forward_stage1_raw(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(radii), ptr(state),
                                              ptr(scratch), ctypes.cast(counts, _vp), stream))
             R, V = int(counts[1]), int(counts[0])
-            _capacity.observe(R)
+            cap.observe(R)
         else:
-            view.c.depth_layers = 2 if DEPTH_LAYERS else 0
             check(lib.w3d_forward_stage1_raw(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(radii), ptr(state),
                                              ptr(scratch), None, stream))
             R, V = guess, -1
+            # the counters start their way to pinned host memory right after stage 1, BEFORE stage 2 is enqueued:
+            # whoever waits for them (finish()) is released while the GPU is still busy with stage 2
+            pinned = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            pinned.copy_(state[:8].view(torch.int32), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            pending = (pinned, ev)
         plist = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
@@ -188,16 +145,8 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, depth_cut=
         check(lib.w3d_forward_stage2(ctypes.byref(view.c), P, ptr(state), ptr(scratch), ptr(plist), ctypes.c_uint64(R),
                                      ptr(color), ptr(depth), ptr(alpha), ptr(gt_mask), num_obj, ptr(used_count),
                                      ptr(contrib_num), ptr(proj_xy), ptr(gs_depth), stream))
-        if guess != 0:
-            # counters (offset 0 of the state) travel to pinned memory AFTER the blend so that the depth-cut
-            # verdict is included; finish() waits on the event
-            pinned = torch.empty(16, dtype=torch.int32, pin_memory=True)
-            pinned.copy_(state[:64].view(torch.int32), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            pending = (pinned, ev)
     handle = dict(view=view, P=P, state=state, point_list=plist, radii=radii, num_rendered=R, num_visible=V,
-                  capacity=R, pending=pending, depth_cut=depth_cut, depth_cut_out=cut_out, suspect_tiles=0)
+                  capacity=R, pending=pending, cap=cap)
     out = {"render": color, "radii": radii, "depth": depth, "alpha": alpha, "handle": handle}
     if flash is not None:
         out.update(contrib_num=contrib_num, used_count=used_count, proj_xy=proj_xy, gs_depth=gs_depth)
@@ -205,19 +154,19 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, depth_cut=
 
 
 def backward_raw(model, handle, dL_dimage, dL_ddepth=None, dL_dalpha=None, update_stats=False, want_norm=False,
-                 want_means2D=False):
-    """Backward into model.flat_grad (OVERWRITTEN).  update_stats: add_densification_stats and the
-    max_radii2D update happen inside the kernel (single-GPU step).  want_norm: also return the
-    per-Gaussian ||dL/dmean2D|| (the view-parallel exchange needs it before reduction)."""
+                 want_means2D=False, into=None):
+    """Backward into model.flat_grad (OVERWRITTEN) — or into `into`, a flat buffer of the same layout.  update_stats:
+    add_densification_stats and the max_radii2D update happen inside the kernel (single-GPU step).  want_norm: also
+    return the per-Gaussian ||dL/dmean2D|| (the view-parallel exchange needs it before reduction)."""
     dev = model.flat.device
     P, view = handle["P"], handle["view"]
     if P != model.num_points:
         raise RuntimeError("model was resized between forward and backward")
     prm = _raw_params(model)
     g = W3DRawGrads()
-    for n, attr in (("xyz", "xyz"), ("f_dc", "f_dc"), ("f_rest", "f_rest"), ("opacity", "opacity"),
-                    ("scaling", "scaling"), ("rotation", "rotation")):
-        setattr(g, n, model._p[attr].grad.data_ptr())
+    sl = model.block_slices()
+    for n in _BLOCK_ORDER:
+        setattr(g, n, (model.flat_grad if into is None else into).data_ptr() + 4 * sl[n][0])
     st = W3DDensifyStats()
     gnorm = torch.empty(P, dtype=torch.float32, device=dev) if want_norm else None
     m2d = torch.empty(P, 3, dtype=torch.float32, device=dev) if want_means2D else None
@@ -237,6 +186,59 @@ def backward_raw(model, handle, dL_dimage, dL_ddepth=None, dL_dalpha=None, updat
     return gnorm, m2d
 
 
+class _RasterizeRawFn(torch.autograd.Function):
+    """render() under autograd on the flat GaussianModel — what an unmodified train_vanilla_3dgs.py:73-80 runs through
+    (render(), then loss.backward()).  The graph has ONE node between the six parameter tensors and the image: the
+    kernels apply exp / sigmoid / normalize / the dc-rest split themselves and chain their derivatives, so none of the
+    activation, cat and split kernels of reference scene/gaussian_model.py:101-121 (nor their autograd backward) is
+    launched.  The backward writes the parameter gradients straight into the model's flat gradient bucket and hands
+    autograd VIEWS of it: with .grad None (optimizer.zero_grad(set_to_none=True), train_vanilla_3dgs.py:115) the engine
+    adopts them without a copy or an accumulation pass."""
+
+    @staticmethod
+    def forward(ctx, means2D, xyz, f_dc, f_rest, opacity, scaling, rotation, model, cam, bg, scaling_modifier):
+        pkg = render_raw(cam, model, bg, scaling_modifier, sync=False)
+        if not finish(pkg["handle"]):                 # list buffer too small: repeat with the exact size
+            pkg = render_raw(cam, model, bg, scaling_modifier, sync=True)
+        ctx.model, ctx.handle = model, pkg["handle"]
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(pkg["radii"])
+        return pkg["render"], pkg["radii"], pkg["depth"], pkg["alpha"]
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth, g_alpha):
+        model, handle = ctx.model, ctx.handle
+        dev = model.flat.device
+        H, W = handle["view"].c.image_height, handle["view"].c.image_width
+        if g_color is None:
+            g_color = torch.zeros(3, H, W, dtype=torch.float32, device=dev)
+        f32 = lambda t: None if t is None else t.to(torch.float32).contiguous()  # noqa: E731
+        # The kernel OVERWRITES its gradient buffers.  Straight into the bucket only when no gradient is being
+        # accumulated there (every .grad None); otherwise into a temporary that autograd adds to the existing .grad.
+        direct = all(p.grad is None for p in model._p.values())
+        into = None if direct else torch.empty_like(model.flat_grad)
+        _, m2d = backward_raw(model, handle, f32(g_color), f32(g_depth), f32(g_alpha), want_means2D=True, into=into)
+        ctx.handle = None
+        if direct:
+            grads = {n: model.grad_view(n) for n in _BLOCK_ORDER}
+        else:
+            sl = model.block_slices()
+            grads = {n: into[sl[n][0]:sl[n][1]].view(model._p[n].shape) for n in _BLOCK_ORDER}
+        return (m2d, grads["xyz"], grads["f_dc"], grads["f_rest"], grads["opacity"], grads["scaling"], grads["rotation"],
+                None, None, None, None)
+
+
+def render_raw_autograd(cam, model, bg_color, scaling_modifier=1.0):
+    """The dict of render() (reference gaussian_renderer/__init__.py:99-106) through _RasterizeRawFn."""
+    xyz = model._p["xyz"]
+    screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+    p = model._p
+    color, radii, depth, alpha = _RasterizeRawFn.apply(screenspace_points, p["xyz"], p["f_dc"], p["f_rest"], p["opacity"],
+                                                       p["scaling"], p["rotation"], model, cam, bg_color, scaling_modifier)
+    return {"render": color, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+            "depth": depth, "alpha": alpha}
+
+
 def backward_raw_adam(model, handle, dL_dimage, skip=(), want_norm=True, update_stats=False):
     """Backward with the optimizer fused in (single GPU): the kernel that finishes each Gaussian's gradient applies
     FlatAdam's update to the parameter blocks and both moments in place, so the 59*P gradient bucket is neither written
@@ -252,7 +254,6 @@ def backward_raw_adam(model, handle, dL_dimage, skip=(), want_norm=True, update_
     prm, ad = W3DRawGrads(), W3DAdamFused()
     sl = model.block_slices()
     b1, b2 = opt.betas
-    t = opt.step_count + 1
     for i, n in enumerate(_BLOCK_ORDER):
         a, _ = sl[n]
         setattr(prm, n, model._p[n].data_ptr())
@@ -260,8 +261,9 @@ def backward_raw_adam(model, handle, dL_dimage, skip=(), want_norm=True, update_
         setattr(ad.exp_avg_sq, n, opt.exp_avg_sq.data_ptr() + 4 * a)
         ad.lr[i] = float(opt.lrs[n])
         ad.skip[i] = int(n in skip)
+        # the update this kernel applies is step t+1 of the block (note_fused_step advances the counters afterwards)
+        ad.bias_correction1[i], ad.bias_correction2[i] = opt.bias_corrections(n, ahead=1)
     ad.beta1, ad.beta2, ad.eps = float(b1), float(b2), float(opt.eps)
-    ad.bias_correction1, ad.bias_correction2 = 1.0 - math.pow(b1, t), 1.0 - math.pow(b2, t)
     st = W3DDensifyStats()
     gnorm = torch.empty(P, dtype=torch.float32, device=dev) if want_norm else None
     st.grad2d_norm = None if gnorm is None else gnorm.data_ptr()
@@ -310,7 +312,7 @@ def backward_raw_lowrank(model, handle, dL_dimage, want_norm=True):
     prm = _raw_params(model)
     g = W3DRawGrads()
     for n in GEO_BLOCKS:
-        setattr(g, n, model._p[n].grad.data_ptr())
+        setattr(g, n, model.grad_view(n).data_ptr())
     st = W3DDensifyStats()
     gnorm = torch.empty(P, dtype=torch.float32, device=dev) if want_norm else None
     st.grad2d_norm = None if gnorm is None else gnorm.data_ptr()
@@ -357,12 +359,13 @@ def sh_adam_lowrank(model, dcolor_all, campos_all, skip=(), rows=None):
             dirs = dirs / dirs.norm(dim=1, keepdim=True)
             basis = sh_basis(deg, dirs)                      # (P, (deg+1)^2)
             grad[:, :basis.shape[1]] += basis[:, :, None] * dcolor_all[v][:, None, :]
-        model._p["f_dc"].grad.copy_(grad[:, :1])
-        model._p["f_rest"].grad.copy_(grad[:, 1:])
+        model.grad_view("f_dc").copy_(grad[:, :1])
+        model.grad_view("f_rest").copy_(grad[:, 1:])
         opt.step(only=SH_BLOCKS, skip=skip, advance=False)
         return
     sl = model.block_slices()
-    bc1, bc2 = opt.bias_corrections()
+    assert opt.steps["f_dc"] == opt.steps["f_rest"] or "f_dc" in skip or "f_rest" in skip
+    bc1, bc2 = opt.bias_corrections("f_rest" if "f_dc" in skip else "f_dc")
     b1, b2 = opt.betas
     m, v = opt.exp_avg, opt.exp_avg_sq
     (a_dc, _), (a_rest, _) = sl["f_dc"], sl["f_rest"]

@@ -4,7 +4,7 @@ Same public surface as reference scene/gaussian_model.py (GaussianModel): `get_x
 `get_scaling` (exp), `get_rotation` (normalize), `get_opacity` (sigmoid), `get_features`
 (cat(dc, rest)), `get_covariance`, `active_sh_degree`/`oneupSHdegree`, `training_setup`,
 `update_learning_rate`, `add_densification_stats`, `densify_and_prune`, `reset_opacity`,
-`capture`/`restore`, `create_from_points`.  The storage is MI355X-first rather than a
+`capture`/`restore`, `create_from_pcd`, `reset_label`.  The storage is MI355X-first rather than a
 translation: all 59 trainable floats per Gaussian live in ONE flat fp32 buffer laid out as
 six contiguous blocks [xyz | f_dc | f_rest | opacity | scaling | rotation], and the gradients in
 a second flat buffer of the same layout, so the view-parallel step all-reduces one bucket
@@ -96,8 +96,8 @@ class GaussianModel:
         """(Re)build the flat buffers from a dict name -> tensor (P, *shape)."""
         P = blocks["xyz"].shape[0]
         n = P * FLOATS_PER_GAUSSIAN
-        # storage padded to a multiple of 256 elements: any world size up to 256 can shard it evenly for the
-        # reduce-scatter / all-gather exchange (train.py) without repacking
+        # storage padded to a multiple of 256 elements: every world size that divides 256 (1, 2, 4, 8, ...) shards it
+        # evenly for the reduce-scatter / all-gather exchange (train.py checks) without repacking
         n_pad = (n + 255) // 256 * 256
         self.flat_store = torch.zeros(n_pad, dtype=torch.float32, device=self.device)
         self.flat_grad_store = torch.zeros(n_pad, dtype=torch.float32, device=self.device)
@@ -114,6 +114,17 @@ class GaussianModel:
             p.grad = self.flat_grad[off:off + n].view(P, *shape)
             self._p[name] = p
             off += n
+
+    def grad_view(self, name):
+        """The block of the flat gradient bucket that belongs to parameter `name`, shaped like it (whether or not the
+        parameter's .grad currently points at it)."""
+        a, b = self.block_slices()[name]
+        return self.flat_grad[a:b].view(self._p[name].shape)
+
+    def bind_grad_views(self):
+        """(Re)attach every parameter's .grad to its block of the flat bucket (after zero_grad(set_to_none=True))."""
+        for name, p in self._p.items():
+            p.grad = self.grad_view(name)
 
     def block_slices(self):
         """name -> (start, stop) element offsets of each block inside the flat buffers."""
@@ -190,6 +201,10 @@ class GaussianModel:
         self._reset_stats()
         self._which_object = torch.zeros(P, 1, dtype=torch.int, device=self.device)
 
+    def create_from_pcd(self, pcd, spatial_lr_scale: float):
+        """Reference signature (scene/gaussian_model.py:138): `pcd` carries .points and .colors (BasicPointCloud)."""
+        self.create_from_points(np.asarray(pcd.points), np.asarray(pcd.colors), spatial_lr_scale)
+
     def create_from_tensors(self, xyz, features_dc, features_rest, scaling, rotation, opacity, spatial_lr_scale=1.0):
         """Directly from pre-activation tensors (synthetic scenes, checkpoints)."""
         self.spatial_lr_scale = spatial_lr_scale
@@ -230,10 +245,18 @@ class GaussianModel:
 
     # ------------------------------------------------------------------ densification (gaussian_model.py:399-463)
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        """reference :461-463.  Same values, written as masked arithmetic over all P rows: boolean-mask indexing costs a
+        host sync per statement (the size of the selection), `x + 0` leaves the other rows bit-identical."""
         g = viewspace_point_tensor.grad if isinstance(viewspace_point_tensor, torch.Tensor) and \
             viewspace_point_tensor.grad is not None else viewspace_point_tensor
-        self.xyz_gradient_accum[update_filter] += torch.norm(g[update_filter, :2], dim=-1, keepdim=True)
-        self.denom[update_filter] += 1
+        if update_filter.dtype != torch.bool:        # an index list: the reference's statement as it is
+            self.xyz_gradient_accum[update_filter] += torch.norm(g[update_filter, :2], dim=-1, keepdim=True)
+            self.denom[update_filter] += 1
+            return
+        f = update_filter.reshape(-1, 1).to(self.xyz_gradient_accum.dtype)
+        norm = torch.norm(g[:, :2], dim=-1, keepdim=True)
+        self.xyz_gradient_accum += torch.where(update_filter.reshape(-1, 1), norm, torch.zeros_like(norm))
+        self.denom += f
 
     def _bind_store(self, flat_store, flat_grad_store, P):
         """Adopt already-filled flat buffers (layout of _bind) without copying."""
@@ -310,7 +333,7 @@ class GaussianModel:
         self._which_object = self._which_object.index_select(0, src64)
         stats = None if reset_stats else (self.xyz_gradient_accum.index_select(0, src64), self.denom.index_select(0, src64),
                                           self.max_radii2D.index_select(0, src64))
-        steps = opt.step_count if opt is not None else 0
+        steps = dict(opt.steps) if opt is not None else 0
         # the buffers just vacated serve the next compaction
         self._spare = {"store": cur.get("store", self.flat_store)}
         if opt is not None:
@@ -447,8 +470,43 @@ class GaussianModel:
         self._reset_stats()
         self.active_sh_degree = self.max_sh_degree
 
+    # ------------------------------------------------------------------ labels (gaussian_model.py:465-506)
+    def reset_label(self, obj_used_mask, set_which_object_to=None, overlap_threshold=0.8):
+        """Assign `set_which_object_to` to the Gaussians of obj_used_mask unless they largely (> overlap_threshold) belong
+        to earlier objects already; then the dominant earlier object decides: if the new set covers less than 60 % of
+        itself inside that object it becomes a new object anyway (returns None), otherwise it is merged into the old one
+        (returns the old id).  Decision rules and return values of reference reset_label; the counts are computed on the
+        device (one bincount instead of unique + .cpu() copies of two P-sized masks)."""
+        mask = obj_used_mask.reshape(-1).to(torch.bool)
+        wo = self._which_object.reshape(-1)
+        sel = wo[mask]
+        n_sel = int(mask.sum())
+        nonzero_count = int(torch.count_nonzero(sel))
+        if nonzero_count > 0:
+            overlap_ratio = nonzero_count / n_sel
+            if overlap_ratio > overlap_threshold:
+                counts = torch.bincount(sel.to(torch.int64).clamp_min(0))
+                counts[0] = 0
+                # torch.unique returns ascending values and argmax the first maximum: smallest id among equal counts
+                which_overlap_object = int(torch.argmax(counts))
+                old = wo == which_overlap_object
+                n_new = int(mask.sum())
+                intersect_ratio = float((mask & old).sum()) / n_new if n_new > 0 else 0.0
+                if intersect_ratio < 0.6:
+                    self._which_object[mask] = set_which_object_to
+                    return None
+                self._which_object[mask] = which_overlap_object
+                return which_overlap_object
+            self._which_object[mask] = set_which_object_to
+            return None
+        if set_which_object_to is not None:
+            self._which_object[mask] = set_which_object_to
+        return None
+
     # ------------------------------------------------------------------ checkpoint (gaussian_model.py:63-99)
     def capture(self):
+        """The reference's 13-tuple, optimizer state in torch.optim.Adam's state_dict layout (FlatAdam.state_dict), so a
+        checkpoint written here restores in the reference and vice versa."""
         return (self.active_sh_degree, self._xyz.detach().clone(), self._features_dc.detach().clone(),
                 self._features_rest.detach().clone(), self._scaling.detach().clone(), self._rotation.detach().clone(),
                 self._opacity.detach().clone(), self._which_object, self.max_radii2D, self.xyz_gradient_accum,
@@ -457,9 +515,12 @@ class GaussianModel:
     def restore(self, model_args, training_args):
         (self.active_sh_degree, xyz, f_dc, f_rest, scaling, rotation, opacity, which_object, max_radii2D, accum, denom,
          opt_dict, self.spatial_lr_scale) = model_args
-        self._bind(dict(xyz=xyz, f_dc=f_dc, f_rest=f_rest, opacity=opacity, scaling=scaling, rotation=rotation))
-        self._which_object = which_object
+        det = lambda t: t.detach() if isinstance(t, torch.Tensor) else t  # noqa: E731  (reference tuples hold nn.Parameters)
+        self._bind(dict(xyz=det(xyz), f_dc=det(f_dc), f_rest=det(f_rest), opacity=det(opacity), scaling=det(scaling),
+                        rotation=det(rotation)))
+        self._which_object = which_object.to(self.device)
         self.training_setup(training_args)
-        self.max_radii2D, self.xyz_gradient_accum, self.denom = max_radii2D, accum, denom
+        self.max_radii2D, self.xyz_gradient_accum, self.denom = (max_radii2D.to(self.device), accum.to(self.device),
+                                                                 denom.to(self.device))
         if opt_dict is not None:
             self.optimizer.load_state_dict(opt_dict)

@@ -25,16 +25,27 @@ def _settings(cls, cam, pc, bg_color, scaling_modifier, debug, **extra):
                prefiltered=False, debug=debug, **extra)
 
 
+# render() on this package's flat GaussianModel hands the PRE-ACTIVATION parameter blocks to the kernels (one autograd
+# node, no activation / cat kernels — fused_step._RasterizeRawFn).  False: always marshal activated tensors through
+# GaussianRasterizer exactly as the reference's render() does (what any other GaussianModel gets anyway).
+RAW_AUTOGRAD = True
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
     xyz = pc.get_xyz
-    if (not torch.is_grad_enabled() and override_color is None and hasattr(pc, "flat") and pc.flat.is_cuda and
+    if (override_color is None and hasattr(pc, "flat") and pc.flat.is_cuda and
             not pipe.compute_cov3D_python and not pipe.convert_SHs_python and pc.max_sh_degree == 3):
-        # evaluation renders (reference render.py:24-35, eval loops: all under no_grad) on the flat model: the
-        # raw-parameter forward — no exp / sigmoid / normalize launches, no cat of the (P,16,3) features
-        from .fused_step import render_raw
-        r = render_raw(viewpoint_camera, pc, bg_color, scaling_modifier)
-        return {"render": r["render"], "viewspace_points": torch.zeros_like(xyz), "visibility_filter": r["radii"] > 0,
-                "radii": r["radii"], "depth": r["depth"], "alpha": r["alpha"]}
+        if not torch.is_grad_enabled():
+            # evaluation renders (reference render.py:24-35, eval loops: all under no_grad) on the flat model: the
+            # raw-parameter forward — no exp / sigmoid / normalize launches, no cat of the (P,16,3) features
+            from .fused_step import render_raw
+            r = render_raw(viewpoint_camera, pc, bg_color, scaling_modifier)
+            return {"render": r["render"], "viewspace_points": torch.zeros_like(xyz), "visibility_filter": r["radii"] > 0,
+                    "radii": r["radii"], "depth": r["depth"], "alpha": r["alpha"]}
+        if RAW_AUTOGRAD:
+            # training renders (train_vanilla_3dgs.py:73): same kernels behind one autograd node
+            from .fused_step import render_raw_autograd
+            return render_raw_autograd(viewpoint_camera, pc, bg_color, scaling_modifier)
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
         screenspace_points.retain_grad()

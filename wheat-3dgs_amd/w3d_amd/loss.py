@@ -17,12 +17,38 @@ def l1_loss(network_output, gt):
     return torch.abs(network_output - gt).mean()
 
 
+class _FusedSSIM(torch.autograd.Function):
+    """ssim(img1, img2) of reference utils/loss_utils.py:39-63 through the fused HIP kernel pair (csrc/w3d_loss.hip,
+    called with lambda_dssim = 1: its loss is then exactly 1 - SSIM and its gradient -dSSIM/dimg1), so that the
+    UNCHANGED loss lines of train_vanilla_3dgs.py:77-79 run two LDS-tiled passes instead of five grouped 11x11
+    convolutions and their autograd backward.  Gradient w.r.t. img1 only (img2 is the ground truth there)."""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        from .fused import l1_ssim_fwd_bwd
+        loss, grad = l1_ssim_fwd_bwd(img1, img2, 1.0)
+        ctx.save_for_backward(grad)
+        return 1.0 - loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * (-g), None
+
+
 def gaussian_window_1d(window_size=11, sigma=1.5):
     g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
     return g / g.sum()
 
 
 def ssim(img1, img2, window_size=11, size_average=True):
+    if img1.is_cuda and img1.dim() == 3 and window_size == 11 and size_average and not img2.requires_grad:
+        return _FusedSSIM.apply(img1, img2)
+    return ssim_torch(img1, img2, window_size, size_average)
+
+
+def ssim_torch(img1, img2, window_size=11, size_average=True):
+    """The reference formula with torch ops (CPU tests, 4-D inputs, and the parity check of the fused kernel)."""
     channel = img1.size(-3)
     w1 = gaussian_window_1d(window_size).unsqueeze(1)
     window = w1.mm(w1.t()).float()[None, None].expand(channel, 1, window_size, window_size).contiguous().to(img1)
@@ -45,7 +71,7 @@ def psnr(img1, img2):
 
 
 def photometric_loss_torch(image, gt, lambda_dssim=0.2):
-    return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+    return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim_torch(image, gt))
 
 
 class _FusedL1SSIM(torch.autograd.Function):

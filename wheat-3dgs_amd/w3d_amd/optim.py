@@ -18,10 +18,14 @@ class FlatAdam:
         self.lrs = dict(lrs)
         self.betas = betas
         self.eps = eps
-        self.step_count = 0
+        # one step counter per parameter block, as torch.optim.Adam keeps one per parameter: a block whose update is
+        # skipped (its nn.Parameter was replaced in that iteration, so its .grad is None for the reference's optimizer)
+        # does not advance, and its bias corrections stay those of the steps it really took
+        self.steps = {n: 0 for n in self.lrs}
         if moments is not None and isinstance(moments[0], torch.Tensor):
             # flat moments with the layout of model.flat, adopted as they are (densification's compaction kernel wrote them)
-            self.exp_avg, self.exp_avg_sq, self.step_count = moments[0], moments[1], int(moments[2])
+            self.exp_avg, self.exp_avg_sq = moments[0], moments[1]
+            self._set_steps(moments[2])
             assert self.exp_avg.shape == model.flat.shape and self.exp_avg_sq.shape == model.flat.shape
             return
         self.exp_avg = torch.zeros_like(model.flat)
@@ -31,7 +35,22 @@ class FlatAdam:
             for name, (a, b) in model.block_slices().items():
                 self.exp_avg[a:b].copy_(new_m[name].reshape(-1))
                 self.exp_avg_sq[a:b].copy_(new_v[name].reshape(-1))
-            self.step_count = steps
+            self._set_steps(steps)
+
+    def _set_steps(self, steps):
+        if isinstance(steps, dict):
+            self.steps.update({n: int(v) for n, v in steps.items()})
+        else:
+            self.steps = {n: int(steps) for n in self.steps}
+
+    @property
+    def step_count(self):
+        """Largest per-block step (all blocks agree unless some were skipped)."""
+        return max(self.steps.values()) if self.steps else 0
+
+    @step_count.setter
+    def step_count(self, v):
+        self._set_steps(int(v))
 
     # -- the pieces of torch.optim.Optimizer the reference's host code touches
     @property
@@ -54,62 +73,111 @@ class FlatAdam:
         self.exp_avg_sq[a:b].zero_()
 
     def zero_grad(self, set_to_none=True):
-        # gradients are views of one flat buffer (the all-reduce bucket): zero it in place.
-        self.model.flat_grad.zero_()
+        """torch.optim.Optimizer.zero_grad (train_vanilla_3dgs.py:115 calls it with set_to_none=True): the parameters'
+        .grad become None, so the next autograd backward hands its gradient tensors over without an accumulation pass
+        (rasterizer backward writes them straight into the flat bucket and returns views of it).  set_to_none=False
+        zeroes the bucket in place and keeps the views."""
+        if set_to_none:
+            for p in self.model._p.values():
+                p.grad = None
+        else:
+            self.model.flat_grad.zero_()
+            self.model.bind_grad_views()
+
+    # torch.optim.Adam's state_dict layout (what a reference chkpnt*.pth holds as model_params[11],
+    # scene/gaussian_model.py:63-99): param_groups in training_setup's order, state[i] = {step, exp_avg, exp_avg_sq}
+    TORCH_GROUP_ORDER = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
 
     def state_dict(self):
-        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step_count,
-                "lrs": dict(self.lrs)}
+        mom = self.moments()
+        state, groups = {}, []
+        for i, n in enumerate(self.TORCH_GROUP_ORDER):
+            state[i] = {"step": torch.tensor(float(self.steps[n])), "exp_avg": mom[n][0].clone(),
+                        "exp_avg_sq": mom[n][1].clone()}
+            groups.append({"lr": self.lrs[n], "name": n, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0,
+                           "amsgrad": False, "maximize": False, "params": [i]})
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, d):
-        self.exp_avg.copy_(d["exp_avg"])
-        self.exp_avg_sq.copy_(d["exp_avg_sq"])
-        self.step_count = int(d["step"])
-        self.lrs.update(d["lrs"])
+        if "param_groups" not in d:      # round-1 flat layout
+            self.exp_avg.copy_(d["exp_avg"])
+            self.exp_avg_sq.copy_(d["exp_avg_sq"])
+            self._set_steps(d["step"])
+            self.lrs.update(d["lrs"])
+            return
+        sl = self.model.block_slices()
+        for i, g in enumerate(d["param_groups"]):
+            n = g.get("name", self.TORCH_GROUP_ORDER[i])
+            self.lrs[n] = float(g["lr"])
+            st = d["state"].get(g["params"][0])
+            a, b = sl[n]
+            if st is None:               # torch keeps no state for a parameter that never stepped
+                self.exp_avg[a:b].zero_()
+                self.exp_avg_sq[a:b].zero_()
+                self.steps[n] = 0
+                continue
+            self.exp_avg[a:b].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[a:b].copy_(st["exp_avg_sq"].reshape(-1))
+            self.steps[n] = int(st["step"])
 
-    def note_fused_step(self):
+    def note_fused_step(self, skip=()):
         """The backward kernel applied this step's update itself (fused_step.backward_raw_adam)."""
-        self.step_count += 1
+        for n in self.steps:
+            if n not in skip:
+                self.steps[n] += 1
 
-    def bias_corrections(self):
+    def advance(self, names, skip=()):
+        """Advance the step counters of `names` (minus `skip`) ahead of a step(advance=False) / sh_adam_lowrank pair."""
+        for n in names:
+            if n not in skip:
+                self.steps[n] += 1
+
+    def bias_corrections(self, name=None, ahead=0):
+        """(1 - beta1^t, 1 - beta2^t) of block `name` (default: the largest step), `ahead` steps from now."""
         b1, b2 = self.betas
-        return 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
+        t = (self.step_count if name is None else self.steps[name]) + ahead
+        return 1.0 - b1 ** t, 1.0 - b2 ** t
 
     @torch.no_grad()
     def step(self, zero_grad=False, skip=(), elem_range=None, only=None, advance=True):
         """One Adam step on every block.  zero_grad=True clears the gradient bucket in the same
         sweep (what `optimizer.zero_grad(set_to_none=True)` achieves at train_vanilla_3dgs.py:115).
+        A block in `skip`, or whose parameter has .grad None (torch.optim.Adam's rule), is left alone and its step
+        counter does not advance.
         elem_range=(lo, hi): only that slice of the flat buffer is stepped — the shard this rank owns in
         the dense view-parallel exchange (the other shards arrive through the parameter all-gather).
-        only=names: step just these blocks; advance=False: the step counter was already advanced for this
+        only=names: step just these blocks; advance=False: the step counters were already advanced for this
         iteration (the low-rank exchange steps the geometry blocks and the SH blocks separately)."""
-        if advance:
-            self.step_count += 1
         b1, b2 = self.betas
-        bc1 = 1.0 - b1 ** self.step_count
-        bc2 = 1.0 - b2 ** self.step_count
         p, g, m, v = self.model.flat, self.model.flat_grad, self.exp_avg, self.exp_avg_sq
         slices = {}
         for name, (a, b) in self.model.block_slices().items():
+            if only is not None and name not in only:
+                continue
+            stepped = name not in skip and self.model._p[name].grad is not None
+            if stepped and advance:
+                self.steps[name] += 1          # (the counter follows the block, not the shard this rank sweeps)
             if elem_range is not None:
                 a, b = max(a, elem_range[0]), min(b, elem_range[1])
-            if a < b and (only is None or name in only):
-                slices[name] = (a, b)
+            if a < b:
+                slices[name] = (a, b, stepped)
         if p.is_cuda:
             from .fused import adam_step
-            for name, (a, b) in slices.items():
-                if name in skip:
+            for name, (a, b, stepped) in slices.items():
+                if not stepped:
                     if zero_grad:
                         g[a:b].zero_()
                     continue
+                bc1, bc2 = self.bias_corrections(name)
                 adam_step(p[a:b], g[a:b], m[a:b], v[a:b], self.lrs[name], b1, b2, self.eps, bc1, bc2, zero_grad)
             return
-        for name, (a, b) in slices.items():
+        for name, (a, b, stepped) in slices.items():
             gg = g[a:b]
-            if name in skip:
+            if not stepped:
                 if zero_grad:
                     gg.zero_()
                 continue
+            bc1, bc2 = self.bias_corrections(name)
             m[a:b].mul_(b1).add_(gg, alpha=1 - b1)
             v[a:b].mul_(b2).addcmul_(gg, gg, value=1 - b2)
             denom = (v[a:b].sqrt() / math.sqrt(bc2)).add_(self.eps)

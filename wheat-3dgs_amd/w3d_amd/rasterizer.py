@@ -57,6 +57,39 @@ class FlashSplatRasterizationSettings(NamedTuple):
     num_obj: int = 2
 
 
+class ListCapacity:
+    """Speculative sizing of the per-tile list buffer, so that the forward's only host wait overlaps GPU work.
+
+    The list length R (= num_rendered) is only known on the device after stage 1.  Waiting for it before stage 2 can be
+    launched leaves the GPU idle for the host's wake-up + allocation + launch.  Instead the list is allocated from the
+    largest R seen so far for this image size (x `slack`), stage 2 is enqueued right behind stage 1, and only then does
+    the host wait for the counters — which the GPU produced BEFORE it started stage 2, so the wait ends while stage 2
+    is still running.  The fill kernel never writes past the capacity it was given; if R turns out larger, stage 2 is
+    simply run again with the exact size (outputs are overwritten)."""
+
+    def __init__(self, slack=1.25):
+        self.slack = slack
+        self.known = 0          # largest R observed
+
+    def guess(self):
+        return int(self.known * self.slack) + 1024 if self.known else 0
+
+    def observe(self, R):
+        self.known = max(self.known, int(R))
+
+
+_capacities = {}
+
+
+def list_capacity(device, H, W) -> ListCapacity:
+    """One estimate per (device, image size): list lengths of different resolutions have nothing to do with each other."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(H), int(W))
+    cap = _capacities.get(key)
+    if cap is None:
+        cap = _capacities[key] = ListCapacity()
+    return cap
+
+
 def _f32c(t: Optional[torch.Tensor], device):
     if t is None:
         return None
@@ -91,7 +124,6 @@ class _View:
         v.bg, v.viewmatrix = self.bg.data_ptr(), self.vm.data_ptr()
         v.projmatrix, v.campos = self.pm.data_ptr(), self.cp.data_ptr()
         v.tile_cull = int(bool(TILE_CULL))
-        v.depth_layers = 0
         self.c = v
 
 
@@ -128,12 +160,29 @@ def _forward_impl(settings, means3D, shs, colors_precomp, opacities, scales, rot
         state = torch.empty(state_b.value, dtype=torch.uint8, device=dev)
         scratch = torch.empty(scratch_b.value, dtype=torch.uint8, device=dev)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
-        counts = (ctypes.c_uint32 * 2)()
-        check(lib.w3d_forward_stage1(ctypes.byref(view.c), P, ptr(means3D), ptr(shs), ptr(colors_precomp),
-                                     ptr(opacities), ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(radii),
-                                     ptr(state), ptr(scratch), ctypes.cast(counts, ctypes.c_void_p), stream))
-        num_rendered = int(counts[1])
-        point_list = torch.empty(max(num_rendered, 1), dtype=torch.int32, device=dev)
+        cap = list_capacity(dev, H, W)
+        guess = cap.guess()
+        pending = None
+        if guess == 0:
+            # first view of this size: nothing to go by, wait for R before the list is allocated
+            counts = (ctypes.c_uint32 * 2)()
+            check(lib.w3d_forward_stage1(ctypes.byref(view.c), P, ptr(means3D), ptr(shs), ptr(colors_precomp),
+                                         ptr(opacities), ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(radii),
+                                         ptr(state), ptr(scratch), ctypes.cast(counts, ctypes.c_void_p), stream))
+            num_visible, num_rendered = int(counts[0]), int(counts[1])
+            cap.observe(num_rendered)
+            list_len = num_rendered
+        else:
+            # speculative list size (ListCapacity): the counters start their way to the host right after stage 1
+            check(lib.w3d_forward_stage1(ctypes.byref(view.c), P, ptr(means3D), ptr(shs), ptr(colors_precomp),
+                                         ptr(opacities), ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(radii),
+                                         ptr(state), ptr(scratch), None, stream))
+            pinned = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            pinned.copy_(state[:8].view(torch.int32), non_blocking=True)
+            pending = torch.cuda.Event()
+            pending.record()
+            list_len = guess
+        point_list = torch.empty(max(list_len, 1), dtype=torch.int32, device=dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
         alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
@@ -152,13 +201,26 @@ def _forward_impl(settings, means3D, shs, colors_precomp, opacities, scales, rot
             proj_xy = torch.empty(P, 2, dtype=torch.float32, device=dev)
             gs_depth = torch.empty(P, dtype=torch.float32, device=dev)
             extras = (contrib_num, used_count, proj_xy, gs_depth)
-        check(lib.w3d_forward_stage2(ctypes.byref(view.c), P, ptr(state), ptr(scratch), ptr(point_list),
-                                     ctypes.c_uint64(num_rendered), ptr(color), ptr(depth), ptr(alpha),
-                                     ptr(gt_mask), num_obj, ptr(used_count), ptr(contrib_num), ptr(proj_xy),
-                                     ptr(gs_depth), stream))
+
+        def stage2():
+            check(lib.w3d_forward_stage2(ctypes.byref(view.c), P, ptr(state), ptr(scratch), ptr(point_list),
+                                         ctypes.c_uint64(list_len), ptr(color), ptr(depth), ptr(alpha),
+                                         ptr(gt_mask), num_obj, ptr(used_count), ptr(contrib_num), ptr(proj_xy),
+                                         ptr(gs_depth), stream))
+        stage2()
+        if pending is not None:
+            pending.synchronize()          # the GPU is inside stage 2 by now: this wait costs it nothing
+            num_visible, num_rendered = int(pinned[0]) & 0xFFFFFFFF, int(pinned[1]) & 0xFFFFFFFF
+            cap.observe(num_rendered)
+            if num_rendered > list_len:    # the guess was too small: same stage again with the exact size
+                list_len = num_rendered
+                point_list = torch.empty(list_len, dtype=torch.int32, device=dev)
+                if used_count is not None:
+                    used_count.zero_()     # (stage 2 accumulates into it)
+                stage2()
     saved = dict(view=view, P=P, means3D=means3D, shs=shs, colors_precomp=colors_precomp, opacities=opacities,
                  scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, state=state,
-                 point_list=point_list, num_rendered=num_rendered, num_visible=int(counts[0]))
+                 point_list=point_list, num_rendered=num_rendered, num_visible=num_visible)
     return color, radii, depth, alpha, saved, extras
 
 

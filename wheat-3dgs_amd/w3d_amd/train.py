@@ -15,8 +15,6 @@ same step; then
   * densify/prune then run identically on every rank (same statistics, same RNG seed for the
     split samples) so the replicas stay in lock-step without a parameter broadcast.
 """
-import os
-
 import torch
 import torch.distributed as dist
 
@@ -39,7 +37,17 @@ def dist_info():
 
 class Trainer:
     def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
-                 densify=True, loss_fn=photometric_loss, fused=None, force_exchange=False):
+                 densify=True, loss_fn=photometric_loss, fused=None, force_exchange=False, fused_adam=True,
+                 exchange="lowrank", early_gather=False, lowrank_chunks=None):
+        """fused_adam: single GPU — the optimizer update is applied by the backward kernel itself
+        (fused_step.backward_raw_adam), except in the iterations that densify / reset opacity (there the reference
+        skips the replaced parameters' update).
+        exchange: view-parallel exchange of the fused step.  "lowrank" ships dL/dRGB (3 floats per Gaussian and view)
+        plus the 11 geometry gradients and replicates the optimizer; "dense" reduce-scatters the 59-float bucket, shards
+        Adam and all-gathers the parameters (also what the autograd step uses).
+        early_gather (lowrank only): issue the colour-gradient all-gather between the blend backward and the
+        per-Gaussian backward, so that it travels while that kernel runs (costs a 25-us extraction kernel).
+        lowrank_chunks: row chunks of the colour-gradient all-gather (None: 4 above 256 k Gaussians)."""
         self.model, self.cameras, self.opt = model, cameras, opt
         self.bg = background
         self.pipe = pipe or PipelineParams()
@@ -53,29 +61,21 @@ class Trainer:
                          not self.pipe.convert_SHs_python and not self.pipe.compute_cov3D_python)
         self.fused = fused
         self.rank, self.world = dist_info()
+        if self.world > 1 and model.flat_store.numel() % self.world != 0:
+            # the flat buffers are padded to a multiple of 256 elements (GaussianModel._bind): the dense exchange shards
+            # them evenly only for world sizes that divide 256
+            raise ValueError(f"world size {self.world} does not divide the padded parameter buffer "
+                             f"({model.flat_store.numel()} elements, a multiple of 256): use 1, 2, 4, 8, ... ranks")
         # force_exchange: run the multi-rank exchange path (collectives, sharded optimizer) even in a
         # 1-rank process group — lets the RCCL code path be exercised on a single GPU
         self.force_exchange = bool(force_exchange)
-        # speculative per-tile list truncation from the previous visit of each camera (fused step only).
-        # OFF by default: exact (verified, view repeated on a miss) but measured slower on the benchmark —
-        # with the banded walk only ~12 Gaussians per 64-batch reach the serial loop, so the per-lane
-        # pre-filter over each Gaussian's tiles costs as much as it saves, and the fast-changing synthetic
-        # scene misses its cuts on ~60 % of the revisits.
-        # single GPU: the optimizer update is applied by the backward kernel itself (fused_step.backward_raw_adam), except
-        # in the iterations that densify / reset opacity (there the reference skips the replaced parameters' update)
-        self.fused_adam = os.environ.get("W3D_FUSED_ADAM", "1") == "1"
-        # view-parallel exchange of the fused step: "lowrank" ships dL/dRGB (3 floats per Gaussian and view) + the 11
-        # geometry gradients and replicates the optimizer; "dense" reduce-scatters the 59-float bucket, shards Adam and
-        # all-gathers the parameters (also what the autograd step uses)
-        self.exchange_mode = os.environ.get("W3D_EXCHANGE", "lowrank")
-        # lowrank only: issue the colour-gradient all-gather between the blend backward and the per-Gaussian backward (it
-        # then travels while that kernel runs).  OFF until measured on a multi-GPU node: it costs a 25 us extraction kernel
-        self.early_gather = os.environ.get("W3D_EARLY_GATHER", "0") == "1"
+        if exchange not in ("lowrank", "dense"):
+            raise ValueError("exchange must be 'lowrank' or 'dense'")
+        self.fused_adam = bool(fused_adam)
+        self.exchange_mode = exchange
+        self.early_gather = bool(early_gather)
         self._d_chunks, self._geo_work = [], None
-        self.lowrank_chunks = None          # row chunks of the colour-gradient all-gather (None: 4 above 256 k Gaussians)
-        self.use_depth_cuts = os.environ.get("W3D_DEPTH_CUTS", "0") == "1"
-        self.depth_cuts = {}
-        self.cut_misses = 0
+        self.lowrank_chunks = lowrank_chunks
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.perm = torch.randperm(len(cameras), generator=g).tolist()
         self.last = {}
@@ -176,9 +176,9 @@ class Trainer:
         """Replicated optimizer step after exchange_lowrank: SH blocks from the gathered colour gradients (needs the
         pre-update xyz, so it runs first, while the geometry all-reduces are still in flight), then the geometry blocks
         from the reduced bucket.  Identical inputs and a fixed view order keep the replicas bit-identical."""
-        from .fused_step import GEO_BLOCKS, sh_adam_lowrank
+        from .fused_step import GEO_BLOCKS, SH_BLOCKS, sh_adam_lowrank
         m = self.model
-        m.optimizer.step_count += 1
+        m.optimizer.advance(GEO_BLOCKS + SH_BLOCKS, skip)
         campos = self.campos_of_all_ranks(iteration).to(m.flat.device)
         whole = len(self._d_chunks) == 1
         for rows, d_all, work in self._d_chunks:
@@ -238,6 +238,13 @@ class Trainer:
             buf.copy_(full[:n])
         self._moments_sharded = False
 
+    def capture(self):
+        """GaussianModel.capture() of a consistent replica: in the dense exchange every rank only steps the Adam moments
+        of its shard, so they are gathered first."""
+        self.gather_moments()
+        assert not getattr(self, "_moments_sharded", False)
+        return self.model.capture()
+
     def _structure_change_due(self, iteration):
         """Does _post_backward densify / prune / reset opacity in this iteration?"""
         opt = self.opt
@@ -287,19 +294,16 @@ class Trainer:
         with torch.no_grad():
             tracking = iteration < opt.densify_until_iter
             single = self.world == 1 and not self.force_exchange
-            # per-camera depth cuts from the previous visit (speculative list truncation, verified by finish())
-            key = id(cam)
-            cut = self.depth_cuts.get(key) if self.use_depth_cuts else None
             lowrank = (not single) and self.exchange_mode == "lowrank" and m.max_sh_degree == 3
             dcol = None
-            use_adam = (single and self.fused_adam and not self.use_depth_cuts and iteration < opt.iterations and
+            use_adam = (single and self.fused_adam and iteration < opt.iterations and
                         m.max_sh_degree == 3 and not self._structure_change_due(iteration))
             attempts = 0
             while True:
                 attempts += 1
                 if attempts > 4:      # one repeat sizes the list buffer exactly; more means the counters are corrupt
                     raise RuntimeError("fused step: the forward keeps reporting an overflowing list buffer")
-                pkg = render_raw(cam, m, self.bg, sync=False, depth_cut=cut, want_cut=self.use_depth_cuts)
+                pkg = render_raw(cam, m, self.bg, sync=False)
                 loss, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
                 if not single and self.world > 1:
                     dimg.mul_(1.0 / self.world)      # the bucket then holds grad/world: reduce-scatter(SUM) = mean
@@ -321,11 +325,6 @@ class Trainer:
                     gnorm, _ = backward_raw(m, pkg["handle"], dimg, update_stats=False, want_norm=True)
                 if finish(pkg["handle"]):        # the only host wait of the step, with the backward already queued
                     break                        # (on overflow the fused-Adam kernel updated nothing: repeat the view)
-                if pkg["handle"]["suspect_tiles"]:
-                    cut = None                   # some tile needed more than its cut allowed: repeat without cuts
-                    self.cut_misses += 1
-            if self.use_depth_cuts and pkg["handle"]["depth_cut_out"] is not None:
-                self.depth_cuts[key] = pkg["handle"]["depth_cut_out"]
             if single and tracking and not use_adam:       # (the fused-Adam kernel updated the statistics itself)
                 vis = pkg["radii"] > 0
                 m.xyz_gradient_accum += gnorm[:, None]          # gnorm is 0 on culled Gaussians
@@ -393,7 +392,7 @@ class Trainer:
         return loss.detach()
 
 
-RENDER_STREAMS = int(os.environ.get("W3D_RENDER_STREAMS", "2"))
+RENDER_STREAMS = 2      # frames in flight of render_views (independent frames overlap each other's latency-bound stages)
 
 
 def render_views(model, cameras, background, pipe=None):
