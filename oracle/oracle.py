@@ -137,6 +137,12 @@ class COracle:
             out.update(used_count=used_count, contrib_num=contrib_num, proj_xy=proj_xy, gs_depth=gs_depth)
         return out
 
+    @classmethod
+    def set_exp_mode(cls, mode):
+        """0: expf(power) (the restated algorithm).  1: exp2f(power * log2 e) — a rounding-sensitivity probe for the tests:
+        the spread between the two runs is the uncertainty any fp32 implementation has against this oracle."""
+        cls.lib().w3do_set_exp_mode(ctypes.c_int(int(mode)))
+
     def num_rendered(self):
         return int(self.lib().w3do_num_rendered(ctypes.c_void_p(self.h)))
 

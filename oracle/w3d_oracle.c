@@ -43,6 +43,35 @@
 
 #define TILE 16
 
+/* Rounding-sensitivity probe (tests only).  Mode 0 is the restated algorithm: expf(power), per-Gaussian gradient sums in
+ * double.  Bit 0 set: exp2f(power * log2 e) instead of expf — the same function with other roundings.  Bit 1 set: the
+ * per-Gaussian sums are accumulated in fp32 in whatever order the threads arrive, which is what a GPU implementation with
+ * float atomics (the reference's CUDA rasterizer included) does.  Bit 2 set: FMA-contracted exponent (w3do_power).
+ * Every variant is a valid fp32 evaluation of the same
+ * formulas: the spread between a probe run and the mode-0 run is the uncertainty ANY fp32 implementation has against this
+ * oracle — (pixel, Gaussian) pairs whose alpha sits on the 1/255 threshold and pixels whose transmittance sits on 1e-4
+ * flip, and ill-conditioned per-Gaussian sums move. */
+static int g_exp_mode = 0;
+void w3do_set_exp_mode(int mode) { g_exp_mode = mode; }
+static inline float w3do_exp(float x) { return (g_exp_mode & 1) ? exp2f(x * 1.4426950408889634f) : expf(x); }
+/* the exponent of a (pixel, Gaussian) pair.  Probe bit 2: the same expression with the multiply-adds contracted into FMAs,
+ * as a GPU compiler does by default (nvcc -fmad=true for the reference's CUDA build; this file itself is compiled with
+ * -ffp-contract=off) */
+static inline float w3do_power(const float *co, float dx, float dy) {
+    if (g_exp_mode & 4) return fmaf(-0.5f, fmaf(co[2] * dy, dy, co[0] * dx * dx), -(co[1] * dx * dy));
+    return -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+}
+/* one term of a per-Gaussian gradient sum: double accumulator, or (probe bit 1) an fp32 one */
+static inline void acc_add(double *a, float *af, float x) {
+    if (af) {
+#pragma omp atomic
+        *af += x;
+    } else {
+#pragma omp atomic
+        *a += (double)x;
+    }
+}
+
 typedef struct W3DOView {
     int H, W;
     float tanfovx, tanfovy;
@@ -348,9 +377,9 @@ void *w3do_forward(const W3DOView *v, int P, const float *means3D, const float *
                     uint32_t g = s->point_list[i];
                     float dx = s->xy[2 * (size_t)g] - pxf, dy = s->xy[2 * (size_t)g + 1] - pyf;
                     const float *co = s->conic_op + 4 * (size_t)g;
-                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    float power = w3do_power(co, dx, dy);
                     if (power > 0.0f) continue;
-                    float alpha = fminf(0.99f, co[3] * expf(power));
+                    float alpha = fminf(0.99f, co[3] * w3do_exp(power));
                     if (alpha < 1.0f / 255.0f) continue;
                     float test_T = Tr * (1.f - alpha);
                     if (test_T < 0.0001f) break; /* this entry is NOT applied */
@@ -425,6 +454,7 @@ void w3do_backward(void *h, const W3DOView *v, const float *means3D, const float
     /* double accumulators: [mean2D.x, mean2D.y, conic.x, conic.y(half), conic.z, opacity, r, g, b, depth] */
     enum { NA = 10 };
     double *acc = (double *)calloc((size_t)P * NA + 1, sizeof(double));
+    float *accf = (g_exp_mode & 2) ? (float *)calloc((size_t)P * NA + 1, sizeof(float)) : NULL;
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
 
     /* ---- A.4 blend backward: reverse walk per pixel */
@@ -450,30 +480,30 @@ void w3do_backward(void *h, const W3DOView *v, const float *means3D, const float
                     (void)e;
                     float dx = s->xy[2 * (size_t)g] - pxf, dy = s->xy[2 * (size_t)g + 1] - pyf;
                     const float *co = s->conic_op + 4 * (size_t)g;
-                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    float power = w3do_power(co, dx, dy);
                     if (power > 0.0f) continue;
-                    float G = expf(power);
+                    float G = w3do_exp(power);
                     float alpha = fminf(0.99f, co[3] * G);
                     if (alpha < 1.0f / 255.0f) continue;
                     Tr = Tr / (1.f - alpha);
                     float dch = alpha * Tr;
                     float dL_dalpha = 0.f;
                     double *a = acc + (size_t)g * NA;
+                    float *af = accf ? accf + (size_t)g * NA : NULL;
+#define ACC(i, x) acc_add(a + (i), af ? af + (i) : NULL, (x))
                     for (int ch = 0; ch < 3; ch++) {
                         float c = s->rgb[3 * (size_t)g + ch];
                         accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
                         last_color[ch] = c;
                         dL_dalpha += (c - accum_rec[ch]) * dLdp[ch];
-#pragma omp atomic
-                        a[6 + ch] += (double)(dch * dLdp[ch]);
+                        ACC(6 + ch, dch * dLdp[ch]);
                     }
                     {
                         float cd = s->depth[g];
                         accum_d = last_alpha * last_depth + (1.f - last_alpha) * accum_d;
                         last_depth = cd;
                         dL_dalpha += (cd - accum_d) * dLdd;
-#pragma omp atomic
-                        a[9] += (double)(dch * dLdd);
+                        ACC(9, dch * dLdd);
                         accum_a = last_alpha * 1.0f + (1.f - last_alpha) * accum_a;
                         dL_dalpha += (1.0f - accum_a) * dLda;
                     }
@@ -484,20 +514,20 @@ void w3do_backward(void *h, const W3DOView *v, const float *means3D, const float
                     float gdx = G * dx, gdy = G * dy;
                     float dG_ddelx = -gdx * co[0] - gdy * co[1];
                     float dG_ddely = -gdy * co[2] - gdx * co[1];
-#pragma omp atomic
-                    a[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
-#pragma omp atomic
-                    a[1] += (double)(dL_dG * dG_ddely * ddely_dy);
-#pragma omp atomic
-                    a[2] += (double)(-0.5f * gdx * dx * dL_dG);
-#pragma omp atomic
-                    a[3] += (double)(-0.5f * gdx * dy * dL_dG);
-#pragma omp atomic
-                    a[4] += (double)(-0.5f * gdy * dy * dL_dG);
-#pragma omp atomic
-                    a[5] += (double)(G * dL_dalpha);
+                    ACC(0, dL_dG * dG_ddelx * ddelx_dx);
+                    ACC(1, dL_dG * dG_ddely * ddely_dy);
+                    ACC(2, -0.5f * gdx * dx * dL_dG);
+                    ACC(3, -0.5f * gdx * dy * dL_dG);
+                    ACC(4, -0.5f * gdy * dy * dL_dG);
+                    ACC(5, G * dL_dalpha);
                 }
             }
+    }
+
+#undef ACC
+    if (accf) {
+        for (size_t i = 0; i < (size_t)P * NA; i++) acc[i] = (double)accf[i];
+        free(accf);
     }
 
     /* ---- A.5 preprocess backward */

@@ -31,10 +31,17 @@
         }                                                                                   \
     } while (0)
 
-enum Op { OP_FMA = 0, OP_EXP, OP_RCP, OP_DPP_QUAD, OP_DPP_ROWMIRROR, OP_DPP_BCAST, OP_CMP, OP_CNDMASK, OP_MIX, OP_PKFMA, N_OPS };
+enum Op { OP_FMA = 0, OP_EXP, OP_RCP, OP_DPP_QUAD, OP_DPP_ROWMIRROR, OP_DPP_BCAST, OP_CMP, OP_CNDMASK, OP_MIX, OP_PKFMA,
+          OP_MUL, OP_MAX, OP_CNDMASK_SGPR, OP_CMP_SGPR, OP_READFIRSTLANE, OP_MOV_DPP, OP_LDS_READ128_BCAST, OP_LDS_ADD_ROWLEADERS,
+          OP_CNDMASK_VCC_SET, OP_CNDMASK_E64_VCC, OP_CNDMASK_E32_MIXED, OP_CMP_CNDMASK_PAIRS, N_OPS };
 static const char *op_name[N_OPS] = {"v_fma_f32",           "v_exp_f32",           "v_rcp_f32",   "v_add_f32_dpp quad_perm",
                                      "v_add_f32_dpp row_mirror", "v_add_f32_dpp row_bcast15", "v_cmp_lt_f32", "v_cndmask_b32",
-                                     "blend-bwd mix (1 exp + 1 rcp + 4 dpp + 2 cmp + 56 fma)", "v_pk_fma_f32"};
+                                     "blend-bwd mix (1 exp + 1 rcp + 4 dpp + 2 cmp + 56 fma)", "v_pk_fma_f32",
+                                     "v_mul_f32", "v_max_f32", "v_cndmask_b32 e64 (SGPR-pair mask)", "v_cmp_lt_f32 e64 (SGPR-pair result)",
+                                     "v_readfirstlane_b32", "v_mov_b32_dpp row_mirror", "ds_read_b128 (all lanes one address)",
+                                     "ds_add_f32 (4 lanes, one address)", "v_cndmask_b32 (vcc written before the loop)",
+                                     "v_cndmask_b32_e64 with vcc as the explicit mask operand", "4 v_cndmask_b32_e32 + 4 v_fma_f32 alternating",
+                                     "4 x (v_cmp_lt_f32 vcc ; v_cndmask_b32_e32 vcc) pairs"};
 
 template <int OP>
 __global__ void __launch_bounds__(1024) valu_kernel(float *out, uint32_t *hwid, int iters) {
@@ -43,6 +50,14 @@ __global__ void __launch_bounds__(1024) valu_kernel(float *out, uint32_t *hwid, 
     for (int i = 0; i < 8; i++) a[i] = 0.25f + 1e-3f * (float)((threadIdx.x + i) & 63);
     float b = 0.999f, c = 1e-3f;
     asm volatile("" : "+v"(b), "+v"(c));
+    __shared__ float lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    // (per-wave LDS address, identical in all lanes of the wave)
+    const unsigned lds_addr = (unsigned)(uintptr_t)(&lds[(threadIdx.x >> 6) * 64]);
+    unsigned long long smask = 0x5555555555555555ull, sink = 0;
+    asm volatile("" : "+s"(smask));
+    if (OP == OP_CNDMASK_VCC_SET || OP == OP_CNDMASK_E64_VCC || OP == OP_CNDMASK_E32_MIXED) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[0]), "v"(b) : "vcc");
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -92,6 +107,85 @@ __global__ void __launch_bounds__(1024) valu_kernel(float *out, uint32_t *hwid, 
                 asm volatile("v_pk_fma_f32 %0, %0, %4, %5\nv_pk_fma_f32 %1, %1, %4, %5\nv_pk_fma_f32 %2, %2, %4, %5\nv_pk_fma_f32 %3, %3, %4, %5\n"
                              : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3])
                              : "v"(bb), "v"(cc));
+            } else if (OP == OP_MUL) {
+                asm volatile("v_mul_f32 %0, %0, %8\nv_mul_f32 %1, %1, %8\nv_mul_f32 %2, %2, %8\nv_mul_f32 %3, %3, %8\n"
+                             "v_mul_f32 %4, %4, %8\nv_mul_f32 %5, %5, %8\nv_mul_f32 %6, %6, %8\nv_mul_f32 %7, %7, %8\n"
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                             : "v"(b));
+            } else if (OP == OP_MAX) {
+                asm volatile("v_max_f32 %0, %0, %8\nv_max_f32 %1, %1, %8\nv_max_f32 %2, %2, %8\nv_max_f32 %3, %3, %8\n"
+                             "v_max_f32 %4, %4, %8\nv_max_f32 %5, %5, %8\nv_max_f32 %6, %6, %8\nv_max_f32 %7, %7, %8\n"
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                             : "v"(b));
+            } else if (OP == OP_CNDMASK_SGPR) {
+                asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\nv_cndmask_b32_e64 %1, %1, %8, %9\nv_cndmask_b32_e64 %2, %2, %8, %9\n"
+                             "v_cndmask_b32_e64 %3, %3, %8, %9\nv_cndmask_b32_e64 %4, %4, %8, %9\nv_cndmask_b32_e64 %5, %5, %8, %9\n"
+                             "v_cndmask_b32_e64 %6, %6, %8, %9\nv_cndmask_b32_e64 %7, %7, %8, %9\n"
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                             : "v"(b), "s"(smask));
+            } else if (OP == OP_CNDMASK_VCC_SET) {
+                asm volatile("v_cndmask_b32 %0, %0, %8, vcc\nv_cndmask_b32 %1, %1, %8, vcc\nv_cndmask_b32 %2, %2, %8, vcc\n"
+                             "v_cndmask_b32 %3, %3, %8, vcc\nv_cndmask_b32 %4, %4, %8, vcc\nv_cndmask_b32 %5, %5, %8, vcc\n"
+                             "v_cndmask_b32 %6, %6, %8, vcc\nv_cndmask_b32 %7, %7, %8, vcc\n"
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                             : "v"(b));
+            } else if (OP == OP_CNDMASK_E64_VCC) {
+                asm volatile("v_cndmask_b32_e64 %0, %0, %8, vcc\nv_cndmask_b32_e64 %1, %1, %8, vcc\nv_cndmask_b32_e64 %2, %2, %8, vcc\n"
+                             "v_cndmask_b32_e64 %3, %3, %8, vcc\nv_cndmask_b32_e64 %4, %4, %8, vcc\nv_cndmask_b32_e64 %5, %5, %8, vcc\n"
+                             "v_cndmask_b32_e64 %6, %6, %8, vcc\nv_cndmask_b32_e64 %7, %7, %8, vcc\n"
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                             : "v"(b));
+            } else if (OP == OP_CNDMASK_E32_MIXED) {
+                asm volatile("v_cndmask_b32 %0, %0, %8, vcc\nv_fma_f32 %1, %1, %8, %9\nv_cndmask_b32 %2, %2, %8, vcc\nv_fma_f32 %3, %3, %8, %9\n"
+                             "v_cndmask_b32 %4, %4, %8, vcc\nv_fma_f32 %5, %5, %8, %9\nv_cndmask_b32 %6, %6, %8, vcc\nv_fma_f32 %7, %7, %8, %9\n"
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                             : "v"(b), "v"(c));
+            } else if (OP == OP_CMP_CNDMASK_PAIRS) {
+                asm volatile("v_cmp_lt_f32 vcc, %1, %8\nv_cndmask_b32 %0, %0, %8, vcc\nv_cmp_lt_f32 vcc, %3, %8\nv_cndmask_b32 %2, %2, %8, vcc\n"
+                             "v_cmp_lt_f32 vcc, %5, %8\nv_cndmask_b32 %4, %4, %8, vcc\nv_cmp_lt_f32 vcc, %7, %8\nv_cndmask_b32 %6, %6, %8, vcc\n"
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                             : "v"(b)
+                             : "vcc");
+            } else if (OP == OP_CMP_SGPR) {
+                unsigned long long r0, r1, r2, r3;
+                asm volatile("v_cmp_lt_f32_e64 %0, %4, %8\nv_cmp_lt_f32_e64 %1, %5, %8\nv_cmp_lt_f32_e64 %2, %6, %8\nv_cmp_lt_f32_e64 %3, %7, %8\n"
+                             "v_cmp_lt_f32_e64 %0, %5, %8\nv_cmp_lt_f32_e64 %1, %6, %8\nv_cmp_lt_f32_e64 %2, %7, %8\nv_cmp_lt_f32_e64 %3, %4, %8\n"
+                             : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3)
+                             : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b));
+                sink ^= r0 ^ r1 ^ r2 ^ r3;
+            } else if (OP == OP_READFIRSTLANE) {
+                unsigned r0, r1, r2, r3;
+                asm volatile("v_readfirstlane_b32 %0, %4\nv_readfirstlane_b32 %1, %5\nv_readfirstlane_b32 %2, %6\nv_readfirstlane_b32 %3, %7\n"
+                             "v_readfirstlane_b32 %0, %5\nv_readfirstlane_b32 %1, %6\nv_readfirstlane_b32 %2, %7\nv_readfirstlane_b32 %3, %4\n"
+                             : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3)
+                             : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+                sink ^= (unsigned long long)(r0 ^ r1 ^ r2 ^ r3);
+            } else if (OP == OP_MOV_DPP) {
+                asm volatile("v_mov_b32_dpp %0, %1 row_mirror row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %1, %2 row_mirror row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %2, %3 row_mirror row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %3, %4 row_mirror row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %4, %5 row_mirror row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %5, %6 row_mirror row_mask:0xf bank_mask:0xf\n"
+                             "v_mov_b32_dpp %6, %7 row_mirror row_mask:0xf bank_mask:0xf\nv_mov_b32_dpp %7, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+                             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+            } else if (OP == OP_LDS_READ128_BCAST) {
+                // what the blend loops do per list entry: every lane reads the same 16 B of the staged record
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 t0, t1, t2, t3, t4, t5, t6, t7;
+                asm volatile("ds_read_b128 %0, %8\nds_read_b128 %1, %8 offset:16\nds_read_b128 %2, %8 offset:32\nds_read_b128 %3, %8 offset:48\n"
+                             "ds_read_b128 %4, %8 offset:64\nds_read_b128 %5, %8 offset:80\nds_read_b128 %6, %8 offset:96\nds_read_b128 %7, %8 offset:112\n"
+                             "s_waitcnt lgkmcnt(0)\n"
+                             : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                             : "v"(lds_addr)
+                             : "memory");
+                a[0] += t0.x + t1.y + t2.z + t3.w + t4.x + t5.y + t6.z + t7.w;
+            } else if (OP == OP_LDS_ADD_ROWLEADERS) {
+                // the blend backward's per-entry accumulation: the 4 row leaders add into ONE LDS word (exec = lanes 0,16,32,48)
+                if ((threadIdx.x & 15) == 0) {
+                    asm volatile("ds_add_f32 %0, %1\nds_add_f32 %0, %1 offset:4\nds_add_f32 %0, %1 offset:8\nds_add_f32 %0, %1 offset:12\n"
+                                 "ds_add_f32 %0, %1 offset:16\nds_add_f32 %0, %1 offset:20\nds_add_f32 %0, %1 offset:24\nds_add_f32 %0, %1 offset:28\n"
+                                 :
+                                 : "v"(lds_addr), "v"(a[0])
+                                 : "memory");
+                }
             } else {   // OP_MIX: the instruction classes of one (entry, quadrant) step of the blend backward, 64 per iteration
                 if (r == 0) {
                     asm volatile("v_exp_f32 %0, %0\nv_rcp_f32 %1, %1\n"
@@ -112,7 +206,7 @@ __global__ void __launch_bounds__(1024) valu_kernel(float *out, uint32_t *hwid, 
             }
         }
     }
-    float s = 0.f;
+    float s = (float)(sink & 1ull) + lds[threadIdx.x & 1023];
 #pragma unroll
     for (int i = 0; i < 8; i++) s += a[i];
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -159,7 +253,7 @@ static void run(int n_cu, int w, int iters, float *out, uint32_t *hwid, double n
     }
     int mn = 1 << 30, mx = 0;
     for (auto &kv : per_simd) { mn = kv.second < mn ? kv.second : mn; mx = kv.second > mx ? kv.second : mx; }
-    const double instr_per_wave = (double)iters * (OP == OP_PKFMA ? 32.0 : 64.0);
+    const double instr_per_wave = (double)iters * (OP == OP_PKFMA ? 32.0 : 64.0);      // (LDS ops: 64 DS instructions per iteration)
     const double total = instr_per_wave * (double)n_waves;
     const double rate = total / (best * 1e-3);                       // wave-instructions per second, whole chip
     const double simds = (double)per_simd.size();
@@ -188,7 +282,8 @@ int main(int argc, char **argv) {
 #define RUN(OP)                                                                \
     for (int w : ws) { run<OP>(n_cu, w, iters, out, hwid, hz, first); first = false; }
     RUN(OP_FMA) RUN(OP_EXP) RUN(OP_RCP) RUN(OP_DPP_QUAD) RUN(OP_DPP_ROWMIRROR) RUN(OP_DPP_BCAST) RUN(OP_CMP) RUN(OP_CNDMASK)
-    RUN(OP_MIX) RUN(OP_PKFMA)
+    RUN(OP_MIX) RUN(OP_PKFMA) RUN(OP_MUL) RUN(OP_MAX) RUN(OP_CNDMASK_SGPR) RUN(OP_CNDMASK_VCC_SET) RUN(OP_CMP_SGPR) RUN(OP_READFIRSTLANE)
+    RUN(OP_MOV_DPP) RUN(OP_LDS_READ128_BCAST) RUN(OP_LDS_ADD_ROWLEADERS) RUN(OP_CNDMASK_E64_VCC) RUN(OP_CNDMASK_E32_MIXED) RUN(OP_CMP_CNDMASK_PAIRS)
     printf("\n ]}\n");
     return 0;
 }

@@ -23,7 +23,7 @@ namespace {
                           // than 1875 four-wave ones (blend backward 0.538 -> 0.518 ms; 2 waves: 0.525)
 #endif
 #define LOG2E 1.4426950408889634f
-#define W3D_ACC_STRIDE 12      // floats per entry in the backward's LDS accumulator (10 used; 48 B keeps float4 alignment)
+#define W3D_ACC_SLOTS 128      // backward: (entry of a 32-entry half batch) x (16-lane row) slots per accumulated value
 
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_mov(float src) {
@@ -44,6 +44,11 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
     return v;
 }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    return v;
+}
 __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
@@ -57,7 +62,8 @@ __device__ __forceinline__ uint32_t wave_to_tile(uint32_t T, uint32_t &tile) {
     const uint32_t b = blockIdx.x;
     const uint32_t per_xcd = (nblocks + 7) / 8;
     const uint32_t logical_block = (b & 7u) * per_xcd + (b >> 3);
-    tile = logical_block * W3D_RW + (threadIdx.x >> 6);
+    // (an SGPR: the per-tile loads become scalar loads and every loop bound derived from them stays scalar)
+    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(logical_block * W3D_RW + (threadIdx.x >> 6)));
     return tile < T;
 }
 
@@ -67,7 +73,6 @@ struct StagedLDS {
     float4 c[64];  // r, g, b, depth
     float4 d[64];  // -0.5*log2e*conic.x, -log2e*conic.y, -0.5*log2e*conic.z, opacity: the exponent in the
                    // log2 domain is dx*(d.x*dx + d.y*dy) + d.z*dy*dy — 5 VALU instead of 7 + 1 for the exp2 scale
-    uint32_t q[64]; // bit k: the Gaussian can reach alpha >= 1/255 somewhere in the 8x8 pixel quadrant k of the tile
 };
 
 // Which of the tile's four 8x8 quadrants can this Gaussian touch?  The minimum of q(d) = 0.5 d^T Conic d over
@@ -100,9 +105,13 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
     return m;
 }
 
-__device__ __forceinline__ void stage_entries(StagedLDS &s, uint32_t lane, uint32_t n, const uint32_t *__restrict__ list,
+// Returns this lane's entry mask: bits 0..3 = quadrants it can touch, bit 4 = its opacity exceeds the 0.99 alpha cap (only
+// then can o * G reach the cap: the blend loops skip the min otherwise).  The masks stay in registers; the loops read
+// them with v_readlane and skip entries that touch no quadrant on a scalar bit scan.
+__device__ __forceinline__ uint32_t stage_entries(StagedLDS &s, uint32_t lane, uint32_t n, const uint32_t *__restrict__ list,
                                               const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
                                               const float4 *__restrict__ rgbd, float tx0, float ty0) {
+    uint32_t q = 0u;
     if (lane < n) {
         const uint32_t g = list[lane];
         const float2 p = xy[g];
@@ -115,9 +124,11 @@ __device__ __forceinline__ void stage_entries(StagedLDS &s, uint32_t lane, uint3
         s.b[lane] = co;
         s.c[lane] = cd;
         s.d[lane] = make_float4(-0.5f * LOG2E * co.x, -LOG2E * co.y, -0.5f * LOG2E * co.z, co.w);
-        s.q[lane] = quadrant_mask(p.x, p.y, co.x, co.y, co.z, pmin, tx0, ty0);
+        q = quadrant_mask(p.x, p.y, co.x, co.y, co.z, pmin, tx0, ty0);
+        if (q != 0u && co.w > 0.99f) q |= 16u;
     }
     __builtin_amdgcn_wave_barrier();
+    return q;
 }
 
 // ------------------------------------------------------------------------------ forward
@@ -189,15 +200,17 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     for (uint32_t base = start; base < end; base += 64) {
         if ((w3d_ballot(hi[0] == 0.f) | w3d_ballot(hi[1] == 0.f) | w3d_ballot(hi[2] == 0.f) | w3d_ballot(hi[3] == 0.f)) == 0ull) break;
         const uint32_t n = min(64u, end - base);
-        stage_entries(s, lane, n, point_list + base, xy, conic_op, rgbd, (float)tx0, (float)ty0);
+        const uint32_t myq = stage_entries(s, lane, n, point_list + base, xy, conic_op, rgbd, (float)tx0, (float)ty0);
+        uint64_t todo = w3d_ballot(myq != 0u);
         // FlashSplat scatter, tiles with one or two labels (every tile of a binary mask): the weights of an entry are summed
         // over each 16-lane row in registers (4 DPP stages), the four row leaders add into the entry's LDS slot, and the
         // batch is flushed with ONE 64-lane atomic per label instead of one single-lane atomic per entry
         const bool facc_path = FLASH && gt_mask && used_count && nlabels >= 1 && nlabels <= 2;
         if (facc_path) { s_facc[wv][2 * lane] = 0.f; s_facc[wv][2 * lane + 1] = 0.f; }
-        for (uint32_t j = 0; j < n; j++) {
-            const uint32_t qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.q[j]);
-            if (qm == 0u) continue;
+        while (todo) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(todo);            // front to back
+            todo &= todo - 1ull;
+            const uint32_t qm = (uint32_t)__builtin_amdgcn_readlane((int)myq, (int)j);
             const float4 ea = s.a[j], ed = s.d[j], ec = s.c[j];
             const uint32_t contributor = base - start + j + 1;
             float wk[4] = {0.f, 0.f, 0.f, 0.f};
@@ -210,7 +223,11 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 // (two ballots of plain compares ANDed as scalars: the ballot of a compound predicate is materialised in a VGPR)
                 if ((w3d_ballot(power <= hi[k]) & w3d_ballot(power >= ea.z)) == 0ull) continue;   // whole quadrant untouched
                 const bool cand = power <= hi[k] && power >= ea.z;
-                const float alpha = fminf(0.99f, ed.w * __builtin_amdgcn_exp2f(power));
+                float alpha = ed.w * __builtin_amdgcn_exp2f(power);
+                if (qm & 16u) {                                        // wave-uniform: o <= 0.99 can never reach the cap
+                    asm volatile("" : "+v"(alpha));                     // (keeps this a scalar branch instead of min + select)
+                    alpha = fminf(0.99f, alpha);
+                }
                 const float test_T = Tr[k] * (1.f - alpha);
                 const bool ok = cand && alpha >= (1.0f / 255.0f);
                 const bool stop = ok && test_T < 0.0001f;
@@ -322,8 +339,11 @@ __device__ __forceinline__ Staged gather_entry(uint32_t g, const float2 *__restr
 }
 
 // HAS_DA: gradients w.r.t. the depth and alpha images are present.
+#ifndef W3D_BWD_OCC
+#define W3D_BWD_OCC 4
+#endif
 template <bool HAS_DA>
-__global__ void __launch_bounds__(64 * W3D_RW, HAS_DA ? 3 : 4)   // 2nd argument = waves per SIMD: caps VGPRs at 128 / 168
+__global__ void __launch_bounds__(64 * W3D_RW, HAS_DA ? 3 : W3D_BWD_OCC)   // 2nd argument = waves per SIMD: caps VGPRs at 168 / 128
 render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restrict__ tile_start,
                   const uint32_t *__restrict__ point_list, const float2 *__restrict__ xy,
                   const float4 *__restrict__ conic_op, const float4 *__restrict__ rgbd, const float *__restrict__ bg,
@@ -331,9 +351,12 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
                   const float *__restrict__ dL_dalpha_px, float *__restrict__ grad2d,
                   const uint32_t *__restrict__ counters) {
-    __shared__ StagedLDS lds[W3D_RW];
-    __shared__ __align__(16) float acc_all[W3D_RW][64 * W3D_ACC_STRIDE];   // per-entry sums of the current batch
     constexpr int NV = HAS_DA ? 10 : 9;
+    __shared__ StagedLDS lds[W3D_RW];
+    // row sums of the current half batch: acc[value][entry * 4 + row].  Every (entry, row) slot is written exactly once
+    // per half batch by that row's leader lane — plain stores, no LDS atomics (measured on gfx950: a ds_add_f32 of four lanes
+    // on one address occupies the CU's LDS for ~15 cycles, nine of them per entry cost more than the entry's arithmetic)
+    __shared__ __align__(16) float acc_all[W3D_RW][NV * W3D_ACC_SLOTS];
     uint32_t tile;
     if (!wave_to_tile(T, tile)) return;
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -369,13 +392,26 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         ar0[k] = ar1[k] = ar2[k] = ard[k] = ara[k] = 0.f;
         maxc = max(maxc, last[k]);
     }
-    maxc = wave_max_u32(maxc);
+    maxc = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(maxc));   // (an SGPR: everything derived from it stays scalar)
     if (maxc == 0) return;
     const uint32_t cap = counters[3];
     const uint32_t start = min(tile_start[tile], cap);
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const bool has_bg = (bg0 != 0.f) || (bg1 != 0.f) || (bg2 != 0.f);     // wave-uniform: black background skips the term
     const int nb = (int)((maxc + 63) / 64);
+    // (idx0 < last[k]) holds for every pixel of quadrant k once idx0 < minlast[k]: from there on the per-lane compare of the
+    // quadrant is replaced by one scalar compare
+    uint32_t minlast[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) minlast[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(last[k]));
+    // where the row sums of this lane go (see the reduce-scatter below): the first lane of every bank (4 lanes) stores the
+    // three values its bank ended up with
+    const uint32_t l4 = (lane >> 2) & 3u, row = lane >> 4;
+    const bool storer = (lane & 3u) == 0u;
+    const uint32_t offA = ((l4 >> 1) + 5u * (l4 & 1u)) * W3D_ACC_SLOTS + row;      // values 0, 5, 1, 6
+    const uint32_t offB = offA + 2u * W3D_ACC_SLOTS;                               // values 2, 7, 3, 8
+    const uint32_t offC = (4u + 5u * (l4 & 1u)) * W3D_ACC_SLOTS + row;             // values 4, 9
+    const bool storeC = storer && (l4 == 0u || (HAS_DA && l4 == 1u));
     // software pipeline over the 64-entry batches (walked back to front): while batch b is consumed from
     // LDS, the records of batch b-1 are already in flight to registers and the ids of batch b-2 to `ids`.
     auto batch_id = [&](int b) -> uint32_t {
@@ -393,108 +429,158 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         const uint32_t n = min(64u, maxc - (uint32_t)b * 64u);
         s.a[lane] = nxt.a; s.b[lane] = nxt.b; s.c[lane] = nxt.c;
         s.d[lane] = make_float4(-0.5f * LOG2E * nxt.b.x, -LOG2E * nxt.b.y, -0.5f * LOG2E * nxt.b.z, nxt.b.w);
-        s.q[lane] = quadrant_mask(nxt.a.x, nxt.a.y, nxt.b.x, nxt.b.y, nxt.b.z, nxt.a.z * (1.0f / LOG2E), (float)tx0, (float)ty0);
-        {
-            float4 *z = reinterpret_cast<float4 *>(&acc[lane * W3D_ACC_STRIDE]);
-            z[0] = make_float4(0.f, 0.f, 0.f, 0.f); z[1] = z[0]; z[2] = z[0];
+        // this lane's entry: quadrant mask (bits 0..3) and "opacity above the 0.99 cap" (bit 4); they stay in the register —
+        // the walk below reads them with v_readlane and skips entries without any quadrant on a scalar bit scan
+        uint32_t myq = 0u;
+        if (lane < n) {
+            myq = quadrant_mask(nxt.a.x, nxt.a.y, nxt.b.x, nxt.b.y, nxt.b.z, nxt.a.z * (1.0f / LOG2E), (float)tx0, (float)ty0);
+            if (myq != 0u && nxt.b.w > 0.99f) myq |= 16u;
         }
-        uint64_t touched = 0ull;
+        const uint64_t todo_all = w3d_ballot(myq != 0u);
         __builtin_amdgcn_wave_barrier();
         if (b > 0) {
             nxt = (ids != 0xFFFFFFFFu) ? gather_entry(ids, xy, conic_op, rgbd) : Staged{};
             ids = batch_id(b - 2);
         }
-        for (int j = (int)n - 1; j >= 0; j--) {
-            const uint32_t qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.q[j]);
-            if (qm == 0u) continue;
-            const float4 ea = s.a[j], ed = s.d[j], ec = s.c[j];
-            const uint32_t idx0 = (uint32_t)b * 64u + (uint32_t)j;   // 0-based position in the tile list
-            // per-lane partial sums of this tile instance.  Geometry enters through the five moments of
-            // m = dL/dG * G:  S1 = sum m dx, S2 = sum m dy, Sxx = sum m dx^2, Sxy = sum m dx dy, Syy = sum m dy^2;
-            // dL/dmean2D and dL/dconic are linear in them and are formed AFTER the wave reduction.
-            // v: S1, S2, Sxx, Sxy, Syy, opacity, r, g, b [, depth]
-            float v[HAS_DA ? 10 : 9];
+        // the batch is consumed in two halves of 32 entries, each followed by its flush (the row-sum slots are per half)
+#pragma unroll 1
+        for (int jlo = 32; jlo >= 0; jlo -= 32) {
+            uint32_t todo = (uint32_t)(todo_all >> jlo);
+            uint32_t touched = 0u;
+            while (todo) {
+                const uint32_t jl = 31u - (uint32_t)__builtin_clz(todo);             // highest entry first: back to front
+                todo &= ~(1u << jl);
+                const uint32_t j = (uint32_t)jlo + jl;
+                const uint32_t qm = (uint32_t)__builtin_amdgcn_readlane((int)myq, (int)j);
+                const float4 ea = s.a[j], ed = s.d[j], ec = s.c[j];
+                const uint32_t idx0 = (uint32_t)b * 64u + j;            // 0-based position in the tile list
+                // per-lane partial sums of this tile instance.  Geometry enters through the five moments of
+                // m = dL/dG * G:  S1 = sum m dx, S2 = sum m dy, Sxx = sum m dx^2, Sxy = sum m dx dy, Syy = sum m dy^2;
+                // dL/dmean2D and dL/dconic are linear in them and are formed AFTER the wave reduction.
+                // v: S1, S2, Sxx, Sxy, Syy, opacity, r, g, b [, depth]
+                float v[10];
 #pragma unroll
-            for (int i = 0; i < (HAS_DA ? 10 : 9); i++) v[i] = 0.f;
-            bool any = false;
+                for (int i = 0; i < 10; i++) v[i] = 0.f;
+                bool any = false;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (!(qm & (1u << k))) continue;
-                const float dx = ea.x - (pxb + (float)((k & 1) * 8)), dy = ea.y - (pyb + (float)((k >> 1) * 8));
-                const float power = fmaf(ed.z * dy, dy, fmaf(ed.y, dy, ed.x * dx) * dx);      // log2 domain
-                // (ballots of plain compares, ANDed as scalars — see the forward kernel)
-                const uint64_t mc = w3d_ballot(idx0 < last[k]) & w3d_ballot(power <= 0.f) & w3d_ballot(power >= ea.z);
-                if (mc == 0ull) continue;
-                const bool cand = idx0 < last[k] && power <= 0.f && power >= ea.z;
-                const float Graw = __builtin_amdgcn_exp2f(power);
-                const float araw = fminf(0.99f, ed.w * Graw);
-                const bool ok = cand && araw >= (1.0f / 255.0f);
-                if ((mc & w3d_ballot(araw >= (1.0f / 255.0f))) == 0ull) continue;
-                any = true;                                        // wave-uniform: some lane blends this Gaussian
-                // Branch-free per lane: a lane that does not blend this Gaussian runs the same recurrences
-                // with alpha = G = 0, which leaves T and the suffix accumulators untouched and adds zeros.
-                const float alpha = ok ? araw : 0.f;
-                const float G = ok ? Graw : 0.f;
-                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-                const float Tn = Tr[k] * inv;
-                const float dch = alpha * Tn;
-                const float d0 = ec.x - ar0[k], d1 = ec.y - ar1[k], d2 = ec.z - ar2[k];
-                float dL_dalpha = d0 * dp0[k] + d1 * dp1[k] + d2 * dp2[k];
-                ar0[k] += alpha * d0; ar1[k] += alpha * d1; ar2[k] += alpha * d2;   // A <- a c + (1-a) A
-                if (HAS_DA) {
-                    const float dd = ec.w - ard[k], da = 1.f - ara[k];
-                    dL_dalpha += dd * dpd[k] + da * dpa[k];
-                    ard[k] += alpha * dd; ara[k] += alpha * da;
-                    v[9] += dch * dpd[k];
+                for (int k = 0; k < 4; k++) {
+                    if (!(qm & (1u << k))) continue;
+                    const float dx = ea.x - (pxb + (float)((k & 1) * 8)), dy = ea.y - (pyb + (float)((k >> 1) * 8));
+                    const float power = fmaf(ed.z * dy, dy, fmaf(ed.y, dy, ed.x * dx) * dx);      // log2 domain
+                    // (ballots of plain compares, ANDed as scalars — see the forward kernel)
+                    bool cand = power <= 0.f;
+                    uint64_t mc = w3d_ballot(cand) & w3d_ballot(power >= ea.z);
+                    cand = cand && power >= ea.z;
+                    if (idx0 >= minlast[k]) {                          // (wave-uniform; false for most of the walk)
+                        mc &= w3d_ballot(idx0 < last[k]);
+                        cand = cand && idx0 < last[k];
+                    }
+                    if (mc == 0ull) continue;
+                    const float Graw = __builtin_amdgcn_exp2f(power);
+                    float araw = ed.w * Graw;
+                    if (qm & 16u) {                                    // wave-uniform: o <= 0.99 can never reach the cap
+                        asm volatile("" : "+v"(araw));                  // (keeps this a scalar branch instead of min + select)
+                        araw = fminf(0.99f, araw);
+                    }
+                    const uint64_t mk = mc & w3d_ballot(araw >= (1.0f / 255.0f));
+                    if (mk == 0ull) continue;
+                    any = true;                                        // wave-uniform: some lane blends this Gaussian
+                    // Branch-free per lane: a lane that does not blend this Gaussian runs the same recurrences
+                    // with alpha = G = 0, which leaves T and the suffix accumulators untouched and adds zeros.
+                    const bool ok = cand && araw >= (1.0f / 255.0f);    // (its lane mask is mk, already in an SGPR pair)
+                    const float alpha = ok ? araw : 0.f;
+                    const float G = ok ? Graw : 0.f;
+                    const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                    const float Tn = Tr[k] * inv;
+                    const float dch = alpha * Tn;
+                    const float d0 = ec.x - ar0[k], d1 = ec.y - ar1[k], d2 = ec.z - ar2[k];
+                    float dL_dalpha = d0 * dp0[k] + d1 * dp1[k] + d2 * dp2[k];
+                    ar0[k] += alpha * d0; ar1[k] += alpha * d1; ar2[k] += alpha * d2;   // A <- a c + (1-a) A
+                    if (HAS_DA) {
+                        const float dd = ec.w - ard[k], da = 1.f - ara[k];
+                        dL_dalpha += dd * dpd[k] + da * dpa[k];
+                        ard[k] += alpha * dd; ara[k] += alpha * da;
+                        v[9] += dch * dpd[k];
+                    }
+                    Tr[k] = Tn;
+                    dL_dalpha *= Tn;
+                    if (has_bg) {
+                        // (the empty asm keeps this a scalar branch: if-converted it costs 3 VALU per quadrant on black backgrounds)
+                        asm volatile("" : "+v"(dL_dalpha));
+                        dL_dalpha -= (Tfin[k] * inv) * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);
+                    }
+                    const float m = ed.w * dL_dalpha * G;      // dL/dG * G
+                    const float mx = m * dx, my = m * dy;
+                    v[0] += mx; v[1] += my;
+                    v[2] += mx * dx; v[3] += mx * dy; v[4] += my * dy;
+                    v[5] += G * dL_dalpha;
+                    v[6] += dch * dp0[k]; v[7] += dch * dp1[k]; v[8] += dch * dp2[k];
                 }
-                Tr[k] = Tn;
-                dL_dalpha *= Tn;
-                if (has_bg) {
-                    // (the empty asm keeps this a scalar branch: if-converted it costs 3 VALU per quadrant on black backgrounds)
-                    asm volatile("" : "+v"(dL_dalpha));
-                    dL_dalpha -= (Tfin[k] * inv) * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);
+                if (!any) continue;
+                // Row sums by reduce-scatter.  A DPP "bank" is a group of four consecutive lanes, and a DPP add with a bank
+                // mask writes only the enabled banks.  Stage 1 (partner = the neighbouring bank, lane +- 4) therefore halves the
+                // register count while it adds: banks 0 and 2 take values 0..4, banks 1 and 3 values 5..9; stage 2 (lane +- 8)
+                // halves it again: bank q of s0 / s1 / s2 ends up with value {0,5,1,6}[q] / {2,7,3,8}[q] / {4,9}[q], summed over
+                // the four lanes of the row that share lane % 4; two quad-permute stages on those 3 registers finish the row
+                // sums.  21 DPP adds per entry instead of 36.
+                float r0, r1, r2, r3, r4, s0, s1, s2 = 0.f;
+                asm volatile("s_nop 1\n\t"
+                             "v_add_f32_dpp %0, %5, %5 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                             "v_add_f32_dpp %1, %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                             "v_add_f32_dpp %2, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                             "v_add_f32_dpp %3, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                             "v_add_f32_dpp %4, %9, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                             "v_add_f32_dpp %0, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                             "v_add_f32_dpp %1, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                             "v_add_f32_dpp %2, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                             "v_add_f32_dpp %3, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                             "v_add_f32_dpp %4, %14, %14 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
+                             : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]));
+                asm volatile("s_nop 1\n\t"
+                             "v_add_f32_dpp %0, %3, %3 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                             "v_add_f32_dpp %1, %5, %5 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                             "v_add_f32_dpp %2, %7, %7 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                             "v_add_f32_dpp %0, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                             "v_add_f32_dpp %1, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                             "s_nop 1"           // (the compiler's DPP reads of s0..s2 follow: it cannot see the hazard behind inline asm)
+                             : "=&v"(s0), "=&v"(s1), "+v"(s2)
+                             : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4));
+                s0 += dpp_mov<0xB1>(s0); s1 += dpp_mov<0xB1>(s1); s2 += dpp_mov<0xB1>(s2);      // quad_perm [1,0,3,2]
+                s0 += dpp_mov<0x4E>(s0); s1 += dpp_mov<0x4E>(s1); s2 += dpp_mov<0x4E>(s2);      // quad_perm [2,3,0,1]
+                touched |= 1u << jl;
+                if (storer) {
+                    acc[offA + jl * 4u] = s0;
+                    acc[offB + jl * 4u] = s1;
+                    if (storeC) acc[offC + jl * 4u] = s2;
                 }
-                const float m = ed.w * dL_dalpha * G;      // dL/dG * G
-                const float mx = m * dx, my = m * dy;
-                v[0] += mx; v[1] += my;
-                v[2] += mx * dx; v[3] += mx * dy; v[4] += my * dy;
-                v[5] += G * dL_dalpha;
-                v[6] += dch * dp0[k]; v[7] += dch * dp1[k]; v[8] += dch * dp2[k];
             }
-            if (!any) continue;
-            // reduce within the 16-lane rows in registers (4 DPP stages), then one lane per row adds the row sums
-            // into this entry's LDS accumulator (4 lanes on one address per ds_add_f32); the batch is flushed
-            // below with 4 records per atomic instruction
-            row_sum_n(v);
-            touched |= 1ull << j;
-            if ((lane & 15u) == 0u) {
-#pragma unroll
-                for (int i = 0; i < NV; i++) atomicAdd(&acc[j * W3D_ACC_STRIDE + i], v[i]);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // flush: lane -> (entry e = 4*pass + lane/16, value k = lane%16); the five moments become
-        // dL/dmean2D and dL/dconic here.  record: [0] dL/dmean2D.x [1] .y [2] dL/dconic.x [3] .y (half) [4] .z
-        // [5] opacity [6..8] rgb [9] depth
-        {
-            const uint32_t k = lane & 15u, sub = lane >> 4;
+            __builtin_amdgcn_wave_barrier();
+            // flush: lane -> (entry e = 4*pass + lane/16, value k = lane%16) adds the four row sums; the five moments become
+            // dL/dmean2D and dL/dconic here.  record: [0] dL/dmean2D.x [1] .y [2] dL/dconic.x [3] .y (half) [4] .z
+            // [5] opacity [6..8] rgb [9] depth
+            if (touched) {
+                const uint32_t k = lane & 15u, sub = lane >> 4;
 #pragma unroll 4
-            for (uint32_t pass = 0; pass < 16; pass++) {
-                const uint32_t e = pass * 4u + sub;
-                if (((touched >> e) & 1ull) && k < (uint32_t)NV) {
-                    const float *a = &acc[e * W3D_ACC_STRIDE];
-                    const float4 co = s.b[e];
-                    float val;
-                    if (k == 0u) val = -(co.x * a[0] + co.y * a[1]) * ddelx_dx;
-                    else if (k == 1u) val = -(co.z * a[1] + co.y * a[0]) * ddely_dy;
-                    else if (k < 5u) val = -0.5f * a[k];
-                    else val = a[k];
-                    const uint32_t g = __float_as_uint(s.a[e].w);
-                    atomicAdd(&grad2d[(size_t)g * W3D_G2D_STRIDE + k], val);
+                for (uint32_t pass = 0; pass < 8; pass++) {
+                    const uint32_t e = pass * 4u + sub;
+                    if (((touched >> e) & 1u) && k < (uint32_t)NV) {
+                        const float4 r4v = *reinterpret_cast<const float4 *>(&acc[k * W3D_ACC_SLOTS + e * 4u]);
+                        const float sk = (r4v.x + r4v.y) + (r4v.z + r4v.w);
+                        const float so = dpp_mov<0xB1>(sk);            // k = 0 <-> k = 1 exchange their sums (S1, S2)
+                        const float4 co = s.b[jlo + e];
+                        float val;
+                        if (k == 0u) val = -(co.x * sk + co.y * so) * ddelx_dx;
+                        else if (k == 1u) val = -(co.z * sk + co.y * so) * ddely_dy;
+                        else if (k < 5u) val = -0.5f * sk;
+                        else val = sk;
+                        const uint32_t g = __float_as_uint(s.a[jlo + e].w);
+                        atomicAdd(&grad2d[(size_t)g * W3D_G2D_STRIDE + k], val);
+                    }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
