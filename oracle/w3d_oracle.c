@@ -47,6 +47,7 @@
  * double.  Bit 0 set: exp2f(power * log2 e) instead of expf — the same function with other roundings.  Bit 1 set: the
  * per-Gaussian sums are accumulated in fp32 in whatever order the threads arrive, which is what a GPU implementation with
  * float atomics (the reference's CUDA rasterizer included) does.  Bit 2 set: FMA-contracted exponent (w3do_power).
+ * Bit 3 set: the suffix recurrence of the backward walk in its other algebraic form (w3do_lerp).
  * Every variant is a valid fp32 evaluation of the same
  * formulas: the spread between a probe run and the mode-0 run is the uncertainty ANY fp32 implementation has against this
  * oracle — (pixel, Gaussian) pairs whose alpha sits on the 1/255 threshold and pixels whose transmittance sits on 1e-4
@@ -60,6 +61,13 @@ static inline float w3do_exp(float x) { return (g_exp_mode & 1) ? exp2f(x * 1.44
 static inline float w3do_power(const float *co, float dx, float dy) {
     if (g_exp_mode & 4) return fmaf(-0.5f, fmaf(co[2] * dy, dy, co[0] * dx * dx), -(co[1] * dx * dy));
     return -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+}
+/* the backward walk's recurrence for what lies behind an entry: a * c + (1 - a) * acc.  Probe bit 3: the algebraically equal
+ * acc + a * (c - acc) — other roundings of the same value (the gradient takes differences c - acc, which amplifies them where
+ * a Gaussian's colour is close to what lies behind it) */
+static inline float w3do_lerp(float acc, float c, float a) {
+    if (g_exp_mode & 8) return acc + a * (c - acc);
+    return a * c + (1.f - a) * acc;
 }
 /* one term of a per-Gaussian gradient sum: double accumulator, or (probe bit 1) an fp32 one */
 static inline void acc_add(double *a, float *af, float x) {
@@ -493,18 +501,18 @@ void w3do_backward(void *h, const W3DOView *v, const float *means3D, const float
 #define ACC(i, x) acc_add(a + (i), af ? af + (i) : NULL, (x))
                     for (int ch = 0; ch < 3; ch++) {
                         float c = s->rgb[3 * (size_t)g + ch];
-                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        accum_rec[ch] = w3do_lerp(accum_rec[ch], last_color[ch], last_alpha);
                         last_color[ch] = c;
                         dL_dalpha += (c - accum_rec[ch]) * dLdp[ch];
                         ACC(6 + ch, dch * dLdp[ch]);
                     }
                     {
                         float cd = s->depth[g];
-                        accum_d = last_alpha * last_depth + (1.f - last_alpha) * accum_d;
+                        accum_d = w3do_lerp(accum_d, last_depth, last_alpha);
                         last_depth = cd;
                         dL_dalpha += (cd - accum_d) * dLdd;
                         ACC(9, dch * dLdd);
-                        accum_a = last_alpha * 1.0f + (1.f - last_alpha) * accum_a;
+                        accum_a = w3do_lerp(accum_a, 1.0f, last_alpha);
                         dL_dalpha += (1.0f - accum_a) * dLda;
                     }
                     dL_dalpha *= Tr;

@@ -1,7 +1,8 @@
 """Per-kernel SQ counters (mean over the second half of a kernel's dispatches = the benchmark's full-size launches) from
-rocprofv3 --pmc passes -> sq_counters.csv (stdout).  valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (SQ_BUSY_CYCLES/32 x 1024 SIMDs):
-the share of the kernel's duration a SIMD spends issuing VALU instructions if they were spread evenly (wave64 on SIMD16:
-4 cycles per instruction; SQ_BUSY_CYCLES is summed over the 32 shader engines)."""
+rocprofv3 --pmc passes -> sq_counters.csv (stdout).  simd_cycles_per_valu_instr = (SQ_BUSY_CYCLES / 32 x 1024 SIMDs) / SQ_INSTS_VALU:
+SIMD cycles of the kernel's duration per wave64 VALU instruction it issued (SQ_BUSY_CYCLES is summed over the 32 shader
+engines).  What a SIMD can sustain per instruction class is measured by profiles/valu_microbench.hip (r02: v_fma/v_mul/
+v_cndmask_e32 2.3-2.6 cycles with >= 2 waves per SIMD, DPP / v_cmp / v_max / v_cndmask_e64 4.2-4.5, v_exp / v_rcp 8.2)."""
 import collections
 import csv
 import re
@@ -17,7 +18,7 @@ for path in sys.argv[1:]:
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU",
         "SQ_WAIT_INST_ANY"]
-print("kernel,dispatches," + ",".join(cols) + ",valu_issue_frac")
+print("kernel,dispatches," + ",".join(cols) + ",simd_cycles_per_valu_instr")
 rows = []
 for k, v in acc.items():
     vals = {}
@@ -26,7 +27,7 @@ for k, v in acc.items():
         x = x[len(x) // 2:]
         vals[c] = sum(x) / len(x) if x else 0.0
     busy = vals["SQ_BUSY_CYCLES"] / 32.0
-    frac = vals["SQ_INSTS_VALU"] * 4.0 / (busy * 1024.0) if busy > 0 else 0.0
+    frac = busy * 1024.0 / vals["SQ_INSTS_VALU"] if vals["SQ_INSTS_VALU"] > 0 else 0.0
     rows.append((vals["SQ_INSTS_VALU"], k, len(v.get("SQ_WAVES", [])), vals, frac))
 for _, k, n, vals, frac in sorted(rows, reverse=True):
-    print(f"\"{k}\",{n}," + ",".join(f"{vals[c]:.0f}" for c in cols) + f",{frac:.3f}")
+    print(f"\"{k}\",{n}," + ",".join(f"{vals[c]:.0f}" for c in cols) + f",{frac:.2f}")
