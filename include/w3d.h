@@ -252,6 +252,17 @@ int w3d_densify_compact(int32_t n_blocks, const int32_t *block_dims_host, int32_
                         float *param_new, float *exp_avg_new, float *exp_avg_sq_new, const float *child_xyz,
                         const float *child_scaling, w3d_stream_t stream);
 
+/* ---- next-row N4: the mask work around the FlashSplat render, on the device.
+ * w3d_mask_binarize <- utils/wheatgs_utils.py:26-37 binarize_mask(PILtoTorch(png)) as used at run_3d_seg.py:88-89:
+ *   pixels (H,W,C) uint8 as decoded (C = 1 or 3), out (H,W) fp32: 1 where any channel is non-zero, else 0.
+ * w3d_mask_iou <- run_3d_seg.py:127-163 find_match's scoring: pred = alpha > thresh; out (2K+5) uint32:
+ *   [2k] = |mask_k AND pred|, [2k+1] = |mask_k OR pred|  (utils/wheatgs_utils.py:94-103 calculate_seg_iou),
+ *   [2K..2K+3] = bounding box of pred {x_min, y_min, x_max, y_max} (get_bbox_from_mask :45-53; x_min = 0xFFFFFFFF when
+ *   pred is empty), [2K+4] = |pred|.  masks (K,H,W) uint8, non-zero = inside.  K may be 0. */
+int w3d_mask_binarize(int32_t H, int32_t W, int32_t C, const uint8_t *pixels, float *out, w3d_stream_t stream);
+int w3d_mask_iou(int32_t H, int32_t W, int32_t K, const float *alpha, float thresh, const uint8_t *masks, uint32_t *out,
+                 w3d_stream_t stream);
+
 /* Diagnostics for bench.py's roofline leg: time the launches whose stage name contains
  * `kernel_substr` ("*" = all, NULL/"" = off) with HIP events on their launch stream;
  * w3d_profile_collect waits for them and writes "name count total_ms" lines into out. */

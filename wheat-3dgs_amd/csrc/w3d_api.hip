@@ -425,6 +425,17 @@ int w3d_knn_dist2_grid(int32_t N, const float *points, float *out, void *scratch
     return w3d_launch_knn_grid(N, points, out, static_cast<char *>(scratch), reinterpret_cast<hipStream_t>(stream_));
 }
 
+int w3d_mask_binarize(int32_t H, int32_t W, int32_t C, const uint8_t *pixels, float *out, w3d_stream_t stream_) {
+    if (H <= 0 || W <= 0 || (C != 1 && C != 3 && C != 4) || !pixels || !out) { w3d_set_error("mask_binarize: bad arguments"); return W3D_ERR_INVALID; }
+    return w3d_launch_mask_binarize(H, W, C, pixels, out, reinterpret_cast<hipStream_t>(stream_));
+}
+
+int w3d_mask_iou(int32_t H, int32_t W, int32_t K, const float *alpha, float thresh, const uint8_t *masks, uint32_t *out,
+                 w3d_stream_t stream_) {
+    if (H <= 0 || W <= 0 || K < 0 || K > 2000 || !alpha || !out || (K > 0 && !masks)) { w3d_set_error("mask_iou: bad arguments"); return W3D_ERR_INVALID; }
+    return w3d_launch_mask_iou(H, W, K, alpha, thresh, masks, out, reinterpret_cast<hipStream_t>(stream_));
+}
+
 int w3d_debug_tile_ranges(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *ranges_out, w3d_stream_t stream_) {
     W3DLayout L;
     int rc = w3d_make_layout(P, H, W, &L);

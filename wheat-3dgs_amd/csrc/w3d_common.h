@@ -183,6 +183,9 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
                                    float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors, float *dL_dshs,
                                    float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
                                    const struct W3DRawBwdArgs *rawargs, hipStream_t stream);
+int w3d_launch_mask_binarize(int H, int W, int C, const uint8_t *pixels, float *out, hipStream_t stream);
+int w3d_launch_mask_iou(int H, int W, int K, const float *alpha, float thresh, const uint8_t *masks, uint32_t *out,
+                        hipStream_t stream);
 int w3d_launch_knn(int32_t N, const float *points, float *out, hipStream_t stream);
 uint64_t w3d_knn_scratch_bytes(int32_t N);
 int w3d_launch_knn_grid(int32_t N, const float *points, float *out, char *scratch, hipStream_t stream);

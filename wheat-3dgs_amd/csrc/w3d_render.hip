@@ -23,6 +23,7 @@ namespace {
                           // than 1875 four-wave ones (blend backward 0.538 -> 0.518 ms; 2 waves: 0.525)
 #endif
 #define LOG2E 1.4426950408889634f
+#define W3D_FLASH_LABELS 4     // FlashSplat: labels per tile that take the LDS row-sum path (more: one wave reduction per label and entry)
 #define W3D_ACC_SLOTS 128      // backward: (entry of a 32-entry half batch) x (16-lane row) slots per accumulated value
 
 template <int CTRL, int ROW_MASK = 0xF>
@@ -143,7 +144,8 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   int32_t *__restrict__ contrib_num, uint32_t list_cap, uint32_t *__restrict__ counters) {
     __shared__ StagedLDS lds[W3D_RW];
     __shared__ int s_labels[W3D_RW][FLASH ? 256 : 1];
-    __shared__ float s_facc[W3D_RW][FLASH ? 64 * 2 : 1];      // FlashSplat: per-entry weight sums of the current batch, <= 2 labels
+    // FlashSplat: row sums of the per-entry, per-label weights of the current batch: [label slot][entry][16-lane row]
+    __shared__ __align__(16) float s_facc[W3D_RW][FLASH ? W3D_FLASH_LABELS * 64 * 4 : 4];
     uint32_t tile;
     if (!wave_to_tile(T, tile)) return;
     // the list buffer may be smaller than the lists (speculative sizing, see w3d_forward_stage2): never read
@@ -177,8 +179,13 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             label[k] = (l >= 0 && l <= num_obj) ? l : -1;
         }
     }
-    // distinct labels present in this tile (FlashSplat scatter loops over them)
-    int nlabels = 0, label_a = -1, label_b = -1;      // the first two labels also live in registers
+    // distinct labels present in this tile (FlashSplat scatter loops over them), ascending; the first W3D_FLASH_LABELS of
+    // them also live in scalar registers: a wheat-head instance map puts one to three labels into a tile (background, a
+    // head, its neighbour), and those tiles take the row-sum path below for every label
+    int nlabels = 0;
+    int lab[W3D_FLASH_LABELS];
+#pragma unroll
+    for (int i = 0; i < W3D_FLASH_LABELS; i++) lab[i] = -1;
     if (FLASH && gt_mask && used_count) {
         int cur = -1;
         for (;;) {
@@ -186,11 +193,12 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (label[k] > cur) m = min(m, label[k]);
-            m = wave_min_i32(m);
+            m = __builtin_amdgcn_readfirstlane(wave_min_i32(m));
             if (m == 0x7fffffff) break;
             if (lane == 0) s_labels[wv][nlabels] = m;
-            if (nlabels == 0) label_a = m;
-            if (nlabels == 1) label_b = m;
+#pragma unroll
+            for (int i = 0; i < W3D_FLASH_LABELS; i++)
+                if (nlabels == i) lab[i] = m;
             nlabels++;
             cur = m;
         }
@@ -202,11 +210,12 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         const uint32_t n = min(64u, end - base);
         const uint32_t myq = stage_entries(s, lane, n, point_list + base, xy, conic_op, rgbd, (float)tx0, (float)ty0);
         uint64_t todo = w3d_ballot(myq != 0u);
-        // FlashSplat scatter, tiles with one or two labels (every tile of a binary mask): the weights of an entry are summed
-        // over each 16-lane row in registers (4 DPP stages), the four row leaders add into the entry's LDS slot, and the
-        // batch is flushed with ONE 64-lane atomic per label instead of one single-lane atomic per entry
-        const bool facc_path = FLASH && gt_mask && used_count && nlabels >= 1 && nlabels <= 2;
-        if (facc_path) { s_facc[wv][2 * lane] = 0.f; s_facc[wv][2 * lane + 1] = 0.f; }
+        // FlashSplat scatter, tiles with up to W3D_FLASH_LABELS labels (every tile of a binary mask, nearly every tile of an
+        // instance map): per label the weights of an entry are summed over each 16-lane row in registers (4 DPP stages), the
+        // four row leaders store the row sums into the entry's LDS slots (plain stores: every slot is written once per
+        // batch), and the batch is flushed with ONE 64-lane atomic per label instead of one single-lane atomic per entry
+        const bool facc_path = FLASH && gt_mask && used_count && nlabels >= 1 && nlabels <= W3D_FLASH_LABELS;
+        uint64_t ftouched = 0ull;
         while (todo) {
             const uint32_t j = (uint32_t)__builtin_ctzll(todo);            // front to back
             todo &= todo - 1ull;
@@ -242,18 +251,21 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             }
             if (FLASH && gt_mask && used_count) {
                 if (w3d_ballot(any_applied) != 0ull && facc_path) {
-                    for (int li = 0; li < nlabels; li++) {
-                        const int L = (li == 0) ? label_a : label_b;
+                    ftouched |= 1ull << j;
+#pragma unroll
+                    for (int li = 0; li < W3D_FLASH_LABELS; li++) {
+                        if (li >= nlabels) break;
                         float part = 0.f;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) part += (label[k] == L) ? wk[k] : 0.f;
+                        for (int k = 0; k < 4; k++) part += (label[k] == lab[li]) ? wk[k] : 0.f;
                         part += dpp_mov<0xB1>(part);
                         part += dpp_mov<0x4E>(part);
                         part += dpp_mov<0x141>(part);
                         part += dpp_mov<0x140>(part);
-                        if ((lane & 15u) == 0u) atomicAdd(&s_facc[wv][2 * j + li], part);
+                        if ((lane & 15u) == 0u) s_facc[wv][(li * 64 + j) * 4 + (lane >> 4)] = part;
                     }
                 } else if (w3d_ballot(any_applied) != 0ull) {
+                    // more labels in one tile than slots: one wave reduction and one atomic per label and entry
                     const uint32_t g = __float_as_uint(ea.w);
                     for (int li = 0; li < nlabels; li++) {
                         const int L = s_labels[wv][li];
@@ -267,11 +279,15 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (facc_path && lane < n) {
+        if (facc_path && ((ftouched >> lane) & 1ull)) {
             const uint32_t g = __float_as_uint(s.a[lane].w);
-            const float va = s_facc[wv][2 * lane], vb = s_facc[wv][2 * lane + 1];
-            if (va != 0.f) atomicAdd(&used_count[(size_t)label_a * P + g], va);
-            if (nlabels == 2 && vb != 0.f) atomicAdd(&used_count[(size_t)label_b * P + g], vb);
+#pragma unroll
+            for (int li = 0; li < W3D_FLASH_LABELS; li++) {
+                if (li >= nlabels) break;
+                const float4 r4 = *reinterpret_cast<const float4 *>(&s_facc[wv][(li * 64 + lane) * 4]);
+                const float v = (r4.x + r4.y) + (r4.z + r4.w);
+                if (v != 0.f) atomicAdd(&used_count[(size_t)lab[li] * P + g], v);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }

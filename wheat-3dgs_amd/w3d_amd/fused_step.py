@@ -138,7 +138,15 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, flash=None
                 gt_mask = gt_mask.detach().to(device=dev, dtype=torch.float32).contiguous()
                 if tuple(gt_mask.shape[-2:]) != (H, W) or gt_mask.numel() != H * W:
                     raise RuntimeError("gt_mask must have dimensions (image_height, image_width)")
-            used_count = torch.zeros(num_obj + 1, P, dtype=torch.float32, device=dev)
+            # the kernel ADDS into used_count: a caller that sums over views (run_3d_seg.py:95-97 all_counts += used_count)
+            # hands its running total in and saves a (num_obj+1, P) allocation, memset and add per view — 2.4 GB each at
+            # 300 labels x 2 M Gaussians (eval_wheatgs.py:99-105)
+            used_count = flash.get("accumulate_into")
+            if used_count is None:
+                used_count = torch.zeros(num_obj + 1, P, dtype=torch.float32, device=dev)
+            elif tuple(used_count.shape) != (num_obj + 1, P) or used_count.dtype != torch.float32 or not used_count.is_contiguous() \
+                    or used_count.device != dev:
+                raise RuntimeError("accumulate_into must be a contiguous float32 (num_obj+1, P) tensor on the model's device")
             contrib_num = torch.empty(H, W, dtype=torch.int32, device=dev)
             proj_xy = torch.empty(P, 2, dtype=torch.float32, device=dev)
             gs_depth = torch.empty(P, dtype=torch.float32, device=dev)
