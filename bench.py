@@ -422,6 +422,24 @@ def main():
     for _ in range(args.warmup):
         it += 1
         trainer.step(it)
+    # N > 1: nothing re-synchronises the replicas, so the exchange must keep them bit-identical.  Checked on the real links
+    # before anything is timed; if the low-rank exchange (replicated optimizer) fails the check, the replicas are
+    # re-synchronised from rank 0 and the run falls back to the dense exchange (reduce-scatter, sharded Adam, all-gather)
+    selfcheck = None
+    if world > 1:
+        selfcheck = {"mode_requested": trainer.exchange_mode if trainer.fused else "dense",
+                     "replicas_identical_after_warmup": replicas_identical(model, world, dev)}
+        if not selfcheck["replicas_identical_after_warmup"]:
+            for buf in (model.flat_store, model.optimizer.exp_avg, model.optimizer.exp_avg_sq, model.xyz_gradient_accum,
+                        model.denom, model.max_radii2D):
+                dist.broadcast(buf, 0)
+            if trainer.fused and trainer.exchange_mode == "lowrank":
+                trainer.exchange_mode = "dense"
+                selfcheck["fell_back_to"] = "dense"
+            for _ in range(max(2, args.warmup // 2)):
+                it += 1
+                trainer.step(it)
+            selfcheck["replicas_identical_after_fallback"] = replicas_identical(model, world, dev)
     prof_sel = b"*" if args.all_stages else args.profile.encode()
     elapsed, it, stages = timed(args.steps, it, prof_sel)
     final_loss = float(trainer.last["loss"])
@@ -438,6 +456,7 @@ def main():
     if world > 1:
         exchange = exchange_bandwidth(model, world, dev)
         exchange["mode"] = trainer.exchange_mode if trainer.fused else "dense"
+        exchange["selfcheck"] = selfcheck
         exchange["replicas_identical_after_timed_steps"] = replicas_identical(model, world, dev)
     if not args.no_extras:
         # forward-only render throughput (reference render.py's use), same scene, views cycled

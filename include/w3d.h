@@ -37,7 +37,8 @@
  * viewmatrix / projmatrix are the TRANSPOSED matrices exactly as scene/cameras.py:56-58 builds
  * them.  The caller owns every buffer (outputs, state, scratch, lists) and allocates them with
  * its own allocator (torch's, in the Python host); the library never allocates device memory
- * and keeps no global mutable state besides the last-error string (thread-local).
+ * and keeps no global mutable state besides the last-error string (thread-local) and the opt-in, mutex-guarded event
+ * records of w3d_profile_enable / w3d_profile_collect.
  * All work is enqueued on `stream`; nothing synchronises unless stated.
  *
  * Return value: 0 on success, a W3D_ERR_* code otherwise (w3d_last_error() has the text).

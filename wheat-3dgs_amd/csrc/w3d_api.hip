@@ -7,21 +7,27 @@
 #include "w3d_common.h"
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 static thread_local char g_err[512] = "";
 
-// ---- per-kernel event timing (diagnostic state; the only non-error global in the library)
+// ---- per-kernel event timing: opt-in diagnostic state, the only non-error global in the library.  Off unless
+// w3d_profile_enable() was called; the record list is guarded by a mutex (launches from several host threads), the
+// "scope is open" flag is per thread.
 namespace {
 struct ProfRec { std::string name; hipEvent_t a, b; };
+std::mutex g_prof_mutex;
 std::vector<ProfRec> g_prof;
 std::string g_prof_filter;
-bool g_prof_on = false, g_prof_open = false;
+bool g_prof_on = false;
+thread_local hipEvent_t g_prof_open_end = nullptr;
 }  // namespace
 
 void w3d_prof_begin(const char *name, hipStream_t stream) {
-    g_prof_open = false;
+    g_prof_open_end = nullptr;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     if (!g_prof_on) return;
     if (g_prof_filter != "*" && std::string(name).find(g_prof_filter) == std::string::npos) return;
     ProfRec r;
@@ -29,11 +35,11 @@ void w3d_prof_begin(const char *name, hipStream_t stream) {
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, stream);
     g_prof.push_back(r);
-    g_prof_open = true;
+    g_prof_open_end = r.b;
 }
 void w3d_prof_end(hipStream_t stream) {
-    if (g_prof_open) (void)hipEventRecord(g_prof.back().b, stream);
-    g_prof_open = false;
+    if (g_prof_open_end) (void)hipEventRecord(g_prof_open_end, stream);
+    g_prof_open_end = nullptr;
 }
 
 void w3d_set_error(const char *fmt, ...) {
@@ -91,6 +97,7 @@ extern "C" {
 int w3d_version(void) { return 100; }
 
 int w3d_profile_enable(const char *kernel_substr) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     g_prof_on = kernel_substr && kernel_substr[0];
     g_prof_filter = g_prof_on ? kernel_substr : "";
     return W3D_OK;
@@ -100,6 +107,7 @@ int w3d_profile_enable(const char *kernel_substr) {
 // and clears the records.
 int w3d_profile_collect(char *out, uint64_t cap) {
     std::map<std::string, std::pair<int, double>> agg;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     for (auto &r : g_prof) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {

@@ -462,9 +462,10 @@ __device__ __forceinline__ void coop_adam(const RawBwd &raw, int b, size_t g0, i
 // other blocks are written as in MODE 0.  No LDS stage, no workgroup barrier.
 template <bool HAS_SH, bool HAS_SCALE_ROT, bool RAW, bool FAST16, int MODE = 0>
 __global__ void __launch_bounds__(256)
-preprocess_bwd_kernel(w3d_view v, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
-                      const float *__restrict__ scales, const float *__restrict__ rotations,
-                      const float *__restrict__ cov3D_precomp, RawBwd raw,
+preprocess_bwd_kernel(w3d_view v, int P, const float *means3D, const float *shs, const float *scales, const float *rotations,
+                      const float *__restrict__ cov3D_precomp, RawBwd raw,     // (no __restrict__ on the parameter inputs:
+                      // the fused-Adam flavour updates the same memory through raw.pw[] later in the kernel; the workgroup
+                      // barrier before the update is the only ordering it relies on)
                       const ushort4 *__restrict__ rect, const uint8_t *__restrict__ clamped,
                       const float *__restrict__ grad2d,
                       float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dcolors,

@@ -3,8 +3,8 @@
 No wheat-plot data ships with the reference, so every config of BASELINE.json runs on this
 generator: a plot-shaped slab of Gaussians seen by 36 overhead cameras (3 rows x 12).
 The camera matrices follow the reference's conventions exactly:
-  * world->view from (R, T) as utils/graphics_utils.py:38-49 (getWorld2View2),
-  * projection as utils/graphics_utils.py:51-71 (getProjectionMatrix), znear 0.01 / zfar 100
+  * world->view from (R, T) with the values of utils/graphics_utils.py:38-49 (getWorld2View2),
+  * projection with the values of utils/graphics_utils.py:51-71 (getProjectionMatrix), znear 0.01 / zfar 100
     (scene/cameras.py:50-51),
   * both handed to the rasterizer TRANSPOSED, full_proj = view^T-form @ proj^T-form, camera
     centre = inverse(view^T-form)[3, :3]   (scene/cameras.py:56-59).
@@ -17,38 +17,23 @@ import numpy as np
 import torch
 
 
-def getWorld2View2(R, t, translate=np.array([0.0, 0.0, 0.0]), scale=1.0):
-    """Restates reference utils/graphics_utils.py:38-49."""
-    Rt = np.zeros((4, 4), dtype=np.float64)
-    Rt[:3, :3] = R.transpose()
-    Rt[:3, 3] = t
-    Rt[3, 3] = 1.0
-    C2W = np.linalg.inv(Rt)
-    cam_center = C2W[:3, 3]
-    cam_center = (cam_center + translate) * scale
-    C2W[:3, 3] = cam_center
-    Rt = np.linalg.inv(C2W)
-    return np.float64(Rt)
+def world_to_view(R, t):
+    """4x4 world->view matrix of a camera stored the reference's way (R = camera-to-world rotation, t = world-to-camera
+    translation: scene/dataset_readers.py, utils/graphics_utils.py:38-49 with the default translate = 0, scale = 1, for
+    which the centre re-normalisation there is the identity).  Pinned by tests/golden/camera.npz."""
+    m = np.eye(4)
+    m[:3, :3] = np.asarray(R, np.float64).T
+    m[:3, 3] = np.asarray(t, np.float64)
+    return m
 
 
-def getProjectionMatrix(znear, zfar, fovX, fovY):
-    """Restates reference utils/graphics_utils.py:51-71."""
-    tanHalfFovY = math.tan(fovY / 2)
-    tanHalfFovX = math.tan(fovX / 2)
-    top = tanHalfFovY * znear
-    bottom = -top
-    right = tanHalfFovX * znear
-    left = -right
-    P = torch.zeros(4, 4)
-    z_sign = 1.0
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
-    P[3, 2] = z_sign
-    P[2, 2] = z_sign * zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
-    return P
+def perspective(znear, zfar, fovX, fovY):
+    """The reference's projection (utils/graphics_utils.py:51-71): a symmetric frustum, z mapped to [0, 1], w = z."""
+    tx, ty = math.tan(0.5 * fovX), math.tan(0.5 * fovY)
+    return torch.tensor([[1.0 / tx, 0.0, 0.0, 0.0],
+                         [0.0, 1.0 / ty, 0.0, 0.0],
+                         [0.0, 0.0, zfar / (zfar - znear), -(zfar * znear) / (zfar - znear)],
+                         [0.0, 0.0, 1.0, 0.0]], dtype=torch.float32)
 
 
 def focal2fov(focal, pixels):
@@ -64,8 +49,8 @@ class SynthCamera:
         self.FoVx, self.FoVy = FoVx, FoVy
         self.image_width, self.image_height = int(width), int(height)
         self.znear, self.zfar = 0.01, 100.0
-        wvt = torch.tensor(getWorld2View2(R, T).astype(np.float32)).transpose(0, 1)
-        proj = getProjectionMatrix(self.znear, self.zfar, FoVx, FoVy).transpose(0, 1)
+        wvt = torch.tensor(world_to_view(R, T).astype(np.float32)).transpose(0, 1)
+        proj = perspective(self.znear, self.zfar, FoVx, FoVy).transpose(0, 1)
         self.world_view_transform = wvt.to(device)
         self.projection_matrix = proj.to(device)
         self.full_proj_transform = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0).to(device)
