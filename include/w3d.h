@@ -80,6 +80,13 @@ typedef struct w3d_view {
                               * 1: additionally drop (Gaussian, tile) instances whose footprint provably
                               * cannot reach alpha >= 1/255 on any pixel of the tile — identical images and
                               * gradients, about half the list entries */
+    int32_t deterministic;   /* backward only.  0: the blend backward adds every (tile, Gaussian) contribution to the
+                              * Gaussian's record with float atomics — fastest, but the order of the additions (hence the
+                              * last bits of every gradient) differs from run to run, as in the reference's CUDA kernels.
+                              * 1: each contribution is stored in the slot of its list entry and one thread per Gaussian
+                              * adds its slots in ascending tile order: bit-identical gradients run to run (the sanitizer
+                              * mode of SURVEY.md section 5).  Needs scratch of w3d_backward_det_sizes() bytes. */
+    uint64_t det_list_capacity; /* deterministic = 1: entries of point_list (= the capacity stage 2 was given) */
 } w3d_view;
 
 int w3d_version(void);
@@ -112,6 +119,8 @@ int w3d_forward_stage2(const w3d_view *view, int32_t P, void *state, void *scrat
                        float *proj_xy, float *gs_depth, w3d_stream_t stream);
 
 int w3d_backward_sizes(int32_t P, uint64_t *scratch_bytes);
+/* scratch of a backward call with view->deterministic = 1 (64 B per Gaussian + 64 B per list entry) */
+int w3d_backward_det_sizes(int32_t P, uint64_t list_capacity, uint64_t *scratch_bytes);
 
 /* Backward of stage1+stage2.  dL_dcolor (3,H,W) required; dL_ddepth / dL_dalpha (H,W) nullable
  * (Wheat-3DGS's loss never feeds them).  Outputs are OVERWRITTEN (zero rows for culled

@@ -214,6 +214,14 @@ int w3d_backward_sizes(int32_t P, uint64_t *scratch_bytes) {
     return W3D_OK;
 }
 
+int w3d_backward_det_sizes(int32_t P, uint64_t list_capacity, uint64_t *scratch_bytes) {
+    if (P < 0) { w3d_set_error("P < 0"); return W3D_ERR_INVALID; }
+    if (scratch_bytes)
+        *scratch_bytes = w3d_align_up((uint64_t)(P > 0 ? P : 1) * W3D_G2D_STRIDE * sizeof(float)) +
+                         w3d_align_up((list_capacity > 0 ? list_capacity : 1) * W3D_G2D_STRIDE * sizeof(float));
+    return W3D_OK;
+}
+
 int w3d_backward(const w3d_view *view, int32_t P, const float *means3D, const float *shs,
                  const float *colors_precomp, const float *opacities, const float *scales,
                  const float *rotations, const float *cov3D_precomp, const void *state,

@@ -358,7 +358,7 @@ __device__ __forceinline__ Staged gather_entry(uint32_t g, const float2 *__restr
 #ifndef W3D_BWD_OCC
 #define W3D_BWD_OCC 4
 #endif
-template <bool HAS_DA>
+template <bool HAS_DA, bool DET>
 __global__ void __launch_bounds__(64 * W3D_RW, HAS_DA ? 3 : W3D_BWD_OCC)   // 2nd argument = waves per SIMD: caps VGPRs at 168 / 128
 render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restrict__ tile_start,
                   const uint32_t *__restrict__ point_list, const float2 *__restrict__ xy,
@@ -366,7 +366,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                   const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
                   const float *__restrict__ dL_dalpha_px, float *__restrict__ grad2d,
-                  const uint32_t *__restrict__ counters) {
+                  const uint32_t *__restrict__ counters, float *__restrict__ inst, uint32_t inst_cap) {
     constexpr int NV = HAS_DA ? 10 : 9;
     __shared__ StagedLDS lds[W3D_RW];
     // row sums of the current half batch: acc[value][entry * 4 + row].  Every (entry, row) slot is written exactly once
@@ -590,8 +590,15 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                         else if (k == 1u) val = -(co.z * sk + co.y * so) * ddely_dy;
                         else if (k < 5u) val = -0.5f * sk;
                         else val = sk;
-                        const uint32_t g = __float_as_uint(s.a[jlo + e].w);
-                        atomicAdd(&grad2d[(size_t)g * W3D_G2D_STRIDE + k], val);
+                        if (DET) {
+                            // deterministic mode: the contribution goes to the slot of its list entry (written once);
+                            // det_gather_kernel adds a Gaussian's slots in tile order
+                            const uint32_t pos = start + (uint32_t)b * 64u + (uint32_t)jlo + e;
+                            if (pos < inst_cap) inst[(size_t)pos * W3D_G2D_STRIDE + k] = val;
+                        } else {
+                            const uint32_t g = __float_as_uint(s.a[jlo + e].w);
+                            atomicAdd(&grad2d[(size_t)g * W3D_G2D_STRIDE + k], val);
+                        }
                     }
                 }
             }
@@ -600,9 +607,59 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     }
 }
 
-__global__ void __launch_bounds__(256) zero_f4_kernel(float4 *__restrict__ p, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
-        p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+// Zeroes the 64-B gradient records of the VISIBLE Gaussians (an all-zero rect marks a culled one, whose record nobody
+// adds to or reads): 4 threads per record, whole lines.
+__global__ void __launch_bounds__(256) zero_visible_records_kernel(float4 *__restrict__ rec, const uint2 *__restrict__ rect, size_t P) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * P) return;
+    const uint2 r = rect[i >> 2];
+    if (r.x | r.y) rec[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Deterministic mode, second half: one thread per visible Gaussian finds its entry in the list of every tile it was binned
+// to (binary search on the list order: depth bits, then id) and adds the slots in ascending tile order.
+__global__ void __launch_bounds__(256)
+det_gather_kernel(int P, int gx, const uint2 *__restrict__ rect, const uint4 *__restrict__ rect_mask, int cull,
+                  const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                  const float4 *__restrict__ rgbd, const uint32_t *__restrict__ counters, const float *__restrict__ inst,
+                  uint32_t inst_cap, float *__restrict__ grad2d) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    const uint2 rc = rect[g];
+    if (!(rc.x | rc.y)) return;
+    const uint32_t minx = rc.x & 0xFFFFu, miny = rc.x >> 16, maxx = rc.y & 0xFFFFu, maxy = rc.y >> 16;
+    const uint32_t w = maxx - minx, nt = w * (maxy - miny);
+    uint64_t mask = ~0ull;
+    if (cull && nt <= 64u) { const uint4 rm = rect_mask[g]; mask = (uint64_t)rm.z | ((uint64_t)rm.w << 32); }
+    const uint32_t cap = min(counters[3], inst_cap);
+    const uint32_t mykey = __float_as_uint(rgbd[g].w);
+    float sum[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) sum[k] = 0.f;
+    for (uint32_t ty = miny; ty < maxy; ty++)
+        for (uint32_t tx = minx; tx < maxx; tx++) {
+            const uint32_t kbit = (ty - miny) * w + (tx - minx);
+            if (nt <= 64u && !((mask >> kbit) & 1ull)) continue;
+            const uint32_t t = ty * (uint32_t)gx + tx;
+            uint32_t lo = min(tile_start[t], cap), hi = min(tile_start[t + 1], cap);
+            while (lo < hi) {                        // first entry whose (depth bits, id) is not below mine
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t e = point_list[mid];
+                const uint32_t ek = __float_as_uint(rgbd[e].w);
+                if (ek < mykey || (ek == mykey && e < (uint32_t)g)) lo = mid + 1; else hi = mid;
+            }
+            if (lo < min(tile_start[t + 1], cap) && point_list[lo] == (uint32_t)g) {
+                const float4 *sl = reinterpret_cast<const float4 *>(inst + (size_t)lo * W3D_G2D_STRIDE);
+                const float4 a = sl[0], bq = sl[1], c = sl[2];
+                sum[0] += a.x; sum[1] += a.y; sum[2] += a.z; sum[3] += a.w;
+                sum[4] += bq.x; sum[5] += bq.y; sum[6] += bq.z; sum[7] += bq.w;
+                sum[8] += c.x; sum[9] += c.y;
+            }
+        }
+    float4 *out = reinterpret_cast<float4 *>(grad2d + (size_t)g * W3D_G2D_STRIDE);
+    out[0] = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    out[1] = make_float4(sum[4], sum[5], sum[6], sum[7]);
+    out[2] = make_float4(sum[8], sum[9], 0.f, 0.f);
 }
 
 __global__ void copy_pixel_state_kernel(const float *__restrict__ fT, const uint32_t *__restrict__ nc, size_t n,
@@ -647,21 +704,47 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
     const uint32_t T = (uint32_t)L.T;
     uint32_t blocks = (T + W3D_RW - 1) / W3D_RW;
     blocks = (blocks + 7) / 8 * 8;
-    {
-        // the record array starts at zero (own kernel rather than hipMemsetAsync: strictly stream-ordered)
-        const size_t n4 = (size_t)(L.P > 0 ? L.P : 1) * W3D_G2D_STRIDE / 4;
-        hipLaunchKernelGGL(zero_f4_kernel, dim3(2048), dim3(256), 0, stream, reinterpret_cast<float4 *>(grad2d), n4);
+    const bool det = v.deterministic != 0;
+    // deterministic mode: [P records][det_list_capacity slots] in the scratch buffer (w3d_backward_det_sizes)
+    float *inst = nullptr;
+    uint32_t inst_cap = 0;
+    static_assert(W3D_G2D_STRIDE == 16, "4 float4 per record");
+    const size_t Pz = (size_t)(L.P > 0 ? L.P : 0);
+    if (det) {
+        const uint64_t cap = v.det_list_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : v.det_list_capacity;
+        inst = reinterpret_cast<float *>(reinterpret_cast<char *>(grad2d) + w3d_align_up((uint64_t)(Pz ? Pz : 1) * W3D_G2D_STRIDE * sizeof(float)));
+        inst_cap = (uint32_t)cap;
+        // entries the reverse walk never reaches contribute nothing: their slots stay zero
+        if (cap) W3D_HIP_CHECK(hipMemsetAsync(inst, 0, cap * W3D_G2D_STRIDE * sizeof(float), stream));
+    } else if (Pz) {
+        // the records the atomics add to start at zero (own kernel rather than hipMemsetAsync: strictly stream-ordered)
+        hipLaunchKernelGGL(zero_visible_records_kernel, dim3((unsigned)((4 * Pz + 255) / 256)), dim3(256), 0, stream,
+                           reinterpret_cast<float4 *>(grad2d), reinterpret_cast<const uint2 *>(state + L.o_rect), Pz);
     }
 #define ARGS                                                                                                      \
     T, (uint32_t)L.gx, L.W, L.H, reinterpret_cast<const uint32_t *>(state + L.o_tile_start), point_list,          \
         reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_conic_op), \
         reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg,                                                 \
         reinterpret_cast<const float *>(state + L.o_final_T), reinterpret_cast<const uint32_t *>(state + L.o_n_contrib), \
-        dL_dcolor, dL_ddepth, dL_dalpha, grad2d, reinterpret_cast<const uint32_t *>(state + L.o_counters)
+        dL_dcolor, dL_ddepth, dL_dalpha, grad2d, reinterpret_cast<const uint32_t *>(state + L.o_counters), inst, inst_cap
     {
         W3D_PROF("render_bwd", stream);
-        if (dL_ddepth || dL_dalpha) hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
-        else hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
+        const bool da = dL_ddepth || dL_dalpha;
+        if (det) {
+            if (da) hipLaunchKernelGGL((render_bwd_kernel<true, true>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
+            else hipLaunchKernelGGL((render_bwd_kernel<false, true>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
+        } else {
+            if (da) hipLaunchKernelGGL((render_bwd_kernel<true, false>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
+            else hipLaunchKernelGGL((render_bwd_kernel<false, false>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
+        }
+    }
+    if (det && Pz) {
+        W3D_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(det_gather_kernel, dim3((unsigned)((Pz + 255) / 256)), dim3(256), 0, stream, (int)Pz, (int)L.gx,
+                           reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint4 *>(state + L.o_tile_mask),
+                           (int)v.tile_cull, reinterpret_cast<const uint32_t *>(state + L.o_tile_start), point_list,
+                           reinterpret_cast<const float4 *>(state + L.o_rgbd),
+                           reinterpret_cast<const uint32_t *>(state + L.o_counters), inst, inst_cap, grad2d);
     }
 #undef ARGS
     W3D_LAUNCH_CHECK(v.debug, stream);

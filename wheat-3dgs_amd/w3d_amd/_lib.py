@@ -26,7 +26,8 @@ class W3DView(ctypes.Structure):
                 ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
                 ("bg", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
                 ("projmatrix", ctypes.c_void_p), ("campos", ctypes.c_void_p),
-                ("tile_cull", ctypes.c_int32)]
+                ("tile_cull", ctypes.c_int32), ("deterministic", ctypes.c_int32),
+                ("det_list_capacity", ctypes.c_uint64)]
 
 
 def _load():
@@ -43,13 +44,14 @@ def _load():
     lib.w3d_forward_stage1.argtypes = [ctypes.POINTER(W3DView), i32] + [vp] * 7 + [vp, vp, vp, vp, vp]
     lib.w3d_forward_stage2.argtypes = [ctypes.POINTER(W3DView), i32, vp, vp, vp, u64, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.w3d_backward_sizes.argtypes = [i32, ctypes.POINTER(u64)]
+    lib.w3d_backward_det_sizes.argtypes = [i32, u64, ctypes.POINTER(u64)]
     lib.w3d_backward.argtypes = [ctypes.POINTER(W3DView), i32] + [vp] * 7 + [vp, vp] + [vp] * 3 + [vp] * 8 + [vp, vp]
     lib.w3d_knn_dist2.argtypes = [i32, vp, vp, vp]
     lib.w3d_knn_sizes.argtypes = [i32, ctypes.POINTER(u64)]
     lib.w3d_knn_dist2_grid.argtypes = [i32, vp, vp, vp, vp]
     lib.w3d_debug_tile_ranges.argtypes = [i32, i32, i32, vp, vp, vp]
     lib.w3d_debug_pixel_state.argtypes = [i32, i32, i32, vp, vp, vp, vp]
-    for name in ("w3d_forward_sizes", "w3d_forward_stage1", "w3d_forward_stage2", "w3d_backward_sizes",
+    for name in ("w3d_forward_sizes", "w3d_forward_stage1", "w3d_forward_stage2", "w3d_backward_sizes", "w3d_backward_det_sizes",
                  "w3d_backward", "w3d_knn_dist2", "w3d_knn_sizes", "w3d_knn_dist2_grid", "w3d_debug_tile_ranges",
                  "w3d_debug_pixel_state"):
         getattr(lib, name).restype = ctypes.c_int

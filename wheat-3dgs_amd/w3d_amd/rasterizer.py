@@ -224,6 +224,32 @@ def _forward_impl(settings, means3D, shs, colors_precomp, opacities, scales, rot
     return color, radii, depth, alpha, saved, extras
 
 
+_DETERMINISTIC = False
+
+
+def set_deterministic(flag):
+    """Deterministic backward (w3d_view.deterministic, include/w3d.h): every (tile, Gaussian) contribution of the blend
+    backward goes to the slot of its list entry and is added per Gaussian in tile order, instead of float atomics whose
+    order — hence the last bits of every gradient — changes from run to run.  About 2x the backward time; meant for
+    debugging and for tests that compare parameters after several optimizer steps bit for bit.  Returns the old value."""
+    global _DETERMINISTIC
+    old, _DETERMINISTIC = _DETERMINISTIC, bool(flag)
+    return old
+
+
+def backward_scratch(view, P, point_list, dev):
+    """The scratch buffer of a backward call; selects the deterministic mode in `view` if it is switched on."""
+    sb = ctypes.c_uint64()
+    if _DETERMINISTIC:
+        cap = int(point_list.numel())
+        view.c.deterministic, view.c.det_list_capacity = 1, cap
+        check(lib.w3d_backward_det_sizes(P, cap, ctypes.byref(sb)))
+    else:
+        view.c.deterministic, view.c.det_list_capacity = 0, 0
+        check(lib.w3d_backward_sizes(P, ctypes.byref(sb)))
+    return torch.empty(sb.value, dtype=torch.uint8, device=dev)
+
+
 def _backward_impl(saved, grad_color, grad_depth, grad_alpha):
     view, P = saved["view"], saved["P"]
     dev = saved["means3D"].device
@@ -242,9 +268,7 @@ def _backward_impl(saved, grad_color, grad_depth, grad_alpha):
     if P == 0:
         return g_means3D, g_means2D, g_shs, g_colors, g_opac, g_scales, g_rots, g_cov
     with torch.cuda.device(dev):
-        sb = ctypes.c_uint64()
-        check(lib.w3d_backward_sizes(P, ctypes.byref(sb)))
-        scratch = torch.empty(sb.value, dtype=torch.uint8, device=dev)
+        scratch = backward_scratch(view, P, saved["point_list"], dev)
         check(lib.w3d_backward(ctypes.byref(view.c), P, ptr(saved["means3D"]), ptr(shs), ptr(colors_precomp),
                                ptr(saved["opacities"]), ptr(scales), ptr(saved["rotations"]), ptr(cov3D_precomp),
                                ptr(saved["state"]), ptr(saved["point_list"]), ptr(grad_color), ptr(grad_depth),
