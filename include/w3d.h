@@ -241,6 +241,22 @@ int w3d_l1_ssim_fwd_bwd(int32_t C, int32_t H, int32_t W, const float *image, con
                         float lambda_dssim, float *loss_out, float *dL_dimage, void *scratch,
                         w3d_stream_t stream);
 
+/* The same two passes as separate calls, for a caller whose loss lines are the reference's own
+ * (train_vanilla_3dgs.py:77-79:  Ll1 = l1_loss(image, gt);  loss = (1-l)*Ll1 + l*(1 - ssim(image, gt))  with
+ * utils/loss_utils.py:17-18,39-63): w3d_l1_ssim_values runs pass A and writes *l1_out = mean|image - gt| and
+ * *ssim_out = ssim(image, gt) (device scalars); w3d_l1_ssim_grad runs pass B on the maps pass A left in `scratch` (same
+ * buffer, untouched in between) with the two upstream gradients read from the DEVICE, w_l1 = dL/dLl1 and
+ * w_ssim = dL/dssim (NULL = 0):  dL_dimage = w_l1 * dLl1/dimage + w_ssim * dssim/dimage  — no host sync in between. */
+int w3d_l1_ssim_values(int32_t C, int32_t H, int32_t W, const float *image, const float *gt, float *l1_out,
+                       float *ssim_out, void *scratch, w3d_stream_t stream);
+int w3d_l1_ssim_grad(int32_t C, int32_t H, int32_t W, const float *image, const float *gt, const float *w_l1,
+                     const float *w_ssim, float *dL_dimage, void *scratch, w3d_stream_t stream);
+
+/* add_densification_stats of scene/gaussian_model.py:461-463 in one pass: for every row with update_filter != 0
+ * (a (P,) array of bytes, torch.bool):  xyz_gradient_accum += ||dL_dmeans2D[:, :2]||,  denom += 1. */
+int w3d_add_densification_stats(int32_t P, const float *dL_dmeans2D, const uint8_t *update_filter,
+                                float *xyz_gradient_accum, float *denom, w3d_stream_t stream);
+
 /* ---- next-row N2: one Adam step over n contiguous fp32 elements (torch.optim.Adam semantics,
  * no weight decay / amsgrad): m,v updated in place, param -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).
  * The four arrays must share their 16-B misalignment.  zero_grad != 0 also clears grad. */

@@ -479,3 +479,79 @@ def test_training_recovers_a_perturbed_scene():
     assert p_train1 >= p_train0 + 10.0, (p_train0, p_train1)      # measured: 19.1 -> 36.9 dB
     assert p_held1 >= p_held0 + 5.0, (p_held0, p_held1)          # measured: 19.0 -> 27.9 dB
     assert torch.isfinite(m.flat).all()
+
+
+@pytest.mark.parametrize("shape", [(3, 97, 131), (3, 160, 208), (1, 33, 40)])
+def test_reference_loss_lines_run_as_one_fused_pair(shape):
+    """train_vanilla_3dgs.py:77-79 as written — Ll1 = l1_loss(image, gt); loss = (1-l)*Ll1 + l*(1-ssim(image, gt)) — goes
+    through ONE autograd node (loss._FusedLossPair): values and dL/dimage equal the torch restatement of the reference."""
+    from w3d_amd import loss as L
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    gt = torch.rand(*shape, generator=g).to(dev)
+    base = (gt.cpu() + 0.1 * torch.randn(*shape, generator=g)).clamp(0, 1).to(dev)
+    lam = 0.2
+    img = base.clone().requires_grad_(True)
+    Ll1 = L.l1_loss(img, gt)
+    assert L._pending is not None and type(Ll1.grad_fn).__name__.startswith("_FusedLossPair")
+    s = L.ssim(img, gt)
+    assert L._pending is None and s.grad_fn is Ll1.grad_fn            # the same node: no second pass A
+    loss = (1.0 - lam) * Ll1 + lam * (1.0 - s)
+    loss.backward()
+    ref_img = base.clone().requires_grad_(True)
+    ref_l1 = torch.abs(ref_img - gt).mean()
+    ref_s = L.ssim_torch(ref_img, gt)
+    ref = (1.0 - lam) * ref_l1 + lam * (1.0 - ref_s)
+    ref.backward()
+    assert abs(float(Ll1) - float(ref_l1)) <= 2e-6 and abs(float(s) - float(ref_s)) <= 2e-6
+    assert abs(float(loss) - float(ref)) <= 2e-6
+    err = float((img.grad - ref_img.grad).abs().max() / ref_img.grad.abs().max())
+    assert err <= 2e-4, err
+    # and it equals the single-call fused loss bit for bit in value, to rounding in the gradient
+    img2 = base.clone().requires_grad_(True)
+    l2 = L.photometric_loss(img2, gt, lam)
+    l2.backward()
+    assert abs(float(l2) - float(loss)) <= 1e-6
+    assert float((img2.grad - img.grad).abs().max() / img.grad.abs().max()) <= 1e-5
+    # only one of the two outputs used: the other weight is zero
+    img3 = base.clone().requires_grad_(True)
+    (3.0 * L.l1_loss(img3, gt)).backward()
+    r3 = base.clone().requires_grad_(True)
+    (3.0 * torch.abs(r3 - gt).mean()).backward()
+    assert float((img3.grad - r3.grad).abs().max()) <= 1e-7 * 3.0
+    # a pending SSIM is only handed to a call on the SAME tensors; ssim() on other images runs its own kernel pair
+    img4 = base.clone().requires_grad_(True)
+    L.l1_loss(img4, gt)
+    other = (base * 0.5).clone().requires_grad_(True)
+    s_other = L.ssim(other, gt)
+    assert abs(float(s_other) - float(L.ssim_torch(other.detach(), gt))) <= 2e-6
+    assert L._pending is None
+    # without grad (evaluation code) l1_loss is the plain torch expression
+    with torch.no_grad():
+        assert L.l1_loss(base, gt).grad_fn is None and L._pending is None
+
+
+def test_add_densification_stats_kernel_matches_the_reference_statements():
+    """scene/gaussian_model.py:461-463 on a boolean filter: one kernel, same values as the masked torch statements."""
+    from w3d_amd.gaussian_model import GaussianModel
+    from w3d_amd.synth import make_scene
+    dev = torch.device("cuda:0")
+    sc = make_scene(5000, seed=3)
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    from w3d_amd.gaussian_model import OptimizationParams
+    m.training_setup(OptimizationParams())
+    g = torch.Generator().manual_seed(1)
+    vp = torch.zeros(5000, 3, device=dev, requires_grad=True)
+    vp.grad = torch.randn(5000, 3, generator=g).to(dev)
+    filt = (torch.rand(5000, generator=g) > 0.4).to(dev)
+    acc0 = torch.rand(5000, 1, generator=g).to(dev)
+    den0 = torch.randint(0, 5, (5000, 1), generator=g).float().to(dev)
+    m.xyz_gradient_accum.copy_(acc0); m.denom.copy_(den0)
+    m.add_densification_stats(vp, filt)
+    ref_acc, ref_den = acc0.clone(), den0.clone()
+    ref_acc[filt] += torch.norm(vp.grad[filt, :2], dim=-1, keepdim=True)
+    ref_den[filt] += 1
+    assert torch.equal(m.denom, ref_den)
+    assert float((m.xyz_gradient_accum - ref_acc).abs().max()) <= 1e-6
+    assert torch.equal(m.xyz_gradient_accum[~filt], acc0[~filt])

@@ -91,3 +91,31 @@ extern "C" int w3d_densify_compact(int32_t n_blocks, const int32_t *block_dims_h
     W3D_HIP_CHECK(hipGetLastError());
     return W3D_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// add_densification_stats (scene/gaussian_model.py:461-463) for a boolean update filter, one pass over P rows
+namespace {
+__global__ void __launch_bounds__(256)
+densify_stats_kernel(int P, const float *__restrict__ g2d, const uint8_t *__restrict__ filter, float *__restrict__ accum,
+                     float *__restrict__ denom) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P || !filter[g]) return;
+    const float x = g2d[3 * (size_t)g], y = g2d[3 * (size_t)g + 1];
+    accum[g] += sqrtf(x * x + y * y);
+    denom[g] += 1.f;
+}
+}  // namespace
+
+extern "C" int w3d_add_densification_stats(int32_t P, const float *dL_dmeans2D, const uint8_t *update_filter,
+                                           float *xyz_gradient_accum, float *denom, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (P < 0 || (P > 0 && (!dL_dmeans2D || !update_filter || !xyz_gradient_accum || !denom))) {
+        w3d_set_error("add_densification_stats: bad arguments");
+        return W3D_ERR_INVALID;
+    }
+    if (P == 0) return W3D_OK;
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, dL_dmeans2D, update_filter,
+                       xyz_gradient_accum, denom);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}

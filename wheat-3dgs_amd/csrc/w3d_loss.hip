@@ -144,8 +144,16 @@ ssim_pass_a(int H, int W, const float *__restrict__ img, const float *__restrict
 
 __global__ void __launch_bounds__(LNT)
 ssim_pass_b(int H, int W, const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ d_mu1,
-            const float *__restrict__ d_ex2, const float *__restrict__ d_exy, float lambda, float inv_n,
+            const float *__restrict__ d_ex2, const float *__restrict__ d_exy, float c_l1, float c_ssim,
+            const float *__restrict__ w_l1, const float *__restrict__ w_ssim, int weighted,
             float *__restrict__ grad, GW11 gw) {
+    // grad = c_l1 * sign(x - y) - c_ssim * d(sum of the ssim map)/dx.  Classic call: c_l1 = (1 - lambda) / n, c_ssim = lambda / n.
+    // Weighted call (w3d_l1_ssim_grad): the upstream gradients dL/dL1 and dL/dSSIM are device scalars (NULL = 0) and scale
+    // 1/n and -1/n.
+    if (weighted) {
+        c_l1 = w_l1 ? w_l1[0] * c_l1 : 0.f;
+        c_ssim = w_ssim ? w_ssim[0] * c_ssim : 0.f;
+    }
     __shared__ float s[3][LW][LW + 1];
     __shared__ float h[3][LW][LT + 1];
     const int c = blockIdx.z;
@@ -218,13 +226,14 @@ ssim_pass_b(int H, int W, const float *__restrict__ img, const float *__restrict
             const float x = img[pix], y = gt[pix];
             const float d = x - y;
             const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            grad[pix] = (1.f - lambda) * inv_n * sgn - lambda * inv_n * (acc[0][o] + 2.f * x * acc[1][o] + y * acc[2][o]);
+            grad[pix] = c_l1 * sgn - c_ssim * (acc[0][o] + 2.f * x * acc[1][o] + y * acc[2][o]);
         }
     }
 }
 
 __global__ void __launch_bounds__(1024)
-loss_finalize(const float *__restrict__ sums, uint32_t nblocks, float lambda, float inv_n, float *__restrict__ loss) {
+loss_finalize(const float *__restrict__ sums, uint32_t nblocks, float lambda, float inv_n, float *__restrict__ loss,
+              float *__restrict__ l1_out, float *__restrict__ ssim_out) {
     __shared__ float red[16];
     float a = 0.f, b = 0.f;
     const float2 *s2 = reinterpret_cast<const float2 *>(sums);
@@ -232,7 +241,11 @@ loss_finalize(const float *__restrict__ sums, uint32_t nblocks, float lambda, fl
     for (uint32_t i = threadIdx.x; i < nblocks; i += 1024) { const float2 v = s2[i]; a += v.x; b += v.y; }
     const float l1 = block_sum(a, red);
     const float sv = block_sum(b, red);
-    if (threadIdx.x == 0) loss[0] = (1.f - lambda) * (l1 * inv_n) + lambda * (1.f - sv * inv_n);
+    if (threadIdx.x == 0) {
+        if (loss) loss[0] = (1.f - lambda) * (l1 * inv_n) + lambda * (1.f - sv * inv_n);
+        if (l1_out) l1_out[0] = l1 * inv_n;
+        if (ssim_out) ssim_out[0] = sv * inv_n;
+    }
 }
 
 }  // namespace
@@ -244,6 +257,25 @@ extern "C" int w3d_l1_ssim_sizes(int32_t C, int32_t H, int32_t W, uint64_t *scra
     return W3D_OK;
 }
 
+namespace {
+struct LossBufs { float *d_mu1, *d_ex2, *d_exy, *sums; GW11 gw; dim3 grid; float inv_n; };
+LossBufs loss_bufs(int32_t C, int32_t H, int32_t W, void *scratch) {
+    LossBufs b;
+    char *sc = static_cast<char *>(scratch);
+    const uint64_t plane = w3d_align_up((uint64_t)C * H * W * 4);
+    b.d_mu1 = reinterpret_cast<float *>(sc); b.d_ex2 = reinterpret_cast<float *>(sc + plane);
+    b.d_exy = reinterpret_cast<float *>(sc + 2 * plane);
+    b.sums = reinterpret_cast<float *>(sc + 3 * plane);
+    // exact fp32 window of the reference: exp(-(x-5)^2 / (2*1.5^2)) normalised
+    float sum = 0.f;
+    for (int i = 0; i < 11; i++) { b.gw.w[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); sum += b.gw.w[i]; }
+    for (int i = 0; i < 11; i++) b.gw.w[i] /= sum;
+    b.grid = dim3((W + LT - 1) / LT, (H + LT - 1) / LT, C);
+    b.inv_n = 1.0f / ((float)C * (float)H * (float)W);
+    return b;
+}
+}  // namespace
+
 extern "C" int w3d_l1_ssim_fwd_bwd(int32_t C, int32_t H, int32_t W, const float *image, const float *gt,
                                    float lambda_dssim, float *loss_out, float *dL_dimage, void *scratch,
                                    w3d_stream_t stream_) {
@@ -252,23 +284,45 @@ extern "C" int w3d_l1_ssim_fwd_bwd(int32_t C, int32_t H, int32_t W, const float 
         w3d_set_error("loss: bad arguments");
         return W3D_ERR_INVALID;
     }
-    char *sc = static_cast<char *>(scratch);
-    const uint64_t plane = w3d_align_up((uint64_t)C * H * W * 4);
-    float *d_mu1 = reinterpret_cast<float *>(sc), *d_ex2 = reinterpret_cast<float *>(sc + plane),
-          *d_exy = reinterpret_cast<float *>(sc + 2 * plane);
-    float *sums = reinterpret_cast<float *>(sc + 3 * plane);
-    // exact fp32 window of the reference: exp(-(x-5)^2 / (2*1.5^2)) normalised
-    GW11 gw;
-    float sum = 0.f;
-    for (int i = 0; i < 11; i++) { gw.w[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); sum += gw.w[i]; }
-    for (int i = 0; i < 11; i++) gw.w[i] /= sum;
-    const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
-    const float inv_n = 1.0f / ((float)C * (float)H * (float)W);
-    hipLaunchKernelGGL(ssim_pass_a, grid, dim3(LNT), 0, stream, H, W, image, gt, d_mu1, d_ex2, d_exy, sums, gw);
+    const LossBufs b = loss_bufs(C, H, W, scratch);
+    hipLaunchKernelGGL(ssim_pass_a, b.grid, dim3(LNT), 0, stream, H, W, image, gt, b.d_mu1, b.d_ex2, b.d_exy, b.sums, b.gw);
     W3D_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)(grid.x * grid.y * grid.z), lambda_dssim, inv_n, loss_out);
-    hipLaunchKernelGGL(ssim_pass_b, grid, dim3(LNT), 0, stream, H, W, image, gt, d_mu1, d_ex2, d_exy, lambda_dssim, inv_n,
-                       dL_dimage, gw);
+    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(1024), 0, stream, b.sums, (uint32_t)(b.grid.x * b.grid.y * b.grid.z), lambda_dssim,
+                       b.inv_n, loss_out, (float *)nullptr, (float *)nullptr);
+    hipLaunchKernelGGL(ssim_pass_b, b.grid, dim3(LNT), 0, stream, H, W, image, gt, b.d_mu1, b.d_ex2, b.d_exy,
+                       (1.f - lambda_dssim) * b.inv_n, lambda_dssim * b.inv_n, (const float *)nullptr, (const float *)nullptr, 0,
+                       dL_dimage, b.gw);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}
+
+extern "C" int w3d_l1_ssim_values(int32_t C, int32_t H, int32_t W, const float *image, const float *gt, float *l1_out,
+                                  float *ssim_out, void *scratch, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (C <= 0 || H <= 0 || W <= 0 || !image || !gt || !l1_out || !ssim_out || !scratch) {
+        w3d_set_error("loss values: bad arguments");
+        return W3D_ERR_INVALID;
+    }
+    const LossBufs b = loss_bufs(C, H, W, scratch);
+    hipLaunchKernelGGL(ssim_pass_a, b.grid, dim3(LNT), 0, stream, H, W, image, gt, b.d_mu1, b.d_ex2, b.d_exy, b.sums, b.gw);
+    W3D_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(1024), 0, stream, b.sums, (uint32_t)(b.grid.x * b.grid.y * b.grid.z), 0.f,
+                       b.inv_n, (float *)nullptr, l1_out, ssim_out);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}
+
+extern "C" int w3d_l1_ssim_grad(int32_t C, int32_t H, int32_t W, const float *image, const float *gt, const float *w_l1,
+                                const float *w_ssim, float *dL_dimage, void *scratch, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (C <= 0 || H <= 0 || W <= 0 || !image || !gt || !dL_dimage || !scratch) {
+        w3d_set_error("loss grad: bad arguments");
+        return W3D_ERR_INVALID;
+    }
+    const LossBufs b = loss_bufs(C, H, W, scratch);
+    // dSSIM/dx = +1/n * d(sum of the map)/dx: the classic call's c_ssim carries lambda/n with a minus sign in the formula
+    hipLaunchKernelGGL(ssim_pass_b, b.grid, dim3(LNT), 0, stream, H, W, image, gt, b.d_mu1, b.d_ex2, b.d_exy, b.inv_n, -b.inv_n,
+                       w_l1, w_ssim, 1, dL_dimage, b.gw);
     W3D_HIP_CHECK(hipGetLastError());
     return W3D_OK;
 }

@@ -237,7 +237,12 @@ class _RasterizeRawFn(torch.autograd.Function):
 def render_raw_autograd(cam, model, bg_color, scaling_modifier=1.0):
     """The dict of render() (reference gaussian_renderer/__init__.py:99-106) through _RasterizeRawFn."""
     xyz = model._p["xyz"]
-    screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+    # (reference gaussian_renderer/__init__.py:33-37 builds a zeros tensor per call only to collect its .grad: the zeros
+    #  are shared — nothing writes to them — and every call gets its own leaf over them)
+    z = getattr(model, "_screenspace_zeros", None)
+    if z is None or z.shape != xyz.shape or z.device != xyz.device:
+        z = model._screenspace_zeros = torch.zeros_like(xyz)
+    screenspace_points = z.detach().requires_grad_(True)
     p = model._p
     color, radii, depth, alpha = _RasterizeRawFn.apply(screenspace_points, p["xyz"], p["f_dc"], p["f_rest"], p["opacity"],
                                                        p["scaling"], p["rotation"], model, cam, bg_color, scaling_modifier)

@@ -253,6 +253,11 @@ class GaussianModel:
             self.xyz_gradient_accum[update_filter] += torch.norm(g[update_filter, :2], dim=-1, keepdim=True)
             self.denom[update_filter] += 1
             return
+        if g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.dim() == 2 and g.shape[1] == 3 and \
+                self.xyz_gradient_accum.is_contiguous() and self.denom.is_contiguous():
+            from .fused import add_densification_stats
+            add_densification_stats(g, update_filter.reshape(-1).contiguous(), self.xyz_gradient_accum, self.denom)
+            return
         f = update_filter.reshape(-1, 1).to(self.xyz_gradient_accum.dtype)
         norm = torch.norm(g[:, :2], dim=-1, keepdim=True)
         self.xyz_gradient_accum += torch.where(update_filter.reshape(-1, 1), norm, torch.zeros_like(norm))
