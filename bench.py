@@ -542,6 +542,8 @@ def main():
         t_el, it, _ = timed(args.steps, it, None)
         trained = {"value": round(world * args.steps / t_el, 3), "ms_per_step": round(1e3 * t_el / args.steps, 4),
                    "after_steps": it - args.steps, "final_loss": round(float(trainer.last["loss"]), 6)}
+        _, it, st3 = timed(20, it, b"*")                 # per-stage times of the trained scene (outside its timed region)
+        trained["stage_ms"] = {k: round(ms / c, 4) for k, (c, ms) in st3.items() if c > 0}
         if rank == 0:
             w2 = [workload_stats(model, cams[i], bg, dev) for i in (0, len(cams) // 2)]
             trained["walked_instances_per_view"] = int(sum(w["R_walk"] for w in w2) / len(w2))
