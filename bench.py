@@ -372,7 +372,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    force_dist = args.force_dist or os.environ.get("W3D_FORCE_DIST", "0") == "1"
+    force_dist = args.force_dist
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

@@ -8,7 +8,6 @@ memory (outputs, state, scratch, lists all come from its caching allocator, so t
 ``torch.cuda.empty_cache()`` calls — run_3d_seg.py:99 — keep working) and the stream.
 """
 import ctypes
-import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -18,9 +17,9 @@ from ._lib import W3DView, check, lib, ptr, stream_ptr
 
 
 # Exact footprint culling of tile instances (w3d_view.tile_cull): outputs are unchanged, the per-tile
-# lists are about half as long.  Set False (or W3D_TILE_CULL=0) to get the published bounding-square
-# lists, e.g. to compare them entry by entry with another implementation.
-TILE_CULL = os.environ.get("W3D_TILE_CULL", "1") != "0"
+# lists are about 40 % shorter.  Set False to get the published bounding-square lists, e.g. to compare
+# them entry by entry with another implementation (tests/test_gpu_parity.py does).
+TILE_CULL = True
 
 
 class GaussianRasterizationSettings(NamedTuple):
