@@ -9,9 +9,12 @@
 //   * quadrant-level culling: a whole 8x8 quadrant skips exp/accumulate for a Gaussian when no
 //     lane of it can reach alpha >= 1/255 (wave-uniform branch on a ballot);
 //   * in the backward pass the per-Gaussian partial sums of the 4 pixels are added in registers
-//     first, then ONE wave reduction (DPP row ops + row_bcast, no LDS traffic) per tile instance
-//     and ONE 40-B atomic record update per tile instance — instead of 9 atomics per
-//     (pixel, Gaussian) pair.
+//     first, then reduced over each 16-lane row with bank-masked DPP adds (a reduce-scatter: 21
+//     DPP adds for 9-10 values), the row sums go to per-(entry, row) LDS slots with plain stores,
+//     and the flush adds the four rows and issues 4 records (36-40 B each) per global atomic
+//     instruction — instead of 9 atomics per (pixel, Gaussian) pair.  With view.deterministic the
+//     flush stores into the slot of the list entry instead (det_gather_kernel adds them per
+//     Gaussian in tile order).
 // One tile-wave per workgroup (W3D_RW); the wave -> tile map keeps the tiles of one XCD contiguous so
 // neighbouring tiles (which share Gaussians) hit the same L2.
 #include "w3d_common.h"
