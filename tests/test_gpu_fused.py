@@ -555,3 +555,35 @@ def test_add_densification_stats_kernel_matches_the_reference_statements():
     assert torch.equal(m.denom, ref_den)
     assert float((m.xyz_gradient_accum - ref_acc).abs().max()) <= 1e-6
     assert torch.equal(m.xyz_gradient_accum[~filt], acc0[~filt])
+
+
+@pytest.mark.parametrize("P", [1, 63, 65, 4099, 6001])
+def test_raw_forward_with_ragged_point_counts(P):
+    """The raw-parameter preprocess fetches the SH rows of a wave's 64 Gaussians as one span through LDS: point counts that
+    leave a partial last wave (and 1-3 floats behind its last whole 16-B chunk) must give the drop-in module's image."""
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel
+    from w3d_amd.gaussian_renderer import render
+    from w3d_amd.train import PipelineParams
+    import w3d_amd.gaussian_renderer as gr
+    dev = torch.device("cuda:0")
+    cam = make_cameras(3, 208, 160)[1].to(dev)
+    sc = make_scene(P, seed=P, scale_mean=0.05)
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    m.active_sh_degree = 3
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    with torch.no_grad():
+        raw = render(cam, m, PipelineParams(), bg)                    # no grad: the raw-parameter forward
+    gr.RAW_AUTOGRAD = False
+    try:
+        ref = render(cam, m, PipelineParams(), bg)                    # activated tensors through the drop-in module
+    finally:
+        gr.RAW_AUTOGRAD = True
+    assert int((raw["radii"] > 0).sum()) > 0
+    assert torch.equal(raw["radii"] > 0, ref["radii"] > 0)
+    # (in-kernel exp / sigmoid / normalize vs torch's: inputs differ in the last bit, so a pixel where some alpha sits on
+    #  the 1/255 threshold may flip — a wrong SH row would move whole footprints by O(0.1))
+    for k in ("render", "depth"):
+        d = (raw[k] - ref[k]).abs() / max(1.0, float(ref[k].abs().max()))
+        assert float((d > 2e-5).float().mean()) <= 2e-4 and float(d.max()) <= 5e-3, (k, float(d.max()))
