@@ -15,8 +15,11 @@ CLIENT = os.path.join(ROOT, "tests", "c_client", "_bin", "w3d_c_client")
 
 
 def test_plain_c_host_gets_the_same_bits_as_the_python_binding(tmp_path):
-    if not os.path.exists(CLIENT):
-        pytest.fail("tests/c_client/_bin/w3d_c_client is missing: run __graft_entry__.build()")
+    if not os.path.exists(CLIENT):          # (normally built by __graft_entry__.build(); gcc is part of the image)
+        import sys
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build_c_client()
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from w3d_amd import rasterizer
     from w3d_amd.synth import small_test_scene
