@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--dropin-steps", type=int, default=-1, help="steps of the reference-loop measurement (-1: = --steps, 0: skip)")
     ap.add_argument("--trained-steps", type=int, default=3000,
                     help="extra training steps before the second (trained-scene) measurement; 0: skip")
+    ap.add_argument("--dropin-only", action="store_true",
+                    help="run only the reference-loop measurement (for rocprofv3 --kernel-trace of that loop) and print its JSON")
     ap.add_argument("--no-extras", action="store_true", help="skip render / FlashSplat / drop-in / trained-scene measurements")
     ap.add_argument("--force-dist", action="store_true", help="1-rank RCCL group: exercises the exchange path on one GPU")
     ap.add_argument("--dry-run", action="store_true",
@@ -384,6 +386,11 @@ def main():
     bg = torch.zeros(3, device=dev)
     sc, model, opt, cams = build_scene(args, dev)
     make_ground_truth(args, cams, dev, bg)
+    if args.dropin_only:
+        del model
+        g = torch.Generator(device="cpu").manual_seed(0)
+        print(json.dumps({"dropin": time_dropin(args, sc, cams, bg, dev, torch.randperm(len(cams), generator=g).tolist())}))
+        return
     loss_fn = photometric_loss_torch if args.torch_loss else photometric_loss
     trainer = Trainer(model, cams, opt, bg, densify=False, loss_fn=loss_fn, fused=False if args.autograd_path else None,
                       force_exchange=force_dist, exchange=args.exchange)
