@@ -79,7 +79,7 @@ typedef struct w3d_view {
                               * rule; lists comparable entry by entry with a reference implementation);
                               * 1: additionally drop (Gaussian, tile) instances whose footprint provably
                               * cannot reach alpha >= 1/255 on any pixel of the tile — identical images and
-                              * gradients, about half the list entries */
+                              * gradients, 40-60 % of the list entries */
     int32_t deterministic;   /* backward only.  0: the blend backward adds every (tile, Gaussian) contribution to the
                               * Gaussian's record with float atomics — fastest, but the order of the additions (hence the
                               * last bits of every gradient) differs from run to run, as in the reference's CUDA kernels.
