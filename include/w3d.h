@@ -177,6 +177,15 @@ int w3d_backward_raw(const w3d_view *view, int32_t P, const w3d_raw_params *para
                      const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth,
                      const float *dL_dalpha, const w3d_raw_grads *grads, const w3d_densify_stats *stats,
                      void *scratch, w3d_stream_t stream);
+/* Stage 1 on a SUBSET of the Gaussians <- flashsplat_render(..., used_mask=obj_used_mask), reference
+ * gaussian_renderer/__init__.py:151-156,168-170,186-187 (means3D[used_mask], opacity[used_mask], scales / rotations /
+ * shs[used_mask]), the most frequent rasterizer call of run_3d_seg.py (:130-134 find_match, :362).  used_mask: (P,) bytes
+ * (torch.bool), non-zero = render this Gaussian; NULL = all.  A Gaussian that is left out is culled before any of its
+ * parameters is read: radii 0, no tile instances.  Everything downstream (stage 2, the FlashSplat extras) is unchanged
+ * and keeps P rows, so row i of every per-Gaussian output still belongs to Gaussian i of the parameter blocks; the
+ * reference's outputs are those rows gathered with the same mask. */
+int w3d_forward_stage1_raw_subset(const w3d_view *view, int32_t P, const w3d_raw_params *params, const uint8_t *used_mask,
+                                  int32_t *radii, void *state, void *scratch, uint32_t *counts_host, w3d_stream_t stream);
 
 /* Single-GPU fusion of the optimizer into the backward pass (next-row N2): the per-Gaussian stage of the backward has
  * the complete gradient of its Gaussian in registers / LDS, so it applies torch.optim.Adam's update

@@ -143,6 +143,24 @@ class COracle:
         the spread between the two runs is the uncertainty any fp32 implementation has against this oracle."""
         cls.lib().w3do_set_exp_mode(ctypes.c_int(int(mode)))
 
+    def fragile_pixels(self, eps):
+        """(H,W) bool: pixels whose walk meets a (pixel, Gaussian) pair within `eps` (relative) of one of the blend's
+        thresholds — alpha vs 1/255, transmittance vs 1e-4, power vs 0 (w3d_oracle.c: w3do_fragile_pixels)."""
+        out = np.zeros((self.H, self.W), np.uint8)
+        lib = self.lib()
+        lib.w3do_fragile_pixels.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.POINTER(ctypes.c_ubyte)]
+        lib.w3do_fragile_pixels(ctypes.c_void_p(self.h), ctypes.c_float(eps), _ptr(out, ctypes.c_ubyte))
+        return out.astype(bool)
+
+    def contributors_of(self, pixel_mask):
+        """(P,) bool: Gaussians blended at any pixel of `pixel_mask` (H,W) (w3do_mark_contributors)."""
+        pm = np.ascontiguousarray(np.asarray(pixel_mask).reshape(self.H, self.W).astype(np.uint8))
+        flags = np.zeros(self.P, np.uint8)
+        lib = self.lib()
+        lib.w3do_mark_contributors.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_ubyte)]
+        lib.w3do_mark_contributors(ctypes.c_void_p(self.h), _ptr(pm, ctypes.c_ubyte), _ptr(flags, ctypes.c_ubyte))
+        return flags.astype(bool)
+
     def num_rendered(self):
         return int(self.lib().w3do_num_rendered(ctypes.c_void_p(self.h)))
 
@@ -170,10 +188,15 @@ class COracle:
         self.lib().w3do_get_pixel_state(ctypes.c_void_p(self.h), _ptr(ft), _ptr(nc, ctypes.c_uint32))
         return ft, nc
 
-    def backward(self, dL_dcolor, dL_ddepth=None, dL_dalpha=None):
+    def backward(self, dL_dcolor, dL_ddepth=None, dL_dalpha=None, abs_sums=False):
+        """abs_sums=True: also g["means2D_abs"] (P,2) float64 = sum over the summands of |term| of dL/dmean2D.x / .y — the
+        conditioning of the densification statistic (w3do_set_abs_sums)."""
         assert self.h is not None, "forward first"
         i = self.inputs
         P = self.P
+        absbuf = np.zeros((P, 2), np.float64) if abs_sums else None
+        self.lib().w3do_set_abs_sums.argtypes = [ctypes.POINTER(ctypes.c_double)]
+        self.lib().w3do_set_abs_sums(_ptr(absbuf, ctypes.c_double))
         M = self.v.sh_coeffs
         dL_dcolor = _f32(dL_dcolor).reshape(3, self.H, self.W)
         dL_ddepth = None if dL_ddepth is None else _f32(dL_ddepth).reshape(self.H, self.W)
@@ -191,6 +214,9 @@ class COracle:
                                  _ptr(dL_dalpha), _ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["colors_precomp"]),
                                  _ptr(g["shs"]), _ptr(g["opacities"]), _ptr(g["scales"]), _ptr(g["rotations"]),
                                  _ptr(g["cov3D"]), ctypes.c_int(self.nthreads))
+        self.lib().w3do_set_abs_sums(None)
+        if abs_sums:
+            g["means2D_abs"] = absbuf
         if i["cov3D_precomp"] is None:
             g["cov3D_precomp"] = None
         else:

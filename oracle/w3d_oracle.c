@@ -54,6 +54,14 @@
  * flip, and ill-conditioned per-Gaussian sums move. */
 static int g_exp_mode = 0;
 void w3do_set_exp_mode(int mode) { g_exp_mode = mode; }
+/* Conditioning of the densification statistic (tests only): when set, w3do_backward adds |term| of every summand of
+ * dL/dmean2D.x / .y into abs_out[2g], abs_out[2g+1] (doubles, zeroed by the caller) — with the two products of a summand
+ * (G dx conic.x and G dy conic.y) taken separately, so the bound also covers an implementation that sums the moments
+ * sum(m dx), sum(m dy) first and combines them with the conic afterwards.  sum|terms| / |sum terms| is the condition number of
+ * that Gaussian's sum: an fp32 implementation that rounds each term (relative 2^-24) can be off by ~2^-24 * sum|terms|
+ * however it orders the additions — which exceeds 1e-4 of the result where terms cancel. */
+static double *g_abs_out = NULL;
+void w3do_set_abs_sums(double *abs_out) { g_abs_out = abs_out; }
 static inline float w3do_exp(float x) { return (g_exp_mode & 1) ? exp2f(x * 1.4426950408889634f) : expf(x); }
 /* the exponent of a (pixel, Gaussian) pair.  Probe bit 2: the same expression with the multiply-adds contracted into FMAs,
  * as a GPU compiler does by default (nvcc -fmad=true for the reference's CUDA build; this file itself is compiled with
@@ -415,6 +423,77 @@ void *w3do_forward(const W3DOView *v, int P, const float *means3D, const float *
     return s;
 }
 
+/* ---------------------------------------------------------------- attribution of differences (tests only)
+ * The blend is threshold-laden: a (pixel, Gaussian) pair is skipped when power > 0 or alpha < 1/255, and a pixel stops at
+ * the first entry that would take its transmittance below 1e-4.  A pair that sits ON one of these thresholds can fall on
+ * either side in another fp32 evaluation of the same formulas; when it does, that pixel's contributor set changes and with it
+ * the weights of every later entry (T is multiplied by 1 - alpha >= ... of the flipped entry) and the colour composited
+ * behind every earlier one — so every Gaussian blended at that pixel moves.
+ *
+ * w3do_fragile_pixels: out[pix] = 1 where the oracle's own walk of the pixel meets a pair with
+ *     |alpha * 255 - 1| <= eps,  or  |test_T / 1e-4 - 1| <= eps,  or  |power| <= eps (power within eps of the power > 0 skip).
+ * w3do_mark_contributors: flags[g] = 1 for every Gaussian that is BLENDED (applied) at a pixel with pixel_flags != 0. */
+void w3do_fragile_pixels(void *h, float eps, unsigned char *out) {
+    W3DOState *s = (W3DOState *)h;
+    const int H = s->H, W = s->W, gx = s->gx, T = s->gx * s->gy;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int t = 0; t < T; t++) {
+        int tx0 = (t % gx) * TILE, ty0 = (t / gx) * TILE;
+        uint32_t b = s->ranges[2 * t], e = s->ranges[2 * t + 1];
+        for (int py = ty0; py < ty0 + TILE && py < H; py++)
+            for (int px = tx0; px < tx0 + TILE && px < W; px++) {
+                float Tr = 1.0f, pxf = (float)px, pyf = (float)py;
+                unsigned char frag = 0;
+                for (uint32_t i = b; i < e; i++) {
+                    uint32_t g = s->point_list[i];
+                    float dx = s->xy[2 * (size_t)g] - pxf, dy = s->xy[2 * (size_t)g + 1] - pyf;
+                    const float *co = s->conic_op + 4 * (size_t)g;
+                    float power = w3do_power(co, dx, dy);
+                    if (fabsf(power) <= eps && co[3] >= 1.0f / 255.0f) frag = 1;
+                    if (power > 0.0f) continue;
+                    float alpha = fminf(0.99f, co[3] * w3do_exp(power));
+                    if (fabsf(alpha * 255.0f - 1.0f) <= eps) frag = 1;
+                    if (alpha < 1.0f / 255.0f) continue;
+                    float test_T = Tr * (1.f - alpha);
+                    if (fabsf(test_T * 10000.0f - 1.0f) <= eps) frag = 1;
+                    if (test_T < 0.0001f) break;
+                    Tr = test_T;
+                }
+                out[(size_t)py * W + px] = frag;
+            }
+    }
+}
+
+void w3do_mark_contributors(void *h, const unsigned char *pixel_flags, unsigned char *flags) {
+    W3DOState *s = (W3DOState *)h;
+    const int H = s->H, W = s->W, gx = s->gx, T = s->gx * s->gy;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int t = 0; t < T; t++) {
+        int tx0 = (t % gx) * TILE, ty0 = (t / gx) * TILE;
+        uint32_t b = s->ranges[2 * t];
+        for (int py = ty0; py < ty0 + TILE && py < H; py++)
+            for (int px = tx0; px < tx0 + TILE && px < W; px++) {
+                size_t pix = (size_t)py * W + px;
+                if (!pixel_flags[pix]) continue;
+                float pxf = (float)px, pyf = (float)py;
+                /* everything up to the last contributor that passes the skips is blended (the walk the backward makes);
+                 * entries behind it are marked too when they pass the skips: a termination flip would blend them */
+                uint32_t e = s->ranges[2 * t + 1];
+                for (uint32_t i = b; i < e; i++) {
+                    uint32_t g = s->point_list[i];
+                    float dx = s->xy[2 * (size_t)g] - pxf, dy = s->xy[2 * (size_t)g + 1] - pyf;
+                    const float *co = s->conic_op + 4 * (size_t)g;
+                    float power = w3do_power(co, dx, dy);
+                    if (power > 1e-3f) continue;
+                    float alpha = fminf(0.99f, co[3] * w3do_exp(power));
+                    if (alpha < 0.99f / 255.0f) continue;
+                    flags[g] = 1;           /* (benign race: every writer stores 1) */
+                    if (i - b >= s->n_contrib[pix] + 64u) break;   /* far behind the stop: cannot be reached by a flip */
+                }
+            }
+    }
+}
+
 long w3do_num_rendered(void *h) { return ((W3DOState *)h)->R; }
 void w3do_get_binning(void *h, uint32_t *ranges, uint32_t *point_list) {
     W3DOState *s = (W3DOState *)h;
@@ -524,6 +603,12 @@ void w3do_backward(void *h, const W3DOView *v, const float *means3D, const float
                     float dG_ddely = -gdy * co[2] - gdx * co[1];
                     ACC(0, dL_dG * dG_ddelx * ddelx_dx);
                     ACC(1, dL_dG * dG_ddely * ddely_dy);
+                    if (g_abs_out) {
+#pragma omp atomic
+                        g_abs_out[2 * (size_t)g] += (fabs((double)gdx * co[0]) + fabs((double)gdy * co[1])) * fabs((double)dL_dG) * ddelx_dx;
+#pragma omp atomic
+                        g_abs_out[2 * (size_t)g + 1] += (fabs((double)gdy * co[2]) + fabs((double)gdx * co[1])) * fabs((double)dL_dG) * ddely_dy;
+                    }
                     ACC(2, -0.5f * gdx * dx * dL_dG);
                     ACC(3, -0.5f * gdx * dy * dL_dG);
                     ACC(4, -0.5f * gdy * dy * dL_dG);

@@ -65,15 +65,11 @@ def test_plain_c_host_gets_the_same_bits_as_the_python_binding(tmp_path):
     s = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=tfx, tanfovy=tfy,
                                       bg=tod(bg), scale_modifier=1.0, viewmatrix=tod(cam.world_view_transform),
                                       projmatrix=tod(cam.full_proj_transform), sh_degree=3, campos=tod(cam.camera_center),
-                                      prefiltered=False, debug=False)
-    old = rasterizer.set_deterministic(True)
-    try:
-        color, radii, depth, alpha = GaussianRasterizer(raster_settings=s)(
-            means3D=t["means3D"], means2D=means2D, shs=t["shs"], colors_precomp=None, opacities=t["opacities"],
-            scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
-        (color * torch.as_tensor(dL, device=dev)).sum().backward()
-    finally:
-        rasterizer.set_deterministic(old)
+                                      prefiltered=False, debug=False, deterministic=True)
+    color, radii, depth, alpha = GaussianRasterizer(raster_settings=s)(
+        means3D=t["means3D"], means2D=means2D, shs=t["shs"], colors_precomp=None, opacities=t["opacities"],
+        scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+    (color * torch.as_tensor(dL, device=dev)).sum().backward()
     assert int(counts[0]) == int((radii > 0).sum()) and int(counts[1]) > 0
     eq = lambda a, b: np.array_equal(a.reshape(-1), b.detach().cpu().numpy().reshape(-1))  # noqa: E731
     assert eq(c["radii"], radii)

@@ -8,12 +8,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def deterministic():
-    from w3d_amd import rasterizer
-    old = rasterizer.set_deterministic(True)
-    yield
-    rasterizer.set_deterministic(old)
+# The switch is an attribute of the model (raw-parameter path) / a field of the settings tuple (drop-in module): there is no
+# process-wide mode.
+DET = dict(deterministic=True)
 
 
 def _setup(P=6000, W=208, H=160, seed=9, n_cams=4):
@@ -26,9 +23,10 @@ def _setup(P=6000, W=208, H=160, seed=9, n_cams=4):
     return dev, cams, make_scene(P, seed=seed, scale_mean=0.02)
 
 
-def _model(sc, dev):
+def _model(sc, dev, deterministic=False):
     from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
     m = GaussianModel(3, device=dev)
+    m.deterministic = deterministic
     m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
     m.active_sh_degree = 3
     opt = OptimizationParams()
@@ -49,18 +47,15 @@ def _raw_grads(m, cam, bg, dL, with_da=False):
 
 @pytest.mark.parametrize("with_da", [False, True])
 def test_deterministic_backward_matches_default_and_repeats_bit_for_bit(with_da):
-    from w3d_amd import rasterizer
     dev, cams, sc = _setup()
     bg = torch.tensor([0.1, 0.0, 0.2], device=dev)
     m, _ = _model(sc, dev)
     dL = torch.randn(3, 160, 208, generator=torch.Generator().manual_seed(3)).to(dev) * 1e-3
     ref, ref2d = _raw_grads(m, cams[1], bg, dL, with_da)
-    old = rasterizer.set_deterministic(True)
-    try:
-        a, a2d = _raw_grads(m, cams[1], bg, dL, with_da)
-        b, b2d = _raw_grads(m, cams[1], bg, dL, with_da)
-    finally:
-        rasterizer.set_deterministic(old)
+    m.deterministic = True
+    a, a2d = _raw_grads(m, cams[1], bg, dL, with_da)
+    b, b2d = _raw_grads(m, cams[1], bg, dL, with_da)
+    m.deterministic = False
     assert torch.equal(a, b) and torch.equal(a2d, b2d)
     assert float(ref.abs().max()) > 0
     for name, (lo, hi) in m.block_slices().items():
@@ -75,7 +70,7 @@ def test_deterministic_backward_matches_default_and_repeats_bit_for_bit(with_da)
     assert float(a[lo:hi].view(-1, 3)[~vis].abs().max()) == 0
 
 
-def test_deterministic_backward_through_the_dropin_module(deterministic):
+def test_deterministic_backward_through_the_dropin_module():
     from w3d_amd.gaussian_renderer import render
     import w3d_amd.gaussian_renderer as gr
     from w3d_amd.train import PipelineParams
@@ -85,7 +80,7 @@ def test_deterministic_backward_through_the_dropin_module(deterministic):
     for raw in (False, True, False, True):
         gr.RAW_AUTOGRAD = raw
         try:
-            m, _ = _model(sc, dev)
+            m, _ = _model(sc, dev, **DET)
             img = render(cams[0], m, PipelineParams(), bg)["render"]
             (img * torch.linspace(0, 1, img.numel(), device=dev).view_as(img)).sum().backward()
             res.append(torch.cat([p.grad.reshape(-1) for p in m._p.values()]))
@@ -96,7 +91,7 @@ def test_deterministic_backward_through_the_dropin_module(deterministic):
 
 def _train(sc, cams, bg, dev, steps, **kw):
     from w3d_amd.train import Trainer
-    m, opt = _model(sc, dev)
+    m, opt = _model(sc, dev, **DET)
     tr = Trainer(m, cams, opt, bg, densify=False, **kw)
     for k, v in kw.pop("attrs", {}).items():
         setattr(tr, k, v)
@@ -104,7 +99,7 @@ def _train(sc, cams, bg, dev, steps, **kw):
     return m, losses
 
 
-def test_k_steps_repeat_bit_for_bit(deterministic):
+def test_k_steps_repeat_bit_for_bit():
     dev, cams, sc = _setup(P=8000)
     bg = torch.tensor([0.2, 0.1, 0.0], device=dev)
     runs = []
@@ -117,7 +112,7 @@ def test_k_steps_repeat_bit_for_bit(deterministic):
     assert runs[0][4] == runs[1][4]
 
 
-def test_fused_adam_equals_backward_plus_sweep_without_escape_hatch(deterministic):
+def test_fused_adam_equals_backward_plus_sweep_without_escape_hatch():
     """In the atomic mode this comparison needs 'max diff <= 0.25' (a last-bit sign flip of a ~0 gradient becomes 2*lr under
     Adam).  With deterministic gradients the two optimizer placements see the SAME gradient bits."""
     from w3d_amd.train import Trainer
@@ -125,7 +120,7 @@ def test_fused_adam_equals_backward_plus_sweep_without_escape_hatch(deterministi
     bg = torch.tensor([0.0, 0.1, 0.2], device=dev)
     out = []
     for fused_adam in (False, True):
-        m, opt = _model(sc, dev)
+        m, opt = _model(sc, dev, **DET)
         tr = Trainer(m, cams, opt, bg, densify=False)
         tr.fused_adam = fused_adam
         for it in range(1, 5):

@@ -208,8 +208,11 @@ def oracle_view(P, cam_index, seed=0):
             try:
                 o = make_oracle(cam, bg, nthreads=NTHREADS)
                 ref = o.forward(**(d if mode == 0 else d_probe))
-                gref = o.backward(gc, None, None)
-                o.free()
+                gref = o.backward(gc, None, None, abs_sums=(mode == 0))
+                if mode == 0:       # kept alive: the attribution test asks it which Gaussians are blended at given pixels
+                    oracle0, final_T0 = o, o.pixel_state()[0]
+                else:
+                    o.free()
             finally:
                 COracle.set_exp_mode(0)
             runs.append((ref, gref, raw_grads_from_oracle(gref, sc)))
@@ -229,6 +232,7 @@ def oracle_view(P, cam_index, seed=0):
         n0 = np.linalg.norm(gref["means2D"][:, :2].astype(np.float64), axis=1)
         n1 = np.linalg.norm(gref1["means2D"][:, :2].astype(np.float64), axis=1)
         _cache[key] = dict(sc=sc, cam=cam, bg=bg, ref=ref, gc=gc, gref=gref, want=want, vis=vis, d=d, probe_same_inputs=probe_same_inputs,
+                           oracle=oracle0, final_T=final_T0,
                            probe=gradient_stats(want1, want, vis), probe_norm=densify_norm_error(n1, n0, vis),
                            probe_flips=flip_pixels(ref1, ref))
     return _cache[key]
@@ -411,3 +415,114 @@ def test_c4_flashsplat_counts_full_size(K):
     assert n_diff <= 1e-5 * la.size, f"{n_diff} of {la.size} labels differ"
     assert float(total.sum()) > 0
     _report(test="c4_flashsplat", K=K, P=P, views=n_views, worst_view_rel_err=worst_view, summed_rel_err=err, labels_differ=n_diff)
+
+
+# ------------------------------------------------------------------------------------------------ attribution
+def attributed_gradient_check(name, m, cam_dev, gc, ref, gref, want, final_T_ref, oracle, tag):
+    """north_star: "densification-grad norms within 1e-4".  The blend is threshold-laden, so two fp32 evaluations cannot agree
+    on EVERY (pixel, Gaussian) decision; instead of widening the bar, every difference is attributed:
+
+      1. pixels where the HIP forward and the oracle ended with a different contributor set are FOUND, not assumed: the
+         final transmittance differs by more than 0.1 % there (identical sets agree to ~1e-5; the smallest possible change of
+         a set — one entry at alpha = 1/255 — moves it by 0.39 %); every one of them must be a pixel where the oracle's own
+         walk meets a pair within 1e-3 (relative) of a threshold (w3do_fragile_pixels) — flips happen ON thresholds only;
+      2. the oracle marks every Gaussian blended at such a pixel (w3do_mark_contributors);
+      3. every Gaussian NOT marked must meet the north_star bar on ||dL/dmean2D|| — |own - ref| <= 1e-4 * ref, plus the fp32
+         summation allowance 16 * 2^-24 * sum|terms| of that Gaussian's own sum (oracle abs-sums; it matters only where the
+         terms cancel) — with NO exceptions, and on every parameter block at p99.9 <= 1e-4 / max <= 1e-3;
+      4. hence every Gaussian beyond the bar is one blended at a flipped pixel; their number is reported."""
+    from w3d_amd.fused_step import render_raw, backward_raw
+    from w3d_amd.rasterizer import debug_pixel_state
+    dev = cam_dev.world_view_transform.device
+    P = m.num_points
+    pkg = render_raw(cam_dev, m, torch.zeros(3, device=dev), sync=True)
+    gnorm, _ = backward_raw(m, pkg["handle"], torch.as_tensor(gc, device=dev), want_norm=True, want_means2D=True)
+    vis = check_radii_raw(pkg["radii"].cpu().numpy(), ref["radii"], tag)
+    T_own = debug_pixel_state(pkg["handle"])[0].cpu().numpy().astype(np.float64)
+    T_ref = final_T_ref.astype(np.float64)
+    flipped = np.abs(T_own - T_ref) > 1e-3 * T_ref
+    fragile = oracle.fragile_pixels(1e-3)
+    n_unexplained = int((flipped & ~fragile).sum())
+    marked = oracle.contributors_of(flipped)
+    # (3) the densification statistic
+    n_ref = np.linalg.norm(gref["means2D"][:, :2].astype(np.float64), axis=1)
+    n_own = gnorm.cpu().numpy().astype(np.float64)
+    cond_allow = 16.0 * 2.0 ** -24 * np.abs(gref["means2D_abs"]).sum(1)
+    has = vis & (n_ref > 0)
+    err = np.abs(n_own - n_ref)
+    beyond = has & (err > 1e-4 * n_ref)
+    beyond_allow = has & (err > 1e-4 * n_ref + cond_allow)
+    clean = has & ~marked
+    rel_clean = (err[clean] / n_ref[clean]) if clean.any() else np.zeros(1)
+    rec = dict(test="attributed", config=name, P=P, visible=int(vis.sum()), with_gradient=int(has.sum()),
+               flipped_pixels=int(flipped.sum()), fragile_pixels=int(fragile.sum()), flipped_not_fragile=n_unexplained,
+               marked_gaussians=int((marked & has).sum()), beyond_1e4=int(beyond.sum()), beyond_1e4_marked=int((beyond & marked).sum()),
+               beyond_1e4_unmarked=int((beyond & ~marked).sum()), beyond_with_allowance_unmarked=int((beyond_allow & ~marked).sum()),
+               clean_p999=float(np.percentile(rel_clean, 99.9)), clean_max=float(rel_clean.max()),
+               num_rendered=pkg["handle"]["num_rendered"])
+    got = {k: m.grad_view(k).detach().cpu().numpy() for k in want}
+    blocks = {}
+    for k, w in want.items():
+        e, nz, _ = per_gaussian_error(np.asarray(got[k]).reshape(w.shape), w)
+        c = e[nz & vis & ~marked]
+        blocks[k] = dict(n=int(c.size), p99=float(np.percentile(c, 99)), p999=float(np.percentile(c, 99.9)), max=float(c.max()),
+                         beyond_1e4=int((c > 1e-4).sum()), beyond_1e4_marked=int((e[nz & vis & marked] > 1e-4).sum()))
+    rec["blocks_unmarked"] = blocks
+    _report(**rec)
+    assert n_unexplained == 0, f"{tag}{n_unexplained} pixels changed their contributor set away from any threshold: {rec}"
+    assert flipped.mean() <= 1e-4, f"{tag}{int(flipped.sum())} flipped pixels"
+    assert int((beyond_allow & ~marked).sum()) == 0, \
+        f"{tag}{int((beyond_allow & ~marked).sum())} Gaussians beyond 1e-4 on the densification norm without a flipped pixel: {rec}"
+    for k, st in blocks.items():
+        assert st["p999"] <= 1e-4 and st["max"] <= 1e-3, f"{tag}grad {k} over the Gaussians without a flipped pixel: {st}"
+    return rec
+
+
+@pytest.mark.parametrize("P,cam_index,name", [(2_000_000, 0, "C3"), (500_000, 5, "C2")])
+def test_gradient_outliers_are_contributor_set_flips(P, cam_index, name):
+    dev = torch.device("cuda:0")
+    c = oracle_view(P, cam_index)
+    m = _model(c["sc"], dev)
+    attributed_gradient_check(name, m, c["cam"].to(dev), c["gc"], c["ref"], c["gref"], c["want"], c["final_T"], c["oracle"],
+                              f"[{name} attribution] ")
+
+
+def test_trained_scene_full_size_against_oracle():
+    """The C3 scene after 1500 training steps on the bench's ground truth (bench.py: trained_scene): opacities have dropped,
+    the lists are shorter and the per-tile walks 2-3x longer than on the untrained scene (whose walks mostly stop early) —
+    the regime a real run spends its time in.  Forward parity + the attributed gradient check of the trained model."""
+    import argparse
+    import bench
+    from w3d_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    args = argparse.Namespace(points=2_000_000, width=W, height=H, views=36)
+    bg = torch.zeros(3, device=dev)
+    sc0, m, opt, cams = bench.build_scene(args, dev)
+    bench.make_ground_truth(args, cams, dev, bg)
+    tr = Trainer(m, cams, opt, bg, densify=False)
+    assert tr.fused
+    for it in range(1, 1501):
+        tr.step(it)
+    torch.cuda.synchronize()
+    cam = cams[0]
+
+    class Snap:       # the trained parameters as a scene (what view_inputs / raw_grads_from_oracle read)
+        xyz, opacity = m._xyz.detach().cpu().clone(), m._opacity.detach().cpu().clone()
+        scaling, rotation = m._scaling.detach().cpu().clone(), m._rotation.detach().cpu().clone()
+        features_dc, features_rest = m._features_dc.detach().cpu().clone(), m._features_rest.detach().cpu().clone()
+    cam_cpu = make_cameras(36, W, H)[0]
+    d = np_inputs(view_inputs(Snap, cam_cpu))
+    gc = np.random.RandomState(3).randn(3, H, W).astype(np.float32)
+    o = make_oracle(cam_cpu, (0.0, 0.0, 0.0), nthreads=NTHREADS)
+    ref = o.forward(**d)
+    gref = o.backward(gc, None, None, abs_sums=True)
+    final_T = o.pixel_state()[0]
+    want = raw_grads_from_oracle(gref, Snap)
+    # forward parity of the trained model
+    from w3d_amd.fused_step import render_raw
+    pkg = render_raw(cam, m, bg, sync=True)
+    out = dict(color=pkg["render"].cpu().numpy(), depth=pkg["depth"].cpu().numpy(), alpha=pkg["alpha"].cpu().numpy())
+    img_stats = check_images_fullsize(out, ref, "[trained C3] ")
+    _report(test="trained_forward", images=img_stats, num_rendered=pkg["handle"]["num_rendered"], mean_alpha=float(ref["alpha"].mean()))
+    attributed_gradient_check("C3-trained", m, cam, gc, ref, gref, want, final_T, o, "[trained C3 attribution] ")
+    o.free()

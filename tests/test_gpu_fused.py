@@ -186,7 +186,7 @@ def test_speculative_list_capacity_overflow_is_repeated(fused_adam):
         fused_step.render_raw = counting
         try:
             for it in range(1, 5):
-                fused_step.list_capacity(dev, H, W).known = 100 if sabotage else 10_000_000      # far too small / generous
+                fused_step.list_capacity(m, H, W).known = 100 if sabotage else 10_000_000      # far too small / generous
                 tr.step(it)
         finally:
             fused_step.render_raw = orig
@@ -587,3 +587,56 @@ def test_raw_forward_with_ragged_point_counts(P):
     for k in ("render", "depth"):
         d = (raw[k] - ref[k]).abs() / max(1.0, float(ref[k].abs().max()))
         assert float((d > 2e-5).float().mean()) <= 2e-4 and float(d.max()) <= 5e-3, (k, float(d.max()))
+
+
+def test_two_views_in_one_backward_pass_add_up():
+    """A multi-view loss: two render() calls on the SAME model feed one loss.backward().  Both autograd nodes run before any
+    AccumulateGrad and both see .grad None; only the first may write the flat bucket directly, the other must hand autograd a
+    temporary — the parameters end up with the SUM of the two views' gradients (a second direct node would overwrite the
+    bucket and the engine would add the same views to themselves: twice the second view, the first lost), and the
+    reference's `optimizer.step()` then steps on that sum."""
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.gaussian_renderer import render
+    from w3d_amd.train import PipelineParams
+    dev = torch.device("cuda:0")
+    W, H = 176, 128
+    cams = [c.to(dev) for c in make_cameras(4, W, H)]
+    sc = make_scene(5000, seed=31, scale_mean=0.03)
+    bg = torch.tensor([0.1, 0.2, 0.0], device=dev)
+    g = torch.Generator().manual_seed(8)
+    wts = [torch.randn(3, H, W, generator=g).to(dev) for _ in range(2)]
+
+    def model():
+        m = GaussianModel(3, device=dev)
+        m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+        m.active_sh_degree = 3
+        m.deterministic = True              # (bit-reproducible gradients: the comparison below can be tight)
+        m.training_setup(OptimizationParams())
+        m.optimizer.zero_grad(set_to_none=True)
+        return m
+    singles = []
+    for v in range(2):
+        m = model()
+        (render(cams[v], m, PipelineParams(), bg)["render"] * wts[v]).sum().backward()
+        singles.append(torch.cat([p.grad.reshape(-1) for p in m._p.values()]).clone())
+        assert all(p.grad.data_ptr() == m.grad_view(n).data_ptr() for n, p in m._p.items())      # adopted without a copy
+    want = singles[0] + singles[1]
+    m = model()
+    loss = sum((render(cams[v], m, PipelineParams(), bg)["render"] * wts[v]).sum() for v in range(2))
+    loss.backward()
+    got = torch.cat([p.grad.reshape(-1) for p in m._p.values()])
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-6 * scale, float((got - want).abs().max()) / scale
+    assert float((got - 2 * singles[1]).abs().max()) > 1e-3 * scale       # (what the unguarded path produced)
+    # ... and the drop-in optimizer.step() uses that sum, wherever autograd left it
+    ref = model()
+    ref.flat_grad.copy_(want)
+    ref.optimizer.step(respect_none_grads=False)
+    m.optimizer.step()
+    assert float((m.flat - ref.flat).abs().max()) <= 1e-6
+    assert m.optimizer.steps == ref.optimizer.steps == {n: 1 for n in m.optimizer.steps}
+    # a fresh pass after zero_grad claims the bucket again
+    m.optimizer.zero_grad(set_to_none=True)
+    (render(cams[2], m, PipelineParams(), bg)["render"] * wts[0]).sum().backward()
+    assert all(p.grad.data_ptr() == m.grad_view(n).data_ptr() for n, p in m._p.items())

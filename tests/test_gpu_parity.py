@@ -23,13 +23,13 @@ from w3d_amd.synth import small_test_scene, make_scene, make_cameras
 pytestmark = pytest.mark.gpu
 
 
-def _settings(cam, bg, sh_degree, scale_modifier, dev, flash=None):
+def _settings(cam, bg, sh_degree, scale_modifier, dev, flash=None, tile_cull=True):
     from w3d_amd.rasterizer import GaussianRasterizationSettings, FlashSplatRasterizationSettings
     kw = dict(image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
               tanfovy=math.tan(cam.FoVy * 0.5), bg=torch.tensor(bg, dtype=torch.float32, device=dev),
               scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform.to(dev),
               projmatrix=cam.full_proj_transform.to(dev), sh_degree=sh_degree, campos=cam.camera_center.to(dev),
-              prefiltered=False, debug=False)
+              prefiltered=False, debug=False, tile_cull=tile_cull)
     if flash is None:
         return GaussianRasterizationSettings(**kw)
     return FlashSplatRasterizationSettings(**kw, mask_grad=False, num_obj=flash)
@@ -38,12 +38,10 @@ def _settings(cam, bg, sh_degree, scale_modifier, dev, flash=None):
 def run_hip(d, cam, bg, sh_degree=3, scale_modifier=1.0, grads=None, tile_cull=True):
     """forward (+ backward with the given image gradients) on cuda:0 through the drop-in module."""
     from diff_gaussian_rasterization import GaussianRasterizer
-    import w3d_amd.rasterizer as wr
-    wr.TILE_CULL = tile_cull
     dev = torch.device("cuda:0")
     t = {k: (None if v is None else v.to(dev).requires_grad_(True)) for k, v in d.items()}
     means2D = torch.zeros_like(t["means3D"], requires_grad=True)
-    rast = GaussianRasterizer(raster_settings=_settings(cam, bg, sh_degree, scale_modifier, dev))
+    rast = GaussianRasterizer(raster_settings=_settings(cam, bg, sh_degree, scale_modifier, dev, tile_cull=tile_cull))
     color, radii, depth, alpha = rast(means3D=t["means3D"], means2D=means2D, shs=t["shs"],
                                       colors_precomp=t["colors_precomp"], opacities=t["opacities"],
                                       scales=t["scales"], rotations=t["rotations"], cov3D_precomp=t["cov3D_precomp"])
@@ -270,8 +268,6 @@ def test_duplicate_gaussians_tie_order():
 @pytest.mark.parametrize("num_obj", [1, 5])
 def test_flashsplat_parity(num_obj):
     from flashsplat_rasterization import GaussianRasterizer
-    import w3d_amd.rasterizer as wr
-    wr.TILE_CULL = True
     dev = torch.device("cuda:0")
     P, W, H = 600, 96, 80
     sc, cams = small_test_scene(P=P, W=W, H=H, seed=21)

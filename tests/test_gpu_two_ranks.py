@@ -6,7 +6,11 @@ statistics reduction, the dense reduce-scatter + sharded Adam + parameter all-ga
 tensors.  Asserted for both exchange modes, across a densification:
   * the two replicas stay BIT-identical (parameters, both moments, statistics) although nothing re-synchronises them;
   * one step equals a single process stepping Adam on the mean of the two views' gradients.
-The same exchange on 8 real GPUs over RCCL is checked at run time by bench.py (`exchange.replicas_identical...`)."""
+
+test_rccl_ranks_* is the SAME test over RCCL itself: world 2 (and 4 / 8 where the box has them) rank processes, one GPU each,
+backend "nccl", NO shim — the in-place reduce-scatter / all-gather of the dense exchange and the chunked asynchronous
+colour-gradient all-gather + geometry all-reduce of the low-rank one run on the real links (config C5's exchange).  It
+skips on a box with fewer GPUs than ranks; bench.py's `exchange.selfcheck` repeats the replica check at benchmark size."""
 import os
 import socket
 import subprocess
@@ -35,7 +39,7 @@ def _scene_and_cams(dev):
     class Opt(OptimizationParams):
         densify_from_iter = 2
         densification_interval = 4
-        opacity_reset_interval = 1000
+        opacity_reset_interval = 6
         densify_until_iter = 100
         densify_grad_threshold = 0.00002
     opt = Opt()
@@ -74,22 +78,27 @@ def _install_host_staged_collectives():
     dist.all_reduce, dist.all_gather_into_tensor, dist.reduce_scatter_tensor = all_reduce, all_gather_into_tensor, reduce_scatter_tensor
 
 
-def worker(rank, world, port, mode, outdir):
+def worker(rank, world, port, mode, outdir, backend="gloo_staged"):
     for p in (ROOT, os.path.join(ROOT, "wheat-3dgs_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    _install_host_staged_collectives()
+    if backend == "nccl":               # one GPU per rank, RCCL over xGMI, the product's collectives as they are
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:                               # both ranks on the one GPU of the box: gloo + host-staged collectives
+        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        _install_host_staged_collectives()
     from w3d_amd.train import Trainer
-    dev = torch.device("cuda:0")
     m, opt, cams = _scene_and_cams(dev)
     tr = Trainer(m, cams, opt, torch.zeros(3, device=dev), densify=True, cameras_extent=2.0, exchange=mode)
-    assert tr.world == 2 and tr.rank == rank
+    assert tr.world == world and tr.rank == rank
     snaps = {}
-    for it in range(1, 8):              # densifies at iteration 4
+    for it in range(1, 8):              # densifies at iteration 4, resets the opacities at iteration 6
         tr.step(it)
         if it in (1, 7):
             tr.gather_moments()
@@ -101,27 +110,41 @@ def worker(rank, world, port, mode, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["lowrank", "dense"])
-def test_two_ranks_one_gpu_replicas_identical_and_equal_mean_gradient_step(mode, tmp_path):
-    import torch
+def _run_ranks(world, mode, backend, tmp_path):
+    """Start `world` rank processes as fresh children (nothing of this process's GPU state is inherited: they are new
+    interpreters, not forks) and return their snapshots."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "wheat-3dgs_amd"), os.path.join(ROOT, "tests")])
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(r), "2", str(port), mode, str(tmp_path)],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(r), str(world), str(port), mode,
+                               str(tmp_path), backend],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=900)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
-    a, b = (np.load(os.path.join(tmp_path, f"rank{r}_{mode}.npz")) for r in range(2))
-    for k in a.files:                    # replicas bit-identical, before and after the densification
-        assert np.array_equal(a[k], b[k]), f"{mode}: replicas differ in {k}"
+    return [np.load(os.path.join(tmp_path, f"rank{r}_{mode}.npz")) for r in range(world)]
+
+
+def _check_replicas_and_mean_gradient_step(snaps, world, mode):
+    import torch
+    a = snaps[0]
+    for r, b in enumerate(snaps[1:], 1):
+        for k in a.files:                # replicas bit-identical, before and after the densification and the opacity reset
+            assert np.array_equal(a[k], b[k]), f"{mode}: rank {r} differs from rank 0 in {k}"
     assert int(a["P_7"]) != P            # the schedule really densified
 
-    # single-process reference of step 1: Adam on the MEAN of the two views' gradients, statistics summed / maxed
+    # single-process reference of step 1: Adam on the MEAN of the ranks' views' gradients, statistics summed / maxed
     from w3d_amd.fused_step import backward_raw, render_raw
     from w3d_amd.fused import l1_ssim_fwd_bwd
     from w3d_amd.train import Trainer
@@ -135,8 +158,8 @@ def test_two_ranks_one_gpu_replicas_identical_and_equal_mean_gradient_step(mode,
     vcount = torch.zeros(P, device=dev)
     rmax = torch.zeros(P, device=dev)
     with torch.no_grad():
-        for r in range(2):
-            cam = cams[tr.perm[(0 * 2 + r) % n]]
+        for r in range(world):
+            cam = cams[tr.perm[(0 * world + r) % n]]
             pkg = render_raw(cam, m, tr.bg, sync=True)
             _, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
             gnorm, _ = backward_raw(m, pkg["handle"], dimg, want_norm=True)
@@ -144,9 +167,8 @@ def test_two_ranks_one_gpu_replicas_identical_and_equal_mean_gradient_step(mode,
             nsum += gnorm
             vcount += (pkg["radii"] > 0).float()
             rmax = torch.max(rmax, pkg["radii"].float())
-        m.flat_grad.copy_(total / 2)
-        m.optimizer.step()
-    b1, b2 = m.optimizer.betas
+        m.flat_grad.copy_(total / world)
+        m.optimizer.step(respect_none_grads=False)
     for blk, (lo, hi) in m.block_slices().items():
         ref_m = m.optimizer.exp_avg[lo:hi].cpu().numpy()
         err = np.abs(a["m_1"][lo:hi] - ref_m).max() / (np.abs(ref_m).max() + 1e-30)
@@ -162,5 +184,26 @@ def test_two_ranks_one_gpu_replicas_identical_and_equal_mean_gradient_step(mode,
     assert e <= 2e-4, f"{mode}: summed gradient norms rel err {e:.2e}"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["lowrank", "dense"])
+def test_two_ranks_one_gpu_replicas_identical_and_equal_mean_gradient_step(mode, tmp_path):
+    _check_replicas_and_mean_gradient_step(_run_ranks(2, mode, "gloo_staged", tmp_path), 2, mode)
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()        # (does not initialise the GPU)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["lowrank", "dense"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rccl_ranks_replicas_identical_and_equal_mean_gradient_step(world, mode, tmp_path):
+    """Config C5's exchange on the real links: `world` ranks, one GPU each, backend nccl (= RCCL), no shims."""
+    if _gpus() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {_gpus()}")
+    _check_replicas_and_mean_gradient_step(_run_ranks(world, mode, "nccl", tmp_path), world, mode)
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--worker":
-    worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6])
+    worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6], sys.argv[7] if len(sys.argv) > 7 else "gloo_staged")

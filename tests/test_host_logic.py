@@ -104,8 +104,8 @@ def test_densification_statistics_and_rebuild():
         kids = m._p["scaling"].detach()[lo + n_clone:]
         assert torch.allclose(kids[:n_split], before["scaling"][sel_split] - math.log(1.6), atol=1e-6)
     assert float(m.xyz_gradient_accum.abs().max()) == 0 and float(m.denom.abs().max()) == 0
-    for n, p in m._p.items():
-        assert p.grad is not None and p.grad.shape == p.shape and float(p.grad.abs().max()) == 0
+    # the rebuilt parameters are NEW nn.Parameters: .grad None (reference cat_tensors_to_optimizer / _prune_optimizer), bucket zeroed
+    assert all(p.grad is None for p in m._p.values()) and float(m.flat_grad.abs().max()) == 0
     # prune by opacity
     with torch.no_grad():
         m._p["opacity"][:5] = -20.0
@@ -378,3 +378,139 @@ def test_zero_grad_set_to_none_and_skip_rule():
     assert torch.equal(before, m.flat) and m.optimizer.step_count == 0
     m.optimizer.zero_grad(set_to_none=False)
     assert all(p.grad is not None and p.grad.data_ptr() == m.grad_view(n).data_ptr() for n, p in m._p.items())
+
+
+def _torch_adam_like_reference(m, opt):
+    """torch.optim.Adam over clones of the six parameters in training_setup's group order (scene/gaussian_model.py:172-182)."""
+    lrs = m._group_lrs(opt)
+    ref = {n: torch.nn.Parameter(m._p[n].detach().clone()) for n in m.optimizer.TORCH_GROUP_ORDER}
+    adam = torch.optim.Adam([{"params": [ref[n]], "lr": lrs[n], "name": n} for n in ref], lr=0.0, eps=1e-15)
+    return ref, adam
+
+
+def test_reference_loop_order_across_densify_and_opacity_reset():
+    """The reference's loop order is backward -> densify_and_prune / reset_opacity -> optimizer.step() -> zero_grad
+    (train_vanilla_3dgs.py:80-115).  Its densify and reset REPLACE nn.Parameters (.grad None), so torch.optim.Adam takes no
+    step on them in that iteration: after a densification nothing moves and no step counter advances; after an opacity
+    reset every block but opacity steps.  FlatAdam.step() — the drop-in's `optimizer.step()` — must do the same."""
+    torch.manual_seed(0)
+    m, _ = _model(P=60, seed=4)
+    opt = OptimizationParams()
+    m.training_setup(opt)
+    g = torch.Generator().manual_seed(5)
+
+    def backward_like():
+        for n, p in m._p.items():
+            p.grad = m.grad_view(n)
+            p.grad.copy_(torch.randn(p.shape, generator=g) * 1e-2)
+    # two ordinary iterations against torch.optim.Adam
+    ref, adam = _torch_adam_like_reference(m, opt)
+    for _ in range(2):
+        backward_like()
+        for n in ref:
+            ref[n].grad = m._p[n].grad.detach().clone()
+        adam.step()
+        m.optimizer.step()
+        m.optimizer.zero_grad(set_to_none=True)
+    for n in ref:
+        assert torch.allclose(ref[n].detach(), m._p[n].detach(), rtol=1e-6, atol=1e-8), n
+    assert m.optimizer.steps == {n: 2 for n in m.optimizer.steps}
+    # densification iteration
+    backward_like()
+    vs = torch.zeros(60, 3)
+    vs[:, 0] = 1e-3
+    m.add_densification_stats(vs, torch.ones(60, dtype=torch.bool))
+    m.densify_and_prune(opt.densify_grad_threshold, 0.005, 10.0, None)
+    assert m.num_points > 60 and all(p.grad is None for p in m._p.values())
+    before, mom = m.flat.clone(), m.optimizer.exp_avg.clone()
+    m.optimizer.step()
+    m.optimizer.zero_grad(set_to_none=True)
+    assert torch.equal(before, m.flat) and torch.equal(mom, m.optimizer.exp_avg)
+    assert m.optimizer.steps == {n: 2 for n in m.optimizer.steps}
+    # opacity-reset iteration: torch Adam with the opacity parameter replaced (grad None, zero moments, step kept)
+    ref, adam = _torch_adam_like_reference(m, opt)
+    adam.load_state_dict(m.optimizer.state_dict())
+    backward_like()
+    for n in ref:
+        ref[n].grad = m._p[n].grad.detach().clone()
+    m.reset_opacity()
+    assert m._p["opacity"].grad is None
+    with torch.no_grad():
+        ref["opacity"].copy_(m._p["opacity"].detach())
+    ref["opacity"].grad = None
+    adam.state[ref["opacity"]]["exp_avg"].zero_()
+    adam.state[ref["opacity"]]["exp_avg_sq"].zero_()
+    op_before = m._p["opacity"].detach().clone()
+    adam.step()
+    m.optimizer.step()
+    assert torch.equal(op_before, m._p["opacity"].detach())                    # not stepped with the stale gradient
+    a, b = m.block_slices()["opacity"]
+    assert float(m.optimizer.exp_avg[a:b].abs().max()) == 0
+    for n in ref:
+        assert torch.allclose(ref[n].detach(), m._p[n].detach(), rtol=1e-6, atol=1e-8), n
+    assert m.optimizer.steps["opacity"] == 2 and m.optimizer.steps["xyz"] == 3
+
+
+def test_step_takes_a_grad_that_is_not_the_bucket_view():
+    """autograd may leave a parameter's .grad in a tensor of its own (several contributions added out of place — a
+    multi-view loss): step() must use THAT gradient, not whatever the flat bucket holds."""
+    m, _ = _model(P=16, seed=6)
+    opt = OptimizationParams()
+    m.training_setup(opt)
+    ref, adam = _torch_adam_like_reference(m, opt)
+    g = torch.Generator().manual_seed(2)
+    m.flat_grad.fill_(123.0)                                  # stale bucket contents
+    for n, p in m._p.items():
+        p.grad = torch.randn(p.shape, generator=g)
+        ref[n].grad = p.grad.clone()
+    adam.step()
+    m.optimizer.step()
+    for n in ref:
+        assert torch.allclose(ref[n].detach(), m._p[n].detach(), rtol=1e-6, atol=1e-8), n
+        assert m._p[n].grad.data_ptr() == m.grad_view(n).data_ptr()
+
+
+def test_trainer_style_step_ignores_none_grads():
+    """The Trainer's fused / exchange paths write the flat bucket directly and never bind .grad: with
+    respect_none_grads=False every block not named in `skip` steps even after zero_grad(set_to_none=True)."""
+    m, _ = _model(P=12, seed=7)
+    m.training_setup(OptimizationParams())
+    m.optimizer.zero_grad(set_to_none=True)
+    m.flat_grad.fill_(1e-3)
+    before = m.flat.clone()
+    m.optimizer.step(skip={"opacity"}, respect_none_grads=False)
+    a, b = m.block_slices()["opacity"]
+    assert torch.equal(before[a:b], m.flat[a:b]) and not torch.equal(before, m.flat)
+    assert m.optimizer.steps["xyz"] == 1 and m.optimizer.steps["opacity"] == 0
+
+
+def test_settings_carry_the_optional_switches_behind_the_reference_fields():
+    from w3d_amd.rasterizer import GaussianRasterizationSettings, FlashSplatRasterizationSettings, list_capacity
+    s = GaussianRasterizationSettings(*range(12))
+    assert s._fields[:12] == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
+                              "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
+    assert s.tile_cull is True and s.deterministic is False
+    f = FlashSplatRasterizationSettings(*range(12))
+    assert f._fields[12:14] == ("mask_grad", "num_obj") and f.num_obj == 2 and f.tile_cull is True
+    # the list-length hint lives with the caller's object, not in the module
+    a, b = torch.zeros(3), torch.zeros(3)
+    list_capacity(a, 10, 20).observe(77)
+    assert list_capacity(a, 10, 20).known == 77 and list_capacity(b, 10, 20).known == 0 and list_capacity(a, 20, 10).known == 0
+    import w3d_amd.rasterizer as wr
+    assert not [n for n in vars(wr) if n.isupper() and n not in ("KNN_GRID_FROM",)]      # no module-level switches left
+
+
+def test_inplace_collective_aliasing_is_checked():
+    """The dense exchange runs RCCL's reduce-scatter / all-gather in place only in the one aliasing NCCL documents
+    (shard == full + rank * count); anything else falls back to a staged copy."""
+    from w3d_amd.train import nccl_inplace_shard
+    full = torch.zeros(1024)
+    for world in (1, 2, 4, 8):
+        n = 1024 // world
+        for rank in range(world):
+            sh = nccl_inplace_shard(full, rank * n, (rank + 1) * n, rank, world)
+            assert sh is not None and sh.data_ptr() == full.data_ptr() + 4 * rank * n and sh.numel() == n
+    assert nccl_inplace_shard(full, 0, 512, 1, 2) is None            # not this rank's slot
+    assert nccl_inplace_shard(full, 512, 1000, 1, 2) is None          # uneven shard
+    assert nccl_inplace_shard(full[::2], 0, 256, 0, 2) is None        # strided buffer
+    assert nccl_inplace_shard(full[:1000], 500, 1000, 1, 2) is not None

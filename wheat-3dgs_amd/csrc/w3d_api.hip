@@ -159,7 +159,7 @@ int w3d_forward_stage1(const w3d_view *view, int32_t P, const float *means3D, co
     }
     char *st = static_cast<char *>(state), *sc = static_cast<char *>(scratch);
     rc = w3d_launch_preprocess(L, *view, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii,
-                               st, sc, nullptr, stream);
+                               st, sc, nullptr, nullptr, stream);
     if (rc) return rc;
     rc = finish_stage1(L, *view, st, sc, counts_host, stream);
     return rc;
@@ -258,6 +258,11 @@ int w3d_backward(const w3d_view *view, int32_t P, const float *means3D, const fl
 // ---- raw-parameter path: activations + dc/rest split fused into the kernels
 int w3d_forward_stage1_raw(const w3d_view *view, int32_t P, const w3d_raw_params *prm, int32_t *radii, void *state,
                            void *scratch, uint32_t *counts_host, w3d_stream_t stream_) {
+    return w3d_forward_stage1_raw_subset(view, P, prm, nullptr, radii, state, scratch, counts_host, stream_);
+}
+
+int w3d_forward_stage1_raw_subset(const w3d_view *view, int32_t P, const w3d_raw_params *prm, const uint8_t *used_mask,
+                                  int32_t *radii, void *state, void *scratch, uint32_t *counts_host, w3d_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     int rc = check_view(view);
     if (rc) return rc;
@@ -278,7 +283,7 @@ int w3d_forward_stage1_raw(const w3d_view *view, int32_t P, const w3d_raw_params
     char *st = static_cast<char *>(state), *sc = static_cast<char *>(scratch);
     rc = w3d_launch_preprocess(L, *view, prm ? prm->xyz : nullptr, prm ? prm->f_dc : nullptr, nullptr,
                                prm ? prm->opacity : nullptr, prm ? prm->scaling : nullptr, prm ? prm->rotation : nullptr,
-                               nullptr, radii, st, sc, prm ? prm->f_rest : nullptr, stream);
+                               nullptr, radii, st, sc, prm ? prm->f_rest : nullptr, used_mask, stream);
     if (rc) return rc;
     return finish_stage1(L, *view, st, sc, counts_host, stream);
 }
@@ -442,7 +447,7 @@ int w3d_knn_dist2_grid(int32_t N, const float *points, float *out, void *scratch
 }
 
 int w3d_mask_binarize(int32_t H, int32_t W, int32_t C, const uint8_t *pixels, float *out, w3d_stream_t stream_) {
-    if (H <= 0 || W <= 0 || (C != 1 && C != 3 && C != 4) || !pixels || !out) { w3d_set_error("mask_binarize: bad arguments"); return W3D_ERR_INVALID; }
+    if (H <= 0 || W <= 0 || (C != 1 && C != 3) || !pixels || !out) { w3d_set_error("mask_binarize: bad arguments"); return W3D_ERR_INVALID; }
     return w3d_launch_mask_binarize(H, W, C, pixels, out, reinterpret_cast<hipStream_t>(stream_));
 }
 

@@ -164,7 +164,7 @@ __device__ __forceinline__ void w3d_adam1(float &p, float g, float &m, float &v,
 int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,
                           const float *colors_precomp, const float *opacities, const float *scales,
                           const float *rotations, const float *cov3D_precomp, int32_t *radii, char *state,
-                          char *scratch, const float *f_rest_raw, hipStream_t stream);
+                          char *scratch, const float *f_rest_raw, const uint8_t *used_mask, hipStream_t stream);
 int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream);
 int w3d_launch_tile_count(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream);
 int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, uint32_t *point_list,

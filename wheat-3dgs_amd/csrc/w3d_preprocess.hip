@@ -256,7 +256,7 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
                       int32_t *__restrict__ radii, float2 *__restrict__ xy, float4 *__restrict__ conic_op,
                       float4 *__restrict__ rgbd, ushort4 *__restrict__ rect, uint8_t *__restrict__ clamped_out,
                       uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ counters,
-                      uint4 *__restrict__ tile_mask) {
+                      uint4 *__restrict__ tile_mask, const uint8_t *__restrict__ used_mask) {
 #pragma clang fp contract(off)
     // f_rest rows of one wave's 64 Gaussians (64 x 180 B, contiguous in memory) on their way to the lanes
     __shared__ float4 s_sh[RAW ? 4 : 1][RAW ? W3D_SH_CHUNKS : 1];
@@ -275,7 +275,10 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
                       (reinterpret_cast<uintptr_t>(f_rest) & 15) == 0;
     float s_in[3] = {0.f, 0.f, 0.f};
     float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
-    if (valid) {
+    // subset render (flashsplat_render(used_mask=...), reference gaussian_renderer/__init__.py:151-156): a Gaussian the
+    // caller's byte mask leaves out is culled before any of its parameters is requested
+    const bool used = valid && (!used_mask || used_mask[g] != 0);
+    if (used) {
         p[0] = means3D[3 * (size_t)g]; p[1] = means3D[3 * (size_t)g + 1]; p[2] = means3D[3 * (size_t)g + 2];
         // scale, rotation and opacity are requested together with the position (one memory latency instead of three
         // dependent ones; 32 B per Gaussian that the culled ones would not have needed)
@@ -287,7 +290,7 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
         if (coop) { dc[0] = shs[3 * (size_t)g]; dc[1] = shs[3 * (size_t)g + 1]; dc[2] = shs[3 * (size_t)g + 2]; }
     }
     do {
-        if (!valid) break;
+        if (!used) break;
         float pv[3];
         xform4x3(cam.V, p, pv);
         if (!(pv[2] > W3D_NEAR)) break;   // near cull (also rejects NaN depth)
@@ -932,7 +935,7 @@ int w3d_launch_sh_adam_lowrank(int32_t P, int32_t nviews, int32_t sh_degree, con
 int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,
                           const float *colors_precomp, const float *opacities, const float *scales,
                           const float *rotations, const float *cov3D_precomp, int32_t *radii, char *state,
-                          char *scratch, const float *f_rest_raw, hipStream_t stream) {
+                          char *scratch, const float *f_rest_raw, const uint8_t *used_mask, hipStream_t stream) {
     // counters: [0] is written by the depth sort's last pass, [1] by the tile scan
     if (L.P == 0) {
         W3D_HIP_CHECK(hipMemsetAsync(state + L.o_counters, 0, 64, stream));
@@ -946,7 +949,7 @@ int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *me
         reinterpret_cast<float4 *>(state + L.o_rgbd), reinterpret_cast<ushort4 *>(state + L.o_rect),                 \
         reinterpret_cast<uint8_t *>(state + L.o_clamped), reinterpret_cast<uint32_t *>(scratch + L.s_keys0),         \
         reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(state + L.o_counters),       \
-        reinterpret_cast<uint4 *>(state + L.o_tile_mask)
+        reinterpret_cast<uint4 *>(state + L.o_tile_mask), used_mask
     if (f_rest_raw) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(grid), dim3(block), 0, stream, ARGS);
     else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(grid), dim3(block), 0, stream, ARGS);
 #undef ARGS

@@ -32,6 +32,8 @@ class W3DDensifyStats(ctypes.Structure):
 
 lib.w3d_forward_stage1_raw.argtypes = [ctypes.POINTER(W3DView), _i32, ctypes.POINTER(W3DRawParams), _vp, _vp, _vp, _vp, _vp]
 lib.w3d_forward_stage1_raw.restype = ctypes.c_int
+lib.w3d_forward_stage1_raw_subset.argtypes = [ctypes.POINTER(W3DView), _i32, ctypes.POINTER(W3DRawParams), _vp, _vp, _vp, _vp, _vp, _vp]
+lib.w3d_forward_stage1_raw_subset.restype = ctypes.c_int
 lib.w3d_backward_raw.argtypes = [ctypes.POINTER(W3DView), _i32, ctypes.POINTER(W3DRawParams), _vp, _vp, _vp, _vp, _vp,
                                  ctypes.POINTER(W3DRawGrads), ctypes.POINTER(W3DDensifyStats), _vp, _vp]
 lib.w3d_backward_raw.restype = ctypes.c_int
@@ -81,10 +83,14 @@ def finish(handle):
     return handle["num_rendered"] <= handle["capacity"]
 
 
-def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, flash=None):
+def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, flash=None, used_mask=None):
     """Forward on the raw parameters.  Returns the dict of render() (minus viewspace_points) plus a
     `handle` for backward_raw().  sync=False: no host synchronisation (rasterizer.ListCapacity); the caller
-    must call finish(handle) before trusting the outputs, and repeat the view when it returns False."""
+    must call finish(handle) before trusting the outputs, and repeat the view when it returns False.
+    used_mask: (P,) bool — only these Gaussians are rendered (flashsplat_render(used_mask=...), reference
+    gaussian_renderer/__init__.py:151-156,168-170,186-187); the others are culled inside the preprocess kernel, so no
+    subset of the parameter blocks is gathered.  Per-Gaussian outputs keep P rows (zeros on the rows left out).
+    The model's `tile_cull` / `deterministic` attributes select the two optional behaviours (rasterizer.py header)."""
     dev = model.flat.device
     if not model.flat.is_cuda:
         raise RuntimeError("the fused step needs the model on the GPU; there is no CPU path")
@@ -92,9 +98,15 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, flash=None
     H, W = int(cam.image_height), int(cam.image_width)
     s = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg_color,
                                       scaling_modifier, cam.world_view_transform, cam.full_proj_transform,
-                                      model.active_sh_degree, cam.camera_center, False, False)
+                                      model.active_sh_degree, cam.camera_center, False, False,
+                                      bool(getattr(model, "tile_cull", True)), bool(getattr(model, "deterministic", False)))
     view = _View(s, (model.max_sh_degree + 1) ** 2, dev)
     prm = _raw_params(model)
+    um = None
+    if used_mask is not None:
+        if used_mask.dtype != torch.bool or used_mask.dim() != 1 or used_mask.shape[0] != P or used_mask.device != dev:
+            raise RuntimeError("used_mask must be a (num_points,) bool tensor on the model's device")
+        um = used_mask.contiguous()
     with torch.cuda.device(dev):
         stream = stream_ptr(dev)
         sb, tb = ctypes.c_uint64(), ctypes.c_uint64()
@@ -102,18 +114,19 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, flash=None
         state = torch.empty(sb.value, dtype=torch.uint8, device=dev)
         scratch = torch.empty(tb.value, dtype=torch.uint8, device=dev)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
-        cap = list_capacity(dev, H, W)
+        # (a subset render says nothing about the list length of a full one, and vice versa: separate hints)
+        cap = list_capacity(model if um is None else used_mask, H, W)
         guess = 0 if sync else cap.guess()
         pending = None
         if guess == 0:
             counts = (ctypes.c_uint32 * 2)()
-            check(lib.w3d_forward_stage1_raw(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(radii), ptr(state),
-                                             ptr(scratch), ctypes.cast(counts, _vp), stream))
+            check(lib.w3d_forward_stage1_raw_subset(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(um), ptr(radii),
+                                                    ptr(state), ptr(scratch), ctypes.cast(counts, _vp), stream))
             R, V = int(counts[1]), int(counts[0])
             cap.observe(R)
         else:
-            check(lib.w3d_forward_stage1_raw(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(radii), ptr(state),
-                                             ptr(scratch), None, stream))
+            check(lib.w3d_forward_stage1_raw_subset(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(um), ptr(radii),
+                                                    ptr(state), ptr(scratch), None, stream))
             R, V = guess, -1
             # the counters start their way to pinned host memory right after stage 1, BEFORE stage 2 is enqueued:
             # whoever waits for them (finish()) is released while the GPU is still busy with stage 2
@@ -221,7 +234,12 @@ class _RasterizeRawFn(torch.autograd.Function):
         f32 = lambda t: None if t is None else t.to(torch.float32).contiguous()  # noqa: E731
         # The kernel OVERWRITES its gradient buffers.  Straight into the bucket only when no gradient is being
         # accumulated there (every .grad None); otherwise into a temporary that autograd adds to the existing .grad.
-        direct = all(p.grad is None for p in model._p.values())
+        # And only ONCE per backward pass: two render() calls on one model feeding one loss.backward() (a multi-view loss)
+        # both see .grad None — their nodes run before any AccumulateGrad — so the first claims the bucket and every
+        # later node writes a temporary that the engine adds (zero_grad / step release the claim).
+        direct = not getattr(model, "_bucket_claimed", False) and all(p.grad is None for p in model._p.values())
+        if direct:
+            model._bucket_claimed = True
         into = None if direct else torch.empty_like(model.flat_grad)
         _, m2d = backward_raw(model, handle, f32(g_color), f32(g_depth), f32(g_alpha), want_means2D=True, into=into)
         ctx.handle = None

@@ -87,6 +87,10 @@ class GaussianModel:
         self.denom = torch.empty(0, device=self.device)
         self._which_object = torch.empty(0, device=self.device)
         self.optimizer = None
+        # optional behaviours of the raw-parameter rasterizer path (fused_step.render_raw reads them; rasterizer.py header)
+        self.tile_cull = True           # exact footprint culling of tile instances (identical outputs, shorter lists)
+        self.deterministic = False      # deterministic blend backward (bit-identical gradients run to run)
+        self._bucket_claimed = False    # a backward node of this pass already writes the flat gradient bucket directly
         self.percent_dense = 0.0
         self.spatial_lr_scale = 1.0
         self._train_args = None
@@ -253,7 +257,13 @@ class GaussianModel:
             self.xyz_gradient_accum[update_filter] += torch.norm(g[update_filter, :2], dim=-1, keepdim=True)
             self.denom[update_filter] += 1
             return
-        if g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.dim() == 2 and g.shape[1] == 3 and \
+        P = self.num_points
+        if g.dim() != 2 or g.shape[0] != P or update_filter.numel() != P:
+            raise RuntimeError(f"add_densification_stats: gradient {tuple(g.shape)} / filter {tuple(update_filter.shape)} "
+                               f"do not match the model's {P} points")
+        if g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.shape[1] == 3 and \
+                update_filter.is_cuda and update_filter.device == g.device and self.xyz_gradient_accum.device == g.device and \
+                self.xyz_gradient_accum.shape[0] == P and self.denom.shape[0] == P and \
                 self.xyz_gradient_accum.is_contiguous() and self.denom.is_contiguous():
             from .fused import add_densification_stats
             add_densification_stats(g, update_filter.reshape(-1).contiguous(), self.xyz_gradient_accum, self.denom)
@@ -264,17 +274,19 @@ class GaussianModel:
         self.denom += f
 
     def _bind_store(self, flat_store, flat_grad_store, P):
-        """Adopt already-filled flat buffers (layout of _bind) without copying."""
+        """Adopt already-filled flat buffers (layout of _bind) without copying.  The new nn.Parameters start with
+        .grad None, as the reference's replaced parameters do (scene/gaussian_model.py:340-397 builds new nn.Parameters
+        in _prune_optimizer / cat_tensors_to_optimizer): the `optimizer.step()` that follows a densification in the
+        reference's loop (train_vanilla_3dgs.py:105-115) therefore skips them, and so does FlatAdam.step()."""
         n = P * FLOATS_PER_GAUSSIAN
         self.flat_store, self.flat_grad_store = flat_store, flat_grad_store
         self.flat, self.flat_grad = flat_store[:n], flat_grad_store[:n]
         self._p = {}
+        self._bucket_claimed = False
         off = 0
         for name, shape in BLOCKS:
             k = P * int(np.prod(shape))
-            p = nn.Parameter(self.flat[off:off + k].view(P, *shape), requires_grad=True)
-            p.grad = self.flat_grad[off:off + k].view(P, *shape)
-            self._p[name] = p
+            self._p[name] = nn.Parameter(self.flat[off:off + k].view(P, *shape), requires_grad=True)
             off += k
 
     def _compact(self, src, n_keep, n_child0=None, child_xyz=None, child_scaling=None, reset_stats=True):
@@ -417,6 +429,11 @@ class GaussianModel:
         new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))
         with torch.no_grad():
             self._p["opacity"].copy_(new)
+        # reference :305-318 replace_tensor_to_optimizer: a NEW nn.Parameter with zeroed moments — its .grad is None, so the
+        # optimizer.step() of the same iteration does not touch the opacities (and the stale pre-reset gradient is dropped)
+        self._p["opacity"].grad = None
+        a, b = self.block_slices()["opacity"]
+        self.flat_grad[a:b].zero_()
         self.optimizer.zero_moments("opacity")
 
     # ------------------------------------------------------------------ PLY snapshots (gaussian_model.py:196-293)

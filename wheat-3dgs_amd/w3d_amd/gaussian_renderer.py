@@ -22,7 +22,8 @@ def _settings(cls, cam, pc, bg_color, scaling_modifier, debug, **extra):
                tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color,
                scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform,
                projmatrix=cam.full_proj_transform, sh_degree=pc.active_sh_degree, campos=cam.camera_center,
-               prefiltered=False, debug=debug, **extra)
+               prefiltered=False, debug=debug, tile_cull=bool(getattr(pc, "tile_cull", True)),
+               deterministic=bool(getattr(pc, "deterministic", False)), **extra)
 
 
 # render() on this package's flat GaussianModel hands the PRE-ACTIVATION parameter blocks to the kernels (one autograd
@@ -72,18 +73,44 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
             "radii": radii, "depth": rendered_depth, "alpha": rendered_alpha}
 
 
+def _subset_rows(used_mask):
+    """Row indices a boolean mask selects (what `t[used_mask]` gathers), computed ONCE per mask: run_3d_seg.py hands the
+    same obj_used_mask tensor to ~30 views in a row (:130-134, :362), and every boolean-mask index would pay a nonzero +
+    host sync of its own.  Kept on the mask tensor itself together with its version counter, so an in-place change of the
+    mask is noticed and nothing outlives the mask."""
+    c = getattr(used_mask, "_w3d_rows", None)
+    if c is None or c[0] != used_mask._version:
+        c = (used_mask._version, used_mask.nonzero(as_tuple=True)[0])
+        used_mask._w3d_rows = c
+    return c[1]
+
+
 def flashsplat_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, gt_mask=None,
                       used_mask=None, unique_label=None, setpdb=False, obj_num=2):
     xyz = pc.get_xyz
-    if (not torch.is_grad_enabled() and used_mask is None and override_color is None and hasattr(pc, "flat") and
-            pc.flat.is_cuda and not pipe.compute_cov3D_python and not pipe.convert_SHs_python and pc.max_sh_degree == 3):
+    subset = used_mask is not None
+    if (not torch.is_grad_enabled() and override_color is None and hasattr(pc, "flat") and pc.flat.is_cuda and
+            (not subset or (isinstance(used_mask, torch.Tensor) and used_mask.dtype == torch.bool and used_mask.dim() == 1
+                            and used_mask.shape[0] == xyz.shape[0] and used_mask.device == xyz.device)) and
+            not pipe.compute_cov3D_python and not pipe.convert_SHs_python and pc.max_sh_degree == 3):
         # every call site of the reference runs under no_grad (run_3d_seg.py:91,130,362): take the raw-parameter forward —
-        # no exp / sigmoid / normalize launches and no cat of the (P,16,3) features (0.77 GB of traffic at 2 M) per view
-        from .fused_step import render_raw
-        r = render_raw(viewpoint_camera, pc, bg_color, scaling_modifier, flash=dict(gt_mask=gt_mask, num_obj=obj_num))
-        return {"render": r["render"], "viewspace_points": torch.zeros_like(xyz), "visibility_filter": r["radii"] > 0,
-                "radii": r["radii"], "alpha": r["alpha"], "depth": r["depth"], "contrib_num": r["contrib_num"],
-                "used_count": r["used_count"], "proj_xy": r["proj_xy"], "gs_depth": r["gs_depth"]}
+        # no exp / sigmoid / normalize launches and no cat of the (P,16,3) features (0.77 GB of traffic at 2 M) per view.
+        # used_mask (find_match / the refine rounds, ~30 views per object mask): the mask goes INTO the preprocess kernel as a
+        # cull, instead of four boolean-index gathers of the activated parameter blocks; the per-Gaussian outputs are then
+        # gathered to the reference's subset indexing (rows = used_mask.nonzero()) with the cached row list.
+        from .fused_step import finish, render_raw
+        flash = dict(gt_mask=gt_mask, num_obj=obj_num)
+        r = render_raw(viewpoint_camera, pc, bg_color, scaling_modifier, sync=not subset, flash=flash, used_mask=used_mask)
+        if subset and not finish(r["handle"]):          # speculative list size was too small: once more, exact
+            r = render_raw(viewpoint_camera, pc, bg_color, scaling_modifier, sync=True, flash=flash, used_mask=used_mask)
+        radii, used_count, proj_xy, gs_depth = r["radii"], r["used_count"], r["proj_xy"], r["gs_depth"]
+        if subset:
+            rows = _subset_rows(used_mask)
+            radii, used_count = radii.index_select(0, rows), used_count.index_select(1, rows)
+            proj_xy, gs_depth = proj_xy.index_select(0, rows), gs_depth.index_select(0, rows)
+        return {"render": r["render"], "viewspace_points": torch.zeros_like(xyz), "visibility_filter": radii > 0,
+                "radii": radii, "alpha": r["alpha"], "depth": r["depth"], "contrib_num": r["contrib_num"],
+                "used_count": used_count, "proj_xy": proj_xy, "gs_depth": gs_depth}
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
         screenspace_points.retain_grad()

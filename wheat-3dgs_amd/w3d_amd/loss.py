@@ -8,14 +8,17 @@ dL/dimage directly, replacing five grouped 11x11 convolutions forward plus their
 backward.
 """
 import math
+import threading
+import weakref
 
 import torch
 import torch.nn.functional as F
 
 
 def _fusable(img1, img2):
-    return (img1.is_cuda and img1.dim() == 3 and img1.dtype == torch.float32 and img2.dtype == torch.float32 and
-            img1.shape == img2.shape and img1.is_contiguous() and img2.is_contiguous() and not img2.requires_grad)
+    return (img1.is_cuda and img2.is_cuda and img1.device == img2.device and img1.dim() == 3 and
+            img1.dtype == torch.float32 and img2.dtype == torch.float32 and img1.shape == img2.shape and
+            img1.is_contiguous() and img2.is_contiguous() and not img2.requires_grad)
 
 
 class _FusedLossPair(torch.autograd.Function):
@@ -43,22 +46,26 @@ class _FusedLossPair(torch.autograd.Function):
         return l1_ssim_grad(img1, img2, g_l1, g_ssim, ctx.scratch), None
 
 
-_pending = None     # (img1, img1._version, img2, img2._version, ssim value) of the last fused l1_loss() call
+# The SSIM value of the last fused l1_loss() call, waiting for the ssim() call on the same two images that follows it in the
+# reference's loss lines.  Per host thread; the images are held through weak references (only the SSIM scalar — whose
+# autograd node the L1 value shares anyway — is kept alive), and every l1_loss() / ssim() call clears or replaces it, so at
+# most one step's loss graph is ever held.
+_tls = threading.local()
 
 
 def l1_loss(network_output, gt):
-    global _pending
+    _tls.pending = None
     if torch.is_grad_enabled() and network_output.requires_grad and _fusable(network_output, gt):
         l1, s = _FusedLossPair.apply(network_output, gt)
-        _pending = (network_output, network_output._version, gt, gt._version, s)
+        _tls.pending = (weakref.ref(network_output), network_output._version, weakref.ref(gt), gt._version, s)
         return l1
     return torch.abs(network_output - gt).mean()
 
 
 def _take_pending(img1, img2):
-    global _pending
-    p, _pending = _pending, None
-    if p is not None and p[0] is img1 and p[1] == img1._version and p[2] is img2 and p[3] == img2._version:
+    p = getattr(_tls, "pending", None)
+    _tls.pending = None
+    if p is not None and p[0]() is img1 and p[1] == img1._version and p[2]() is img2 and p[3] == img2._version:
         return p[4]
     return None
 
@@ -88,10 +95,12 @@ def gaussian_window_1d(window_size=11, sigma=1.5):
 
 
 def ssim(img1, img2, window_size=11, size_average=True):
-    if img1.is_cuda and img1.dim() == 3 and window_size == 11 and size_average and not img2.requires_grad:
-        s = _take_pending(img1, img2)        # the l1_loss() call just before this one already ran pass A on these images
-        if s is not None:
-            return s
+    s = _take_pending(img1, img2) if window_size == 11 and size_average else None
+    if s is not None:
+        return s
+    # (a ground truth on another device, a half-precision or strided image: the torch formula — a raw host pointer must
+    #  never reach the kernel)
+    if _fusable(img1, img2) and window_size == 11 and size_average:
         return _FusedSSIM.apply(img1, img2)
     return ssim_torch(img1, img2, window_size, size_average)
 

@@ -77,6 +77,7 @@ class FlatAdam:
         .grad become None, so the next autograd backward hands its gradient tensors over without an accumulation pass
         (rasterizer backward writes them straight into the flat bucket and returns views of it).  set_to_none=False
         zeroes the bucket in place and keeps the views."""
+        self.model._bucket_claimed = False
         if set_to_none:
             for p in self.model._p.values():
                 p.grad = None
@@ -139,22 +140,36 @@ class FlatAdam:
         return 1.0 - b1 ** t, 1.0 - b2 ** t
 
     @torch.no_grad()
-    def step(self, zero_grad=False, skip=(), elem_range=None, only=None, advance=True):
+    def step(self, zero_grad=False, skip=(), elem_range=None, only=None, advance=True, respect_none_grads=True):
         """One Adam step on every block.  zero_grad=True clears the gradient bucket in the same
         sweep (what `optimizer.zero_grad(set_to_none=True)` achieves at train_vanilla_3dgs.py:115).
-        A block in `skip`, or whose parameter has .grad None (torch.optim.Adam's rule), is left alone and its step
-        counter does not advance.
+        A block in `skip` is left alone and its step counter does not advance.
+        respect_none_grads=True (the default — what the reference's `optimizer.step()` line gets): torch.optim.Adam's
+        rule, a block whose parameter has .grad None is skipped like one in `skip` (the reference's densify / opacity
+        reset REPLACE their nn.Parameters before the step, scene/gaussian_model.py:305-318,340-397, so those take no
+        step in that iteration), and a .grad that is not the block's own view of the flat bucket (autograd accumulated
+        several contributions out of place) is copied into the bucket first.  The Trainer's fused / exchange paths write
+        the bucket directly and never touch .grad: they pass respect_none_grads=False and name their skips explicitly.
         elem_range=(lo, hi): only that slice of the flat buffer is stepped — the shard this rank owns in
         the dense view-parallel exchange (the other shards arrive through the parameter all-gather).
         only=names: step just these blocks; advance=False: the step counters were already advanced for this
         iteration (the low-rank exchange steps the geometry blocks and the SH blocks separately)."""
         b1, b2 = self.betas
-        p, g, m, v = self.model.flat, self.model.flat_grad, self.exp_avg, self.exp_avg_sq
+        model = self.model
+        model._bucket_claimed = False
+        p, g, m, v = model.flat, model.flat_grad, self.exp_avg, self.exp_avg_sq
         slices = {}
-        for name, (a, b) in self.model.block_slices().items():
+        for name, (a, b) in model.block_slices().items():
             if only is not None and name not in only:
                 continue
-            stepped = name not in skip and self.model._p[name].grad is not None
+            stepped = name not in skip
+            if stepped and respect_none_grads:
+                pg = model._p[name].grad
+                if pg is None:
+                    stepped = False
+                elif pg.data_ptr() != g[a:b].data_ptr() or not pg.is_contiguous():
+                    g[a:b].copy_(pg.reshape(-1))
+                    model._p[name].grad = g[a:b].view(model._p[name].shape)
             if stepped and advance:
                 self.steps[name] += 1          # (the counter follows the block, not the shard this rank sweeps)
             if elem_range is not None:

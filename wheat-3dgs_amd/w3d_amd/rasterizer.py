@@ -16,10 +16,16 @@ from . import _lib
 from ._lib import W3DView, check, lib, ptr, stream_ptr
 
 
-# Exact footprint culling of tile instances (w3d_view.tile_cull): outputs are unchanged, the per-tile
-# lists are about 40 % shorter.  Set False to get the published bounding-square lists, e.g. to compare
-# them entry by entry with another implementation (tests/test_gpu_parity.py does).
-TILE_CULL = True
+# This module keeps NO mutable state (two rasterizers are constructed per process).  The two
+# behaviour switches travel in the settings tuple, behind the reference's own fields and with the reference's behaviour as
+# default, so a call site that builds the tuple by keyword (gaussian_renderer/__init__.py:40-53) is unaffected:
+#   tile_cull      exact footprint culling of tile instances (w3d_view.tile_cull): outputs unchanged, per-tile lists ~40 %
+#                  shorter.  False gives the published bounding-square lists, comparable entry by entry with another
+#                  implementation (tests/test_gpu_parity.py relies on that).
+#   deterministic  w3d_view.deterministic: the blend backward stores every (tile, Gaussian) contribution in the slot of its
+#                  list entry and adds them per Gaussian in tile order instead of float atomics — bit-identical gradients
+#                  from run to run, about 2x the backward time (debugging; tests that compare k-step parameters bit for bit).
+# The raw-parameter path (fused_step.py) reads the same two switches from attributes of the GaussianModel it is given.
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -36,6 +42,8 @@ class GaussianRasterizationSettings(NamedTuple):
     campos: torch.Tensor
     prefiltered: bool
     debug: bool
+    tile_cull: bool = True
+    deterministic: bool = False
 
 
 class FlashSplatRasterizationSettings(NamedTuple):
@@ -54,6 +62,8 @@ class FlashSplatRasterizationSettings(NamedTuple):
     debug: bool
     mask_grad: bool = False
     num_obj: int = 2
+    tile_cull: bool = True
+    deterministic: bool = False
 
 
 class ListCapacity:
@@ -64,7 +74,7 @@ class ListCapacity:
     largest R seen so far for this image size (x `slack`), stage 2 is enqueued right behind stage 1, and only then does
     the host wait for the counters — which the GPU produced BEFORE it started stage 2, so the wait ends while stage 2
     is still running.  The fill kernel never writes past the capacity it was given; if R turns out larger, stage 2 is
-    simply run again with the exact size (outputs are overwritten)."""
+    simply run again with the exact size (outputs are overwritten).  A hint only: results never depend on it."""
 
     def __init__(self, slack=1.25):
         self.slack = slack
@@ -77,15 +87,23 @@ class ListCapacity:
         self.known = max(self.known, int(R))
 
 
-_capacities = {}
-
-
-def list_capacity(device, H, W) -> ListCapacity:
-    """One estimate per (device, image size): list lengths of different resolutions have nothing to do with each other."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), int(H), int(W))
-    cap = _capacities.get(key)
+def list_capacity(owner, H, W) -> ListCapacity:
+    """The hint for image size (H, W), kept WITH THE CALLER'S DATA — an attribute of `owner`, the object that survives from
+    one call to the next on the caller's side (the GaussianModel of the raw-parameter path; the means3D tensor the drop-in
+    module is handed, which is the reference's `_xyz` nn.Parameter until a densification replaces it) — not in this module:
+    nothing is shared between two models or two rasterizers of one process, and the hint dies with the data it describes.
+    An owner that cannot carry attributes simply gets a fresh (empty) hint: the first-view, synchronous path."""
+    hints = getattr(owner, "_w3d_list_hints", None)
+    if hints is None:
+        hints = {}
+        try:
+            owner._w3d_list_hints = hints
+        except (AttributeError, TypeError):
+            pass
+    key = (int(H), int(W))
+    cap = hints.get(key)
     if cap is None:
-        cap = _capacities[key] = ListCapacity()
+        cap = hints[key] = ListCapacity()
     return cap
 
 
@@ -122,7 +140,8 @@ class _View:
         v.prefiltered, v.debug = int(bool(s.prefiltered)), int(bool(s.debug))
         v.bg, v.viewmatrix = self.bg.data_ptr(), self.vm.data_ptr()
         v.projmatrix, v.campos = self.pm.data_ptr(), self.cp.data_ptr()
-        v.tile_cull = int(bool(TILE_CULL))
+        v.tile_cull = int(bool(getattr(s, "tile_cull", True)))
+        self.deterministic = bool(getattr(s, "deterministic", False))
         self.c = v
 
 
@@ -140,6 +159,7 @@ def _forward_impl(settings, means3D, shs, colors_precomp, opacities, scales, rot
     """Runs stage 1 + stage 2.  Returns (color, radii, depth, alpha, saved, extras)."""
     _require_gpu(means3D)
     dev = means3D.device
+    hint_owner = means3D            # (the caller's tensor object, before any conversion below)
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     P = int(means3D.shape[0])
@@ -159,7 +179,7 @@ def _forward_impl(settings, means3D, shs, colors_precomp, opacities, scales, rot
         state = torch.empty(state_b.value, dtype=torch.uint8, device=dev)
         scratch = torch.empty(scratch_b.value, dtype=torch.uint8, device=dev)
         radii = torch.empty(P, dtype=torch.int32, device=dev)
-        cap = list_capacity(dev, H, W)
+        cap = list_capacity(hint_owner, H, W)
         guess = cap.guess()
         pending = None
         if guess == 0:
@@ -223,23 +243,10 @@ def _forward_impl(settings, means3D, shs, colors_precomp, opacities, scales, rot
     return color, radii, depth, alpha, saved, extras
 
 
-_DETERMINISTIC = False
-
-
-def set_deterministic(flag):
-    """Deterministic backward (w3d_view.deterministic, include/w3d.h): every (tile, Gaussian) contribution of the blend
-    backward goes to the slot of its list entry and is added per Gaussian in tile order, instead of float atomics whose
-    order — hence the last bits of every gradient — changes from run to run.  About 2x the backward time; meant for
-    debugging and for tests that compare parameters after several optimizer steps bit for bit.  Returns the old value."""
-    global _DETERMINISTIC
-    old, _DETERMINISTIC = _DETERMINISTIC, bool(flag)
-    return old
-
-
 def backward_scratch(view, P, point_list, dev):
-    """The scratch buffer of a backward call; selects the deterministic mode in `view` if it is switched on."""
+    """The scratch buffer of a backward call; selects the deterministic mode in the C struct when `view` asks for it."""
     sb = ctypes.c_uint64()
-    if _DETERMINISTIC:
+    if view.deterministic:
         cap = int(point_list.numel())
         view.c.deterministic, view.c.det_list_capacity = 1, cap
         check(lib.w3d_backward_det_sizes(P, cap, ctypes.byref(sb)))

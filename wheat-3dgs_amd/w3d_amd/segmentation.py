@@ -68,7 +68,9 @@ def binarize_mask_device(image, device="cuda"):
         raise ValueError("mask image must be 8-bit with shape (H,W) or (H,W,C)")
     H, W = int(a.shape[0]), int(a.shape[1])
     C = 1 if a.ndim == 2 else int(a.shape[2])
-    if C not in (1, 3, 4):
+    if C not in (1, 3):
+        # (an RGBA PNG would become all ones through its opaque alpha channel; reference binarize_mask,
+        #  utils/wheatgs_utils.py:26-37, raises for anything but 1 or 3 channels too)
         raise ValueError("Mask tensor should have 1 or 3 channels")
     dev = torch.device(device)
     pix = torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)

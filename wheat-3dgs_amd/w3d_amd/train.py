@@ -35,6 +35,20 @@ def dist_info():
     return 0, 1
 
 
+def nccl_inplace_shard(full, lo, hi, rank, world):
+    """NCCL / RCCL document exactly one aliasing of send and receive buffers as legal: reduce-scatter with
+    recvbuff == sendbuff + rank * recvcount, all-gather with sendbuff == recvbuff + rank * sendcount.  Returns the shard view
+    of `full` if [lo, hi) is that slot (the collective then runs in place, no staging copy of the bucket), else None — the
+    caller stages through a temporary.  A checked invariant instead of an assumption about how the buffers were sliced."""
+    n = hi - lo
+    if n <= 0 or full.numel() != world * n or lo != rank * n or not full.is_contiguous():
+        return None
+    shard = full[lo:hi]
+    if shard.data_ptr() != full.data_ptr() + rank * n * full.element_size():
+        return None
+    return shard
+
+
 class Trainer:
     def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
                  densify=True, loss_fn=photometric_loss, fused=None, force_exchange=False, fused_adam=True,
@@ -107,10 +121,9 @@ class Trainer:
         m = self.model
         if self.world > 1 or self.force_exchange:
             lo, hi = self.shard_range()
-            inplace = dist.get_backend() == "nccl"
-            if inplace:
-                self._rs_work = dist.reduce_scatter_tensor(m.flat_grad_store[lo:hi], m.flat_grad_store,
-                                                           op=dist.ReduceOp.SUM, async_op=True)
+            shard = nccl_inplace_shard(m.flat_grad_store, lo, hi, self.rank, self.world) if dist.get_backend() == "nccl" else None
+            if shard is not None:
+                self._rs_work = dist.reduce_scatter_tensor(shard, m.flat_grad_store, op=dist.ReduceOp.SUM, async_op=True)
             else:
                 shard = torch.empty(hi - lo, dtype=m.flat_grad_store.dtype, device=m.flat_grad_store.device)
                 dist.reduce_scatter_tensor(shard, m.flat_grad_store, op=dist.ReduceOp.SUM)
@@ -187,7 +200,7 @@ class Trainer:
             sh_adam_lowrank(m, d_all, campos, skip=skip, rows=None if whole else rows)
         for w in self._geo_work or ():
             w.wait()
-        m.optimizer.step(only=GEO_BLOCKS, skip=skip, advance=False)
+        m.optimizer.step(only=GEO_BLOCKS, skip=skip, advance=False, respect_none_grads=False)
         self._d_chunks, self._geo_work = [], None
 
     def _drain_lowrank(self):
@@ -210,15 +223,16 @@ class Trainer:
         """Adam on this rank's shard, then all-gather of the updated parameters (single GPU: plain step)."""
         m = self.model
         if self.world == 1 and not self.force_exchange:
-            m.optimizer.step(zero_grad=zero_grad, skip=skip)
+            m.optimizer.step(zero_grad=zero_grad, skip=skip, respect_none_grads=False)
             return
         lo, hi = self.shard_range()
         if getattr(self, "_rs_work", None) is not None:
             self._rs_work.wait()
             self._rs_work = None
-        m.optimizer.step(zero_grad=zero_grad, skip=skip, elem_range=(lo, hi))
-        if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(m.flat_store, m.flat_store[lo:hi])
+        m.optimizer.step(zero_grad=zero_grad, skip=skip, elem_range=(lo, hi), respect_none_grads=False)
+        shard = nccl_inplace_shard(m.flat_store, lo, hi, self.rank, self.world) if dist.get_backend() == "nccl" else None
+        if shard is not None:
+            dist.all_gather_into_tensor(m.flat_store, shard)
         else:
             dist.all_gather_into_tensor(m.flat_store, m.flat_store[lo:hi].clone())
         self._moments_sharded = True
