@@ -55,7 +55,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1600)
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--views", type=int, default=36)
-    ap.add_argument("--profile", default="render_bwd", help="stage timed with HIP events for the roofline object")
+    ap.add_argument("--profile", default="preprocess_bwd",
+                    help="stage timed with HIP events INSIDE the timed region for the `roofline` object (default: the step's "
+                         "dominant kernel, per-Gaussian backward + Adam)")
     ap.add_argument("--all-stages", action="store_true", help="also print per-stage event times to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-loss", action="store_true", help="use the PyTorch conv2d SSIM instead of the fused kernel")
@@ -246,28 +248,97 @@ def valu_peak():
     return VALU_SPEC_TFLOPS, "spec (MI355X_MICROARCH.md, Peak FP32 vector)"
 
 
+def _progress(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
 def cpu_baseline(args):
-    """The oracle (kind "port") timed on this box's host cores on a bounded sample: ONE full
-    train-step's rasterizer work (forward + backward of one 1600x1200 view of the 2M scene)."""
+    """the oracle (kind "port": this repo's C restatement of the rasterizer, OpenMP over tiles, all host
+    cores) timed on this box beside the GPU number.  What is timed, with time.perf_counter, is the bracket of reference
+    train_vanilla_3dgs.py:56,82 — render + 0.8*L1 + 0.2*(1-SSIM) + backward (the loss and its gradient by torch on the
+    CPU; no Adam, as in that bracket) — and the forward alone (Mpix/s):
+      * `value`: ONE view of the benchmark's own C3 workload (a bounded sample: 1 warm-up + 3 timed iterations, median);
+      * `c1`: config C1 (10 k Gaussians, 400x300), 3 warm-up + 10 timed iterations, median — the C oracle and, next to
+        it, the PyTorch restatement (oracle.torch_render, float32, autograd backward)."""
     import numpy as np
     from util import view_inputs, make_oracle, np_inputs
     from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.loss import photometric_loss_torch
     cores = os.cpu_count() or 1
-    sc = make_scene(args.points, seed=0)
-    cam = make_cameras(args.views, args.width, args.height)[0]
-    d = np_inputs(view_inputs(sc, cam))
-    o = make_oracle(cam, (0.0, 0.0, 0.0), nthreads=cores)
-    gc = np.random.RandomState(0).randn(3, args.height, args.width).astype(np.float32)
-    t0 = time.perf_counter()
-    o.forward(**d)
-    t1 = time.perf_counter()
-    o.backward(gc, None, None)
-    t2 = time.perf_counter()
-    o.free()
-    return {"value": round(1.0 / (t2 - t0), 5), "unit": "iters/s", "cores": cores, "kind": "port",
-            "sample": f"1 step (oracle forward {t1 - t0:.2f}s + backward {t2 - t1:.2f}s; rasterizer only, no loss/Adam) "
-                      f"of the same {args.points}-Gaussian {args.width}x{args.height} view, OpenMP over tiles",
-            "render_mpix_per_s": round(args.width * args.height / 1e6 / (t1 - t0), 4)}
+    # (the oracle brings its own OpenMP runtime next to torch's: neither may spin-wait on the other's cores)
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    os.environ.setdefault("GOMP_SPINCOUNT", "0")
+    _progress("cpu_baseline: C3 sample")
+
+    def c_oracle_protocol(P, width, height, warm, timed, seed):
+        sc = make_scene(P, seed=seed, **({} if P >= 100_000 else {"scale_mean": 0.012}))
+        cams = make_cameras(args.views, width, height)
+        g = torch.Generator().manual_seed(3)
+        gt = torch.rand(3, height, width, generator=g)
+        fwd, step = [], []
+        for i in range(warm + timed):
+            cam = cams[i % len(cams)]                       # cameras cycled
+            d = np_inputs(view_inputs(sc, cam))
+            o = make_oracle(cam, (0.0, 0.0, 0.0), nthreads=cores)
+            t0 = time.perf_counter()
+            out = o.forward(**d)
+            t1 = time.perf_counter()
+            img = torch.from_numpy(out["color"]).requires_grad_(True)
+            photometric_loss_torch(img, gt, 0.2).backward()
+            o.backward(img.grad.numpy(), None, None)
+            t2 = time.perf_counter()
+            o.free()
+            if i >= warm:
+                fwd.append(t1 - t0)
+                step.append(t2 - t0)
+        return _median(fwd), _median(step)
+
+    f3, s3 = c_oracle_protocol(args.points, args.width, args.height, 1, 3, 0)
+    _progress("cpu_baseline: C1, C oracle")
+    f1, s1 = c_oracle_protocol(10_000, 400, 300, 3, 10, 4)
+    out = {"value": round(1.0 / s3, 5), "unit": "iters/s", "cores": cores, "kind": "port",
+           "sample": f"render + 0.8*L1+0.2*(1-SSIM) + backward (the bracket of train_vanilla_3dgs.py:56,82; no Adam) of one "
+                     f"{args.points}-Gaussian {args.width}x{args.height} view of the benchmark scene: C oracle (OpenMP over tiles, "
+                     f"{cores} threads) + torch CPU loss; 1 warm-up + 3 timed iterations, median {s3:.2f} s (forward {f3:.2f} s)",
+           "render_mpix_per_s": round(args.width * args.height / 1e6 / f3, 4),
+           "c1": {"workload": "C1: 10000 Gaussians, 400x300", "protocol": "3 warm-up + 10 timed, median, cameras cycled, seed 4",
+                  "c_oracle_iters_per_s": round(1.0 / s1, 3), "c_oracle_render_mpix_per_s": round(0.12 / f1, 3)}}
+    # the PyTorch restatement at C1 (BASELINE.md section 4 names it): float32 torch_render, backward by autograd
+    torch_threads = torch.get_num_threads()
+    try:
+        from oracle.oracle import torch_render
+        _progress("cpu_baseline: C1, PyTorch restatement")
+        # thousands of small tensor ops per view: more threads than this only add fork/join time
+        torch.set_num_threads(min(cores, 16))
+        sc = make_scene(10_000, seed=4, scale_mean=0.012)
+        cams = make_cameras(args.views, 400, 300)
+        gt = torch.rand(3, 300, 400, generator=torch.Generator().manual_seed(3))
+        fwd, step = [], []
+        for i in range(1 + 3):
+            cam = cams[i % len(cams)]
+            d = {k: (None if v is None else v.clone().requires_grad_(True)) for k, v in view_inputs(sc, cam).items()}
+            t0 = time.perf_counter()
+            c = torch_render(300, 400, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3), cam.world_view_transform,
+                             cam.full_proj_transform, cam.camera_center, sh_degree=3, **d)[0]
+            t1 = time.perf_counter()
+            photometric_loss_torch(c, gt, 0.2).backward()
+            t2 = time.perf_counter()
+            if i >= 1:
+                fwd.append(t1 - t0)
+                step.append(t2 - t0)
+        out["c1"].update(torch_restatement_iters_per_s=round(1.0 / _median(step), 3),
+                         torch_restatement_render_mpix_per_s=round(0.12 / _median(fwd), 3),
+                         torch_restatement_protocol=f"1 warm-up + 3 timed, median; {min(cores, 16)} torch threads (a per-tile Python "
+                                                    "loop of small tensor ops: seconds per view)")
+    except Exception as e:      # the baseline leg must never take the bench line down
+        out["c1"]["torch_restatement_error"] = repr(e)
+    torch.set_num_threads(torch_threads)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ drop-in loop
@@ -425,6 +496,7 @@ def main():
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el), it, stages
 
+    _progress("warm-up")
     it = 0
     for _ in range(args.warmup):
         it += 1
@@ -448,6 +520,7 @@ def main():
                 trainer.step(it)
             selfcheck["replicas_identical_after_fallback"] = replicas_identical(model, world, dev)
     prof_sel = b"*" if args.all_stages else args.profile.encode()
+    _progress("timed steps")
     elapsed, it, stages = timed(args.steps, it, prof_sel)
     final_loss = float(trainer.last["loss"])
 
@@ -466,6 +539,7 @@ def main():
         exchange["selfcheck"] = selfcheck
         exchange["replicas_identical_after_timed_steps"] = replicas_identical(model, world, dev)
     if not args.no_extras:
+        _progress("extras: render / FlashSplat")
         # forward-only render throughput (reference render.py's use), same scene, views cycled
         n_r = max(4, min(args.steps, 36))
         render_views(model, cams[:2], bg)
@@ -495,6 +569,26 @@ def main():
             sync()
             extras["flashsplat_views_per_s"] = round(world * n_f / (time.perf_counter() - f0), 1)
         del counts
+        # run_3d_seg.py's MOST FREQUENT call (find_match :130-134, ~29 views per object mask and refine round; :362, 36 views):
+        # flashsplat_render(..., used_mask=obj_used_mask) followed by alpha > 0.5 -> bounding box -> IoU against the
+        # candidate masks.  The mask is applied inside the preprocess kernel; the scoring runs on the device.
+        from w3d_amd.segmentation import mask_iou_device
+        _progress("extras: subset renders")
+        head = ((model.get_xyz.detach() - torch.tensor([0.2, -0.1, 0.3], device=dev)).norm(dim=1) < 0.06)
+        cand = (torch.stack([torch.roll(mask, shifts=25 * k, dims=1) for k in range(4)]) > 0).to(torch.uint8)
+        with torch.no_grad():
+            for i in range(2):
+                flashsplat_render(cams[i], model, PipelineParams(), bg, used_mask=head)
+            sync()
+            f0 = time.perf_counter()
+            for i in range(args.views):
+                pkg_s = flashsplat_render(cams[i % len(cams)], model, PipelineParams(), bg, used_mask=head)
+                mask_iou_device(pkg_s["alpha"], cand, 0.5)
+            sync()
+            extras["flashsplat_subset_views_per_s"] = round(world * args.views / (time.perf_counter() - f0), 1)
+            extras["flashsplat_subset"] = {"gaussians_in_mask": int(head.sum()), "candidate_masks": 4,
+                                           "loop": "flashsplat_render(used_mask) + alpha>0.5 -> bbox -> IoU, per view (host reads 13 counters)"}
+        del head, cand, pkg_s
         # ... and run_3d_seg.py's real loop shape: several object masks per view — one forward, the blend repeated per mask
         n_m = 8
         masks = torch.stack([torch.roll(mask, shifts=40 * k, dims=1) for k in range(n_m)])
@@ -538,11 +632,13 @@ def main():
     # the UNMODIFIED reference loop body on the drop-in modules (single GPU: the reference is single-GPU)
     dropin = None
     if not args.no_extras and world == 1 and not force_dist:
+        _progress("drop-in loop")
         dropin = time_dropin(args, sc, cams, bg, dev, trainer.perm)
 
     # the same measurement on a TRAINED scene: the fit lowers opacities and lengthens the per-tile walks
     trained = None
     if not args.no_extras and args.trained_steps > 0 and trainer.fused:
+        _progress("trained scene")
         for _ in range(args.trained_steps):
             it += 1
             trainer.step(it)
@@ -555,6 +651,7 @@ def main():
             w2 = [workload_stats(model, cams[i], bg, dev) for i in (0, len(cams) // 2)]
             trained["walked_instances_per_view"] = int(sum(w["R_walk"] for w in w2) / len(w2))
             trained["tile_instances_per_view"] = int(sum(w["R"] for w in w2) / len(w2))
+            trained["_V"] = sum(w["V"] for w in w2) / len(w2)
 
     if rank == 0:
         V = sum(w["V"] for w in ws) / len(ws)
@@ -562,41 +659,87 @@ def main():
         Rw = sum(w["R_walk"] for w in ws) / len(ws)
         HW = args.width * args.height
         P = args.points
-        # algorithmic bytes per launch:
-        #   blend backward: 84 B per tile instance the reverse walk visits (44 B gather + 40 B record update)
-        #                   + 20 B per pixel (dL/dpixel 12 + final_T 4 + n_contrib 4)
-        algo = {"render_bwd": 84.0 * Rw + 20.0 * HW, "render_fwd": 48.0 * Rw + 36.0 * HW,
-                "preprocess_fwd": 236.0 * P + 56.0 * V, "preprocess_bwd": 236.0 * P + 64.0 * V + 252.0 * P,
-                "fill_lists": 4.0 * R + 8.0 * V, "depth_sort": 4 * 16.0 * P, "tile_count_scan": 8.0 * V}
+        fused_adam = trainer.fused and trainer.fused_adam and world == 1 and not force_dist
+
+        def kernel_bytes(V, R, Rw):
+            """Algorithmic HBM bytes per launch of every stage (what the stage must read and write once)."""
+            return {
+                "preprocess_fwd": 236.0 * P + 64.0 * V,              # parameters read; packed per-visible records written
+                "depth_sort": 4 * 16.0 * P,                            # 4 passes x (key, id) read + written
+                "gather_sorted": 8.0 * V + 16.0 * V + 24.0 * V,        # sorted (key, id) + rect/mask gather -> 24-B records
+                "tile_count_scan": 24.0 * V,                           # the records, once
+                "fill_lists": 24.0 * V + 4.0 * R,                      # the records once + the lists
+                "render_fwd": 48.0 * Rw + 36.0 * HW,                   # 4-B id + 44-B gather per walked instance; image + aux
+                "loss": 2 * 12.0 * HW + 12.0 * HW,                     # image + gt read, gradient written
+                "render_bwd": 84.0 * Rw + 20.0 * HW,                   # gather + one 40-B record update; dL/dpixel + aux
+                # fused Adam: parameters + both moments read and written, 2-D records read / otherwise gradients written
+                "preprocess_bwd": (6 * 236.0 * P + 104.0 * V) if fused_adam else (236.0 * P + 64.0 * V + 252.0 * P),
+            }
+
+        def kernel_table(stage_ms, V, R, Rw):
+            """Per stage: event-timed ms, algorithmic bytes, achieved GB/s and fraction of the HBM peak, PMC-counter traffic of
+            the newest committed summary and its ratio to the algorithmic bytes (wasted re-reads show up there)."""
+            kb = kernel_bytes(V, R, Rw)
+            pmc_name = {"preprocess_fwd": "preprocess_fwd_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
+                        "render_fwd": "render_fwd_kernel", "render_bwd": "render_bwd_kernel", "fill_lists": "chunk_walk_kernel<1",
+                        "gather_sorted": "gather_sorted_kernel", "loss": "l1_ssim", "depth_sort": "radix_", "tile_count_scan": "chunk_walk_kernel<0"}
+            rows = []
+            for k, ms in sorted(stage_ms.items(), key=lambda kv: -kv[1]):
+                if k not in kb:
+                    continue
+                gbs = kb[k] / (ms * 1e-3) / 1e9
+                tr = pmc_traffic(pmc_name.get(k, k))
+                rows.append({"stage": k, "ms": ms, "algorithmic_bytes": int(kb[k]), "achieved_GBps": round(gbs, 1),
+                             "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "pmc_traffic_bytes": tr,
+                             "traffic_ratio": None if not tr else round(tr / kb[k], 2)})
+            return rows
+
+        def step_roofline(V, R, Rw, it_per_s, stage_ms):
+            """SURVEY.md section 8(d) / BASELINE.md section 5 as written: (B_f + B_b + B_adam) * iters/s / peak with the MEASURED
+            V and R, and the same with this design's own byte count (sum of the stages' algorithmic bytes — fusion removed the
+            gradient round trip and the 64-bit key sort, so it is smaller)."""
+            B_f = 236.0 * P + 56.0 * V + 80.0 * R + 28.0 * HW
+            B_b = 484.0 * P + 80.0 * V + 84.0 * R + 20.0 * HW
+            B_adam = 1652.0 * P
+            tot = B_f + B_b + B_adam
+            kb = kernel_bytes(V, R, Rw)
+            own = sum(kb[k] for k in kb if k in stage_ms)
+            return {"formula": "B_f + B_b + B_adam, B_f = 236P + 56V + 80R + 28HW, B_b = 484P + 80V + 84R + 20HW, B_adam = 1652P",
+                    "P": P, "V": int(V), "R": int(R), "HW": HW, "B_f": int(B_f), "B_b": int(B_b), "B_adam": int(B_adam),
+                    "algorithmic_bytes": int(tot), "achieved_GBps": round(tot * it_per_s / 1e9, 1),
+                    "frac": round(tot * it_per_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "design_bytes": int(own), "design_achieved_GBps": round(own * it_per_s / 1e9, 1),
+                    "design_frac": round(own * it_per_s / 1e9 / HBM_PEAK_GBS, 4)}
+
+        it_per_s = args.steps / elapsed          # per GPU (weak scaling: every rank runs this step)
+        algo = kernel_bytes(V, R, Rw)
         roof = None
         if args.profile in stages and stages[args.profile][0] > 0:
+            # the dominant kernel, timed with HIP events on its launch stream INSIDE the timed region
             cnt, ms = stages[args.profile]
             avg_ms = ms / cnt
             hbm_ach = algo.get(args.profile, 0.0) / (avg_ms * 1e-3) / 1e9
-            n_valu, src = valu_instructions(args.profile + "_kernel")
-            if args.profile.startswith("render") and n_valu:
-                # the blend kernels are VALU-issue bound (no MFMA shape, HBM traffic ~= algorithmic): price the wave64 VALU
-                # instructions one launch issues (SQ_INSTS_VALU, committed PMC summary of this kernel) against the chip's
-                # fp32 vector issue rate, one instruction = 64 lanes x 2 flop
-                peak, peak_src = valu_peak()
-                ach = n_valu * FLOP_PER_VALU_INSTR / (avg_ms * 1e-3) / 1e12
-                # peak: the guide's fp32 vector peak (spec clock); peak_measured: the FMA issue rate this chip sustains
-                # (profiles/valu_microbench.hip: the clock sags under a pure VALU load)
-                roof = {"bound": "valu", "kernel": args.profile, "achieved": round(ach, 2), "peak": VALU_SPEC_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / VALU_SPEC_TFLOPS, 4),
-                        "peak_measured": round(peak, 1), "frac_of_measured": round(ach / peak, 4),
-                        "traffic": pmc_traffic(args.profile + "_kernel"),
-                        "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
-                        "valu_wave_instr_per_launch": int(n_valu), "valu_instr_source": src, "peak_source": peak_src,
-                        "flop_equiv_per_wave_instr": FLOP_PER_VALU_INSTR,
-                        "valu_instr_per_walked_instance": round(n_valu / max(Rw, 1.0), 1),
-                        "algorithmic_bytes_per_launch": int(algo.get(args.profile, 0.0)),
-                        "hbm_achieved_GBps": round(hbm_ach, 1), "hbm_frac": round(hbm_ach / HBM_PEAK_GBS, 5)}
-            else:
-                roof = {"bound": "hbm", "kernel": args.profile, "achieved": round(hbm_ach, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(hbm_ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.profile + "_kernel"),
-                        "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
-                        "algorithmic_bytes_per_launch": int(algo.get(args.profile, 0.0))}
+            label = "preprocess_bwd+adam" if (args.profile == "preprocess_bwd" and fused_adam) else args.profile
+            tr = pmc_traffic(args.profile + "_kernel")
+            roof = {"bound": "hbm", "kernel": label, "achieved": round(hbm_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(hbm_ach / HBM_PEAK_GBS, 4), "traffic": tr,
+                    "traffic_ratio": None if not tr else round(tr / algo[args.profile], 2),
+                    "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
+                    "algorithmic_bytes_per_launch": int(algo.get(args.profile, 0.0)),
+                    "step": step_roofline(V, R, Rw, it_per_s, stage_ms),
+                    "kernels": kernel_table(stage_ms, V, R, Rw)}
+        # the blend backward's own roof is VALU issue, not HBM (DESIGN.md section 2.1): kept beside the HBM objects
+        valu = None
+        n_valu, src = valu_instructions("render_bwd_kernel")
+        if n_valu and "render_bwd" in stage_ms:
+            peak, peak_src = valu_peak()
+            ach = n_valu * FLOP_PER_VALU_INSTR / (stage_ms["render_bwd"] * 1e-3) / 1e12
+            valu = {"bound": "valu", "kernel": "render_bwd", "achieved": round(ach, 2), "peak": VALU_SPEC_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / VALU_SPEC_TFLOPS, 4), "peak_measured": round(peak, 1),
+                    "frac_of_measured": round(ach / peak, 4), "avg_launch_ms": stage_ms["render_bwd"],
+                    "valu_wave_instr_per_launch": int(n_valu), "valu_instr_source": src, "peak_source": peak_src,
+                    "flop_equiv_per_wave_instr": FLOP_PER_VALU_INSTR,
+                    "note": "instruction count from the committed SQ counter summary (collected on the untrained scene)"}
         if args.all_stages:
             for k, (c, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1]):
                 print(f"[stage] {k:18s} {c:5d} launches  avg {ms / c:8.4f} ms", file=sys.stderr)
@@ -605,6 +748,10 @@ def main():
             "value": round(world * args.steps / elapsed, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the same step on the scene after `trained_steps` more training steps (opacities dropped, walks 2-3x longer): the
+            # regime a real run spends its time in
+            "trained_value": None if trained is None else trained["value"],
+            "trained_ms_per_step": None if trained is None else trained["ms_per_step"],
             "dropin_iters_per_s": None if dropin is None else dropin["iters_per_s"],
             "config": {"workload": f"C3: plot-shaped synthetic scene, {P} Gaussians, SH degree 3, "
                                    f"{args.width}x{args.height}, {args.views} overhead cameras, depth+alpha channels",
@@ -615,6 +762,7 @@ def main():
                        "step": "fused raw-parameter kernels (no autograd)" if trainer.fused else "render() + autograd (Trainer.step)",
                        "final_loss": round(final_loss, 6)},
             "roofline": roof,
+            "roofline_valu_kernel": valu,
             "stage_ms": stage_ms,
         }
         out.update(extras)
@@ -623,18 +771,12 @@ def main():
                                               "GaussianModel / l1_loss / ssim; loss.item() and the boolean-mask statistics "
                                               "lines (host syncs of the reference loop) included")
         if trained is not None:
+            tV, tR, tRw = trained.pop("_V"), trained["tile_instances_per_view"], trained["walked_instances_per_view"]
+            trained["roofline"] = {"step": step_roofline(tV, tR, tRw, trained["value"] / world, trained["stage_ms"]),
+                                   "kernels": kernel_table(trained["stage_ms"], tV, tR, tRw)}
             out["trained_scene"] = trained
         if exchange is not None:
             out["exchange"] = exchange
-        # the HBM-bound kernel of the step next to the (VALU-bound) dominant one: per-Gaussian backward + Adam + statistics
-        fused_adam = trainer.fused and trainer.fused_adam and world == 1 and not force_dist
-        if fused_adam and "preprocess_bwd" in stage_ms:
-            b = 6 * 236.0 * P + 104.0 * V          # parameters + both moments read and written; 2-D gradient records read
-            ach = b / (stage_ms["preprocess_bwd"] * 1e-3) / 1e9
-            out["roofline_hbm_kernel"] = {"bound": "hbm", "kernel": "preprocess_bwd+adam", "achieved": round(ach, 1),
-                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                          "traffic": pmc_traffic("preprocess_bwd_kernel"),
-                                          "avg_launch_ms": stage_ms["preprocess_bwd"], "algorithmic_bytes_per_launch": int(b)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         else:

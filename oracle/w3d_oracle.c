@@ -55,9 +55,11 @@
 static int g_exp_mode = 0;
 void w3do_set_exp_mode(int mode) { g_exp_mode = mode; }
 /* Conditioning of the densification statistic (tests only): when set, w3do_backward adds |term| of every summand of
- * dL/dmean2D.x / .y into abs_out[2g], abs_out[2g+1] (doubles, zeroed by the caller) — with the two products of a summand
- * (G dx conic.x and G dy conic.y) taken separately, so the bound also covers an implementation that sums the moments
- * sum(m dx), sum(m dy) first and combines them with the conic afterwards.  sum|terms| / |sum terms| is the condition number of
+ * dL/dmean2D.x / .y into abs_out[2g], abs_out[2g+1] (doubles, zeroed by the caller) — with every DIFFERENCE inside a
+ * summand replaced by the sum of its operands' magnitudes: (colour - colour behind) becomes |colour| + |colour behind|, the
+ * two products G dx conic.x and G dy conic.y are taken separately (which also covers an implementation that sums the
+ * moments sum(m dx), sum(m dy) first and combines them with the conic afterwards).  That is the classical running error
+ * bound: rounding an operand by 2^-24 moves the summand by at most 2^-24 times this magnitude.  sum|terms| / |sum terms| is the condition number of
  * that Gaussian's sum: an fp32 implementation that rounds each term (relative 2^-24) can be off by ~2^-24 * sum|terms|
  * however it orders the additions — which exceeds 1e-4 of the result where terms cancel. */
 static double *g_abs_out = NULL;
@@ -575,6 +577,9 @@ void w3do_backward(void *h, const W3DOView *v, const float *means3D, const float
                     Tr = Tr / (1.f - alpha);
                     float dch = alpha * Tr;
                     float dL_dalpha = 0.f;
+                    /* running magnitude of dL_dalpha with every difference replaced by the sum of its operands' magnitudes
+                     * (tests only, g_abs_out): what the rounding of the operands can move the term by */
+                    double mag_dalpha = 0.0;
                     double *a = acc + (size_t)g * NA;
                     float *af = accf ? accf + (size_t)g * NA : NULL;
 #define ACC(i, x) acc_add(a + (i), af ? af + (i) : NULL, (x))
@@ -583,6 +588,7 @@ void w3do_backward(void *h, const W3DOView *v, const float *means3D, const float
                         accum_rec[ch] = w3do_lerp(accum_rec[ch], last_color[ch], last_alpha);
                         last_color[ch] = c;
                         dL_dalpha += (c - accum_rec[ch]) * dLdp[ch];
+                        mag_dalpha += (fabs((double)c) + fabs((double)accum_rec[ch])) * fabs((double)dLdp[ch]);
                         ACC(6 + ch, dch * dLdp[ch]);
                     }
                     {
@@ -593,10 +599,13 @@ void w3do_backward(void *h, const W3DOView *v, const float *means3D, const float
                         ACC(9, dch * dLdd);
                         accum_a = w3do_lerp(accum_a, 1.0f, last_alpha);
                         dL_dalpha += (1.0f - accum_a) * dLda;
+                        mag_dalpha += (fabs((double)cd) + fabs((double)accum_d)) * fabs((double)dLdd) + (1.0 + fabs((double)accum_a)) * fabs((double)dLda);
                     }
                     dL_dalpha *= Tr;
+                    mag_dalpha *= Tr;
                     last_alpha = alpha;
                     dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    mag_dalpha += fabs((double)(T_final / (1.f - alpha)) * bg_dot);
                     float dL_dG = co[3] * dL_dalpha;
                     float gdx = G * dx, gdy = G * dy;
                     float dG_ddelx = -gdx * co[0] - gdy * co[1];
@@ -604,10 +613,15 @@ void w3do_backward(void *h, const W3DOView *v, const float *means3D, const float
                     ACC(0, dL_dG * dG_ddelx * ddelx_dx);
                     ACC(1, dL_dG * dG_ddely * ddely_dy);
                     if (g_abs_out) {
+                        /* ... and the exponent: power is a difference of products of size |conic| d^2, so its rounding error —
+                         * a RELATIVE error of G, hence of the whole summand — is 2^-24 times their magnitude, not times
+                         * |power| (thin, rotated footprints: large terms that cancel) */
+                        const double pmag = 0.5 * (fabs((double)co[0]) * dx * dx + fabs((double)co[2]) * dy * dy) + fabs((double)co[1] * dx * dy);
+                        const double mG = (double)co[3] * mag_dalpha * (1.0 + pmag);
 #pragma omp atomic
-                        g_abs_out[2 * (size_t)g] += (fabs((double)gdx * co[0]) + fabs((double)gdy * co[1])) * fabs((double)dL_dG) * ddelx_dx;
+                        g_abs_out[2 * (size_t)g] += (fabs((double)gdx * co[0]) + fabs((double)gdy * co[1])) * mG * ddelx_dx;
 #pragma omp atomic
-                        g_abs_out[2 * (size_t)g + 1] += (fabs((double)gdy * co[2]) + fabs((double)gdx * co[1])) * fabs((double)dL_dG) * ddely_dy;
+                        g_abs_out[2 * (size_t)g + 1] += (fabs((double)gdy * co[2]) + fabs((double)gdx * co[1])) * mG * ddely_dy;
                     }
                     ACC(2, -0.5f * gdx * dx * dL_dG);
                     ACC(3, -0.5f * gdx * dy * dL_dG);

@@ -493,9 +493,9 @@ def test_reference_loss_lines_run_as_one_fused_pair(shape):
     lam = 0.2
     img = base.clone().requires_grad_(True)
     Ll1 = L.l1_loss(img, gt)
-    assert L._pending is not None and type(Ll1.grad_fn).__name__.startswith("_FusedLossPair")
+    assert L._tls.pending is not None and type(Ll1.grad_fn).__name__.startswith("_FusedLossPair")
     s = L.ssim(img, gt)
-    assert L._pending is None and s.grad_fn is Ll1.grad_fn            # the same node: no second pass A
+    assert L._tls.pending is None and s.grad_fn is Ll1.grad_fn            # the same node: no second pass A
     loss = (1.0 - lam) * Ll1 + lam * (1.0 - s)
     loss.backward()
     ref_img = base.clone().requires_grad_(True)
@@ -525,10 +525,10 @@ def test_reference_loss_lines_run_as_one_fused_pair(shape):
     other = (base * 0.5).clone().requires_grad_(True)
     s_other = L.ssim(other, gt)
     assert abs(float(s_other) - float(L.ssim_torch(other.detach(), gt))) <= 2e-6
-    assert L._pending is None
+    assert L._tls.pending is None
     # without grad (evaluation code) l1_loss is the plain torch expression
     with torch.no_grad():
-        assert L.l1_loss(base, gt).grad_fn is None and L._pending is None
+        assert L.l1_loss(base, gt).grad_fn is None and L._tls.pending is None
 
 
 def test_add_densification_stats_kernel_matches_the_reference_statements():

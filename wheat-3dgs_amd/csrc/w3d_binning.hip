@@ -25,12 +25,30 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x
 
 // ------------------------------------------------------------------------------ radix sort
 // One pass = histogram, row scan, scatter.  A "run" is the contiguous slice of keys one wave owns.
+//
+// The keys are the bit patterns of positive floats (view depths), and a view's depths rarely span more than two octaves
+// (the wheat-plot cameras hover 2-2.5 units above the canopy: depths 1.7-3.2), so their upper 16 bits take at most 256
+// consecutive values.  The first pass's histogram kernel therefore also finds min / max of the visible keys, and when
+// (kmax >> 16) - (kmin >> 16) <= 255 the third pass sorts by (key >> 16) - (kmin >> 16) — ALL the remaining bits in one
+// 8-bit digit — and the fourth pass does not run: 3 passes instead of 4, same order (the digit is a monotone function of the
+// upper half).  Wider depth ranges take the four plain 8-bit passes.  The decision lives on the device (counters[4..5]):
+// kernels of a pass that is not needed exit at once, and the consumers pick the buffer the last executed pass wrote.
+#define W3D_CTL_KMIN_HI 4       // counters[4] = kmin >> 16
+#define W3D_CTL_THREE 5         // counters[5] = 1: three passes suffice
+__device__ __forceinline__ uint32_t radix_digit(uint32_t key, int pass, const uint32_t *__restrict__ ctl) {
+    if (pass < 2) return (key >> (W3D_RADIX_BITS * pass)) & (W3D_RADIX_BINS - 1u);
+    if (ctl[W3D_CTL_THREE]) return (key >> 16) - ctl[W3D_CTL_KMIN_HI];
+    return (key >> (W3D_RADIX_BITS * pass)) & (W3D_RADIX_BINS - 1u);
+}
+
 __global__ void __launch_bounds__(256)
-radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items, uint32_t n_runs, int shift,
-                  uint32_t *__restrict__ hist /* [256][n_runs] */, const uint32_t *__restrict__ n_dev, int drop_invalid) {
+radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items, uint32_t n_runs, int pass,
+                  uint32_t *__restrict__ hist /* [256][n_runs] */, const uint32_t *__restrict__ n_dev, int drop_invalid,
+                  const uint32_t *__restrict__ ctl, uint32_t *__restrict__ minmax /* pass 0: [n_runs][2] */) {
     __shared__ uint32_t h_all[4][W3D_RADIX_BINS];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
+    if (pass == 3 && ctl[W3D_CTL_THREE]) return;
     uint32_t *h = h_all[wv];
     for (int i = lane; i < W3D_RADIX_BINS; i += 64) h[i] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -39,14 +57,29 @@ radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items,
     if (n_dev) { n = *n_dev; items = max(64u, ((n + n_runs - 1u) / n_runs + 63u) & ~63u); }
     if (run < n_runs) {
         const uint32_t beg = min(n, run * items), end = min(n, beg + items);
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+        // (the digit rule of passes 2 / 3 is wave-uniform and loop-invariant: read once)
+        const uint32_t three = pass >= 2 ? ctl[W3D_CTL_THREE] : 0u, kmin_hi = pass >= 2 ? ctl[W3D_CTL_KMIN_HI] : 0u;
+        const int shift = W3D_RADIX_BITS * pass;
 #pragma unroll 8
         for (uint32_t i = beg + lane; i < end; i += 64) {
             const uint32_t key = keys[i];
-            const uint32_t d = (key >> shift) & (W3D_RADIX_BINS - 1u);
-            if (!drop_invalid || key != W3D_INVALID_KEY) atomicAdd(const_cast<uint32_t *>(&h_all[wv][d]), 1u);
+            const uint32_t d = three ? (key >> 16) - kmin_hi : (key >> shift) & (W3D_RADIX_BINS - 1u);
+            if (!drop_invalid || key != W3D_INVALID_KEY) {
+                atomicAdd(const_cast<uint32_t *>(&h_all[wv][d & (W3D_RADIX_BINS - 1u)]), 1u);
+                kmin = min(kmin, key); kmax = max(kmax, key);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < W3D_RADIX_BINS; i += 64) hist[(size_t)i * n_runs + run] = h[i];
+        if (minmax) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+                kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+            }
+            if (lane == 0) { minmax[2 * run] = kmin; minmax[2 * run + 1] = kmax; }
+        }
     }
 }
 
@@ -82,8 +115,30 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
 
 // one block per digit: exclusive scan of that digit's row of per-run counts (in place) + row total
 __global__ void __launch_bounds__(256)
-radix_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t n_runs, uint32_t *__restrict__ rowtot) {
+radix_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t n_runs, uint32_t *__restrict__ rowtot, int pass,
+                     uint32_t *__restrict__ ctl, const uint32_t *__restrict__ minmax) {
     __shared__ uint32_t wave_tot[17];
+    if (pass == 3 && ctl[W3D_CTL_THREE]) return;
+    if (pass == 0 && blockIdx.x == 0) {
+        // depth range of the visible Gaussians -> how many passes the sort needs (see radix_digit)
+        __shared__ uint32_t red[8];
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+        for (uint32_t i = threadIdx.x; i < n_runs; i += 256) { kmin = min(kmin, minmax[2 * i]); kmax = max(kmax, minmax[2 * i + 1]); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = kmin; red[2 * (threadIdx.x >> 6) + 1] = kmax; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; w++) { kmin = min(kmin, red[2 * w]); kmax = max(kmax, red[2 * w + 1]); }
+            const bool none = kmin > kmax;                       // nothing visible
+            ctl[W3D_CTL_KMIN_HI] = none ? 0u : (kmin >> 16);
+            ctl[W3D_CTL_THREE] = (none || ((kmax >> 16) - (kmin >> 16)) < (uint32_t)W3D_RADIX_BINS) ? 1u : 0u;
+        }
+        __syncthreads();
+    }
     uint32_t *row = hist + (size_t)blockIdx.x * n_runs;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < n_runs; base += 256) {
@@ -100,13 +155,16 @@ radix_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t n_runs, uint32_t *__r
 __global__ void __launch_bounds__(256)
 radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                      uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t items,
-                     uint32_t n_runs, int shift, const uint32_t *__restrict__ offs /* row-scanned [256][n_runs] */,
+                     uint32_t n_runs, int pass, const uint32_t *__restrict__ offs /* row-scanned [256][n_runs] */,
                      const uint32_t *__restrict__ rowtot /* [BINS] */, uint32_t *__restrict__ num_visible,
-                     const uint32_t *__restrict__ n_dev) {
+                     const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ ctl) {
     __shared__ uint32_t cur_all[4][W3D_RADIX_BINS];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
     if (run >= n_runs) return;
+    if (pass == 3 && ctl[W3D_CTL_THREE]) return;
+    const uint32_t three = pass >= 2 ? ctl[W3D_CTL_THREE] : 0u, kmin_hi = pass >= 2 ? ctl[W3D_CTL_KMIN_HI] : 0u;
+    const int shift = W3D_RADIX_BITS * pass;
     // num_visible != NULL: FIRST pass — culled Gaussians (key 0xFFFFFFFF) are dropped and the number of survivors is
     // published; n_dev != NULL: later pass over those survivors only (same re-partition as radix_hist_kernel)
     const bool drop_invalid = num_visible != nullptr;
@@ -144,7 +202,7 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
         const uint32_t key = nkey, val = nval;
         const bool valid = i < end && !(drop_invalid && key == W3D_INVALID_KEY);
         if (i + 64 < end) { nkey = keys_in[i + 64]; nval = vals_in[i + 64]; }
-        const uint32_t d = (key >> shift) & (W3D_RADIX_BINS - 1u);
+        const uint32_t d = (three ? (key >> 16) - kmin_hi : (key >> shift)) & (W3D_RADIX_BINS - 1u);
         // lanes holding the same digit (stable rank = number of such lanes below me)
         uint64_t peers = w3d_ballot(valid);
 #pragma unroll
@@ -166,23 +224,32 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
 // Depth-ordered packed records {id, rect lo, rect hi, depth} + tile mask, so that the (chunk, band) walkers —
 // which re-read their chunk once per band and per pass — stream them coalesced instead of gathering.
 __global__ void __launch_bounds__(256)
-gather_sorted_kernel(const uint32_t *__restrict__ sorted_ids, const uint32_t *__restrict__ sorted_keys,
+gather_sorted_kernel(const uint32_t *__restrict__ ids4, const uint32_t *__restrict__ keys4,
+                     const uint32_t *__restrict__ ids3, const uint32_t *__restrict__ keys3,
                      const uint2 *__restrict__ rect, const uint4 *__restrict__ rect_mask,
                      const uint32_t *__restrict__ counters, uint32_t P,
-                     uint4 *__restrict__ rec, uint2 *__restrict__ rec_mask, int cull) {
+                     uint4 *__restrict__ rec, uint2 *__restrict__ rec_mask, uint32_t *__restrict__ rec_rows, int cull) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= P || s >= counters[0]) return;
+    // the sorted (key, id) pairs sit in the buffer the LAST EXECUTED pass wrote: after three passes or after four
+    const bool three = counters[W3D_CTL_THREE] != 0u;
+    const uint32_t *__restrict__ sorted_ids = three ? ids3 : ids4, *__restrict__ sorted_keys = three ? keys3 : keys4;
     const uint32_t g = sorted_ids[s];
     const uint32_t depth_bits = sorted_keys[s];          // the sort key IS the view depth (for the depth cuts): no gather
     if (cull) {
         const uint4 b = rect_mask[g];                    // one 16-B record per Gaussian: a single random line
         rec[s] = make_uint4(g, b.x, b.y, depth_bits);
         rec_mask[s] = make_uint2(b.z, b.w);
+        rec_rows[s] = (b.x >> 16) | (b.y & 0xFFFF0000u);
     } else {
         const uint2 rc = rect[g];
         rec[s] = make_uint4(g, rc.x, rc.y, depth_bits);
         rec_mask[s] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        rec_rows[s] = (rc.x >> 16) | (rc.y & 0xFFFF0000u);
     }
+    // rec_rows = {first tile row, one past the last} in 4 bytes: a (chunk, band) walker decides from it alone whether a
+    // record concerns its band, and only then fetches the 24-B record — the bands re-stream every record (25 bands in the
+    // fill pass), and that scan ran at the L2's bandwidth with whole records (732 MB per fill at 1.2 M visible)
 }
 
 // One wave per (chunk, band of tile rows).  The wave streams the chunk's depth-ordered records, keeps the
@@ -207,7 +274,7 @@ gather_sorted_kernel(const uint32_t *__restrict__ sorted_ids, const uint32_t *__
 #endif
 template <int MODE, bool CULL>
 __global__ void __launch_bounds__(64 * W3D_WW)
-chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_mask,
+chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_mask, const uint32_t *__restrict__ rec_rows,
                   const uint32_t *__restrict__ counters,
                   uint32_t chunk, uint32_t C, uint32_t T, uint32_t gx, uint32_t gy, uint32_t band_rows,
                   uint16_t *__restrict__ cnt, const uint32_t *__restrict__ off, uint32_t *__restrict__ point_list,
@@ -236,19 +303,17 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
     // the matrices for — all C chunk-waves of a band get work, each a 1/C-th of it
     chunk = min(chunk, max(64u, ((V + C - 1u) / C + 63u) & ~63u));
     const uint32_t s_beg = min(V, c * chunk), s_end = min(V, s_beg + chunk);
-    // the first records are requested before the LDS set-up below, which hides their latency; NB 64-record
-    // batches are kept in flight (rotating registers, so the loop body — and process() — exists once)
-    constexpr int NB = 4;
-    uint4 nx_rec[NB];
-    uint2 nx_mask[NB];
-    auto fetch_one = [&](uint32_t from, uint4 &r, uint2 &mk) {
+    // The scan reads only the 4-B row spans of the chunk's records (NB batches of 64 in flight, requested before the LDS
+    // set-up below, which hides their latency); the 24-B record itself is fetched by the lanes whose record concerns this
+    // band — about one in eight — and lands in the ring one iteration later, so its latency overlaps the next span test.
+    constexpr int NB = 8;
+    uint32_t nx_rows[NB];
+    auto fetch_rows = [&](uint32_t from) -> uint32_t {
         const uint32_t s = from + lane;
-        r = make_uint4(0u, 0u, 0u, 0u);
-        mk = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (s < s_end) { r = rec[s]; if (CULL) mk = rec_mask[s]; }
+        return s < s_end ? rec_rows[s] : 0u;          // (rows [0, 0): concerns no band)
     };
 #pragma unroll
-    for (int i = 0; i < NB; i++) fetch_one(s_beg + (uint32_t)i * 64u, nx_rec[i], nx_mask[i]);
+    for (int i = 0; i < NB; i++) nx_rows[i] = fetch_rows(s_beg + (uint32_t)i * 64u);
     if (MODE == 0) {
         for (uint32_t t = lane; t < Tbpad / 2; t += 64) h32[t] = 0;
     } else {
@@ -394,26 +459,33 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         __builtin_amdgcn_wave_barrier();
     };
 
-    for (uint32_t base = s_beg; base < s_end; base += 64u) {
-        const uint32_t nb = min(64u, s_end - base);
-        const uint4 cur_rec = nx_rec[0];
-        const uint2 cur_mask = nx_mask[0];
+    uint4 pend_rec = make_uint4(0u, 0u, 0u, 0u);
+    uint2 pend_mask = make_uint2(0u, 0u);
+    bool pend_rel = false;
+    // (one iteration more than there are batches: it only commits the last batch's records and drains the ring)
+    for (uint32_t base = s_beg; base < s_end + 64u; base += 64u) {
+        const uint32_t cur_rows = nx_rows[0];
 #pragma unroll
-        for (int i = 0; i + 1 < NB; i++) { nx_rec[i] = nx_rec[i + 1]; nx_mask[i] = nx_mask[i + 1]; }
-        fetch_one(base + 64u * NB, nx_rec[NB - 1], nx_mask[NB - 1]);
+        for (int i = 0; i + 1 < NB; i++) nx_rows[i] = nx_rows[i + 1];
+        nx_rows[NB - 1] = fetch_rows(base + 64u * NB);
         // rect reaches into this band?  (whether its tile mask does is settled when the record is binned)
-        const bool relevant = lane < nb && (cur_rec.y >> 16) < y1 && (cur_rec.z >> 16) > y0;
-        const uint64_t bal = w3d_ballot(relevant);
+        const bool relevant = base + lane < s_end && (cur_rows & 0xFFFFu) < y1 && (cur_rows >> 16) > y0;
+        uint4 new_rec = make_uint4(0u, 0u, 0u, 0u);
+        uint2 new_mask = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (relevant) { new_rec = rec[base + lane]; if (CULL) new_mask = rec_mask[base + lane]; }
+        // the records requested in the previous iteration go into the ring now
+        const uint64_t bal = w3d_ballot(pend_rel);
         if (bal) {
-            if (relevant) {
+            if (pend_rel) {
                 const uint32_t slot = (q_head + q_len + (uint32_t)__popcll(bal & lanemask_lt())) & (W3D_WALK_QUEUE - 1u);
-                qa[slot] = cur_rec; qb[slot] = cur_mask;
+                qa[slot] = pend_rec; qb[slot] = pend_mask;
             }
             q_len += (uint32_t)__popcll(bal);
             __builtin_amdgcn_wave_barrier();
         }
-        // bin 64 queued records — or, after the last batch, whatever is left (the same code, so process() is instantiated once)
-        const bool last = base + 64u >= s_end;
+        pend_rel = relevant; pend_rec = new_rec; pend_mask = new_mask;
+        // bin 64 queued records — or, in the draining iteration, whatever is left (the same code, so process() is instantiated once)
+        const bool last = base >= s_end;
         while (q_len >= 64u || (last && q_len)) {
             const uint32_t nq = min(q_len, 64u);
             process(nq);
@@ -443,22 +515,40 @@ seg_sum_kernel(const uint16_t *__restrict__ cnt, uint32_t C, uint32_t T, uint32_
     part[(size_t)sg * T + t] = s;
 }
 
-// one block: totals per tile (coalesced over tiles) -> exclusive scan -> tile_start[T+1]; counters[1] = total list length
+// one block: totals per tile -> exclusive scan -> tile_start[T+1]; counters[1] = total list length.  Every thread owns a
+// run of consecutive tiles (8 at 1600x1200), so the block scans ONCE over the 1024 run sums instead of once per 1024 tiles
+// (the serial chain of 8 block scans with their barriers was 15 us of a kernel that moves 0.5 MB).
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, uint32_t *__restrict__ tile_start,
                  uint32_t *__restrict__ counters) {
     __shared__ uint32_t wave_tot[17];
+    constexpr uint32_t MAXPER = 8;
+    const uint32_t per = (T + 1023u) / 1024u;
     uint32_t carry = 0u;
-    for (uint32_t base = 0; base < T; base += 1024) {
-        const uint32_t t = base + threadIdx.x;
-        uint32_t v = 0;
-        if (t < T) {
+    // (images beyond 8192 tiles: the same block makes several sweeps of 8192 tiles each)
+    for (uint32_t sweep0 = 0; sweep0 < T; sweep0 += 1024u * MAXPER) {
+        const uint32_t p = min(per, MAXPER), t0 = sweep0 + threadIdx.x * p;
+        uint32_t v[MAXPER];
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < MAXPER; i++) {
+            v[i] = 0;
+            const uint32_t t = t0 + i;
+            if (i < p && t < T && t < sweep0 + 1024u * MAXPER) {
+                uint32_t a = 0;
 #pragma unroll 16
-            for (uint32_t s = 0; s < nseg; s++) v += part[(size_t)s * T + t];
+                for (uint32_t sg = 0; sg < nseg; sg++) a += part[(size_t)sg * T + t];
+                v[i] = a;
+            }
+            sum += v[i];
         }
         uint32_t tot;
-        const uint32_t ex = block_exclusive_scan(v, wave_tot, tot);
-        if (t < T) tile_start[t] = carry + ex;
+        uint32_t run = carry + block_exclusive_scan(sum, wave_tot, tot);
+#pragma unroll
+        for (uint32_t i = 0; i < MAXPER; i++) {
+            const uint32_t t = t0 + i;
+            if (i < p && t < T && t < sweep0 + 1024u * MAXPER) { tile_start[t] = run; run += v[i]; }
+        }
         carry += tot;
     }
     if (threadIdx.x == 0) {
@@ -520,36 +610,40 @@ int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, ch
     uint32_t *vals[2] = {reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(scratch + L.s_vals1)};
     uint32_t *hist = reinterpret_cast<uint32_t *>(scratch + L.s_hist);
     uint32_t *rowtot = reinterpret_cast<uint32_t *>(scratch + L.s_rowtot);
-    const uint32_t *sorted_ids = vals[0], *sorted_keys = keys[0];
     if (L.P == 0) return W3D_OK;
+    uint32_t *minmax = reinterpret_cast<uint32_t *>(scratch + L.s_minmax);
     {
-        // ---- stable LSD radix sort of (depth bits, id), PASSES x BITS bits; culled Gaussians carry key 0xFFFFFFFF
+        // ---- stable LSD radix sort of (depth bits, id): 3 or 4 passes of 8 bits (radix_digit); culled Gaussians carry key
+        // 0xFFFFFFFF and are dropped by the first pass
         const uint32_t n = (uint32_t)L.P, runs = L.sort_waves, blocks = (runs + 3) / 4;
         int src = 0;
         W3D_PROF("depth_sort", stream);
         for (int pass = 0; pass < W3D_RADIX_PASSES; pass++) {
-            const int shift = W3D_RADIX_BITS * pass;
             // pass 0 reads all P keys, drops the culled ones and publishes V = counters[0]; passes 1.. sort V keys
             const uint32_t *n_dev = pass == 0 ? (const uint32_t *)nullptr : counters;
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], n, L.sort_items, runs, shift, hist,
-                               n_dev, pass == 0 ? 1 : 0);
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], n, L.sort_items, runs, pass, hist,
+                               n_dev, pass == 0 ? 1 : 0, counters, pass == 0 ? minmax : (uint32_t *)nullptr);
             W3D_LAUNCH_CHECK(v.debug, stream);
-            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(W3D_RADIX_BINS), dim3(256), 0, stream, hist, runs, rowtot);
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(W3D_RADIX_BINS), dim3(256), 0, stream, hist, runs, rowtot, pass, counters,
+                               minmax);
             W3D_LAUNCH_CHECK(v.debug, stream);
             hipLaunchKernelGGL(radix_scatter_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], vals[src], keys[src ^ 1],
-                               vals[src ^ 1], n, L.sort_items, runs, shift, hist, rowtot,
-                               pass == 0 ? counters : (uint32_t *)nullptr, n_dev);
+                               vals[src ^ 1], n, L.sort_items, runs, pass, hist, rowtot,
+                               pass == 0 ? counters : (uint32_t *)nullptr, n_dev, counters);
             W3D_LAUNCH_CHECK(v.debug, stream);
             src ^= 1;
         }
-        sorted_ids = vals[src];
-        sorted_keys = keys[src];
     }
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3((L.P + 255) / 256), dim3(256), 0, stream, sorted_ids, sorted_keys,
-                       reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint4 *>(state + L.o_tile_mask),
-                       counters, (uint32_t)L.P,
-                       reinterpret_cast<uint4 *>(scratch + L.s_rec),
-                       reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);
+    // four passes leave the result in buffer 0, three passes (the fourth exits at once) in buffer 1
+    {
+        W3D_PROF("gather_sorted", stream);
+        hipLaunchKernelGGL(gather_sorted_kernel, dim3((L.P + 255) / 256), dim3(256), 0, stream, vals[0], keys[0], vals[1], keys[1],
+                           reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint4 *>(state + L.o_tile_mask),
+                           counters, (uint32_t)L.P,
+                           reinterpret_cast<uint4 *>(scratch + L.s_rec),
+                           reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), reinterpret_cast<uint32_t *>(scratch + L.s_rec_rows),
+                           (int)v.tile_cull);
+    }
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;
 }
@@ -563,14 +657,15 @@ static void launch_walk(const W3DLayout &L, const w3d_view &v, char *state, char
     const size_t lds = (size_t)wave_bytes * W3D_WW;
     const uint4 *rec = reinterpret_cast<const uint4 *>(scratch + L.s_rec);
     const uint2 *rmask = reinterpret_cast<const uint2 *>(scratch + L.s_rec_mask);
+    const uint32_t *rrows = reinterpret_cast<const uint32_t *>(scratch + L.s_rec_rows);
     const uint32_t *counters = reinterpret_cast<const uint32_t *>(state + L.o_counters);
     uint16_t *cnt = reinterpret_cast<uint16_t *>(scratch + L.s_cnt);
     const uint32_t *off = reinterpret_cast<const uint32_t *>(scratch + L.s_off);
     if (v.tile_cull)
-        hipLaunchKernelGGL((chunk_walk_kernel<MODE, true>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C,
+        hipLaunchKernelGGL((chunk_walk_kernel<MODE, true>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, rrows, counters, L.chunk, L.C,
                            (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, wave_bytes);
     else
-        hipLaunchKernelGGL((chunk_walk_kernel<MODE, false>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C,
+        hipLaunchKernelGGL((chunk_walk_kernel<MODE, false>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, rrows, counters, L.chunk, L.C,
                            (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, wave_bytes);
 }
 

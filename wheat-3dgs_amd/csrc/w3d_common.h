@@ -30,6 +30,7 @@ struct W3DLayout {
     uint32_t seg;     // chunks per scan segment
     // ---- state buffer (kept until backward)
     uint64_t o_counters;   // u32[16]: [0]=num_visible [1]=num_rendered [3]=capacity of the list buffer given to stage 2
+                           //          [4]=(min depth key)>>16 [5]=1 if the depth sort needs three passes only (w3d_binning.hip)
     uint64_t o_xy;         // float2[P]
     uint64_t o_conic_op;   // float4[P]
     uint64_t o_rgbd;       // float4[P]  (r,g,b,depth)
@@ -45,10 +46,12 @@ struct W3DLayout {
     uint64_t s_keys0, s_keys1, s_vals0, s_vals1; // u32[P] each (depth keys, Gaussian ids)
     uint64_t s_hist;       // u32[BINS * sort_waves] radix digit histograms
     uint64_t s_rowtot;     // u32[BINS] per-digit totals of the current radix pass
+    uint64_t s_minmax;     // u32[2 * sort_waves] per-run min / max of the visible depth keys (first pass)
     uint64_t s_cnt;        // u16[C*T] per-chunk per-tile counts
     uint64_t s_off;        // u32[C*T] per-chunk per-tile list offsets
     uint64_t s_part;       // u32[SEGS*T]
     uint64_t s_rec, s_rec_mask; // uint4[P], uint2[P]: depth-ordered {id, rect} records and tile masks
+    uint64_t s_rec_rows;   // u32[P]: {first tile row, one past the last} of every depth-ordered record (the walkers' scan)
     uint64_t scratch_bytes;
     uint32_t sort_waves;   // waves used by the radix passes
     uint32_t sort_items;   // keys per wave per pass (multiple of 64)
@@ -97,11 +100,13 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->s_vals1 = o; o += w3d_align_up(Pp * 4);
     L->s_hist = o;  o += w3d_align_up((uint64_t)W3D_RADIX_BINS * L->sort_waves * 4);
     L->s_rowtot = o; o += w3d_align_up(W3D_RADIX_BINS * 4);
+    L->s_minmax = o; o += w3d_align_up((uint64_t)L->sort_waves * 8);
     L->s_cnt = o;   o += w3d_align_up((uint64_t)L->C * T * 2);
     L->s_off = o;   o += w3d_align_up((uint64_t)L->C * T * 4);
     L->s_part = o;  o += w3d_align_up((uint64_t)W3D_SCAN_SEGS * T * 4);
     L->s_rec = o;   o += w3d_align_up(Pp * 16);
     L->s_rec_mask = o; o += w3d_align_up(Pp * 8);
+    L->s_rec_rows = o; o += w3d_align_up(Pp * 4);
     L->scratch_bytes = o;
     return W3D_OK;
 }

@@ -285,6 +285,7 @@ extern "C" int w3d_l1_ssim_fwd_bwd(int32_t C, int32_t H, int32_t W, const float 
         return W3D_ERR_INVALID;
     }
     const LossBufs b = loss_bufs(C, H, W, scratch);
+    W3D_PROF("loss", stream);
     hipLaunchKernelGGL(ssim_pass_a, b.grid, dim3(LNT), 0, stream, H, W, image, gt, b.d_mu1, b.d_ex2, b.d_exy, b.sums, b.gw);
     W3D_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(1024), 0, stream, b.sums, (uint32_t)(b.grid.x * b.grid.y * b.grid.z), lambda_dssim,

@@ -438,6 +438,9 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         if (!(b >= 0 && i < maxc)) return 0xFFFFFFFFu;
         return point_list[min(start + i, cap - 1u)];
     };
+#ifdef W3D_BWD_STATS
+    uint32_t st_entries = 0, st_quads = 0, st_exp = 0, st_full = 0, st_staged = 0;
+#endif
     Staged nxt;
     {
         const uint32_t g = batch_id(nb - 1);
@@ -456,6 +459,9 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             if (myq != 0u && nxt.b.w > 0.99f) myq |= 16u;
         }
         const uint64_t todo_all = w3d_ballot(myq != 0u);
+#ifdef W3D_BWD_STATS
+        st_staged += n;
+#endif
         __builtin_amdgcn_wave_barrier();
         if (b > 0) {
             nxt = (ids != 0xFFFFFFFFu) ? gather_entry(ids, xy, conic_op, rgbd) : Staged{};
@@ -481,9 +487,15 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
 #pragma unroll
                 for (int i = 0; i < 10; i++) v[i] = 0.f;
                 bool any = false;
+#ifdef W3D_BWD_STATS
+                st_entries++;
+#endif
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if (!(qm & (1u << k))) continue;
+#ifdef W3D_BWD_STATS
+                    st_quads++;
+#endif
                     const float dx = ea.x - (pxb + (float)((k & 1) * 8)), dy = ea.y - (pyb + (float)((k >> 1) * 8));
                     const float power = fmaf(ed.z * dy, dy, fmaf(ed.y, dy, ed.x * dx) * dx);      // log2 domain
                     // (ballots of plain compares, ANDed as scalars — see the forward kernel)
@@ -495,6 +507,9 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                         cand = cand && idx0 < last[k];
                     }
                     if (mc == 0ull) continue;
+#ifdef W3D_BWD_STATS
+                    st_exp++;
+#endif
                     const float Graw = __builtin_amdgcn_exp2f(power);
                     float araw = ed.w * Graw;
                     if (qm & 16u) {                                    // wave-uniform: o <= 0.99 can never reach the cap
@@ -503,6 +518,9 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                     }
                     const uint64_t mk = mc & w3d_ballot(araw >= (1.0f / 255.0f));
                     if (mk == 0ull) continue;
+#ifdef W3D_BWD_STATS
+                    st_full++;
+#endif
                     any = true;                                        // wave-uniform: some lane blends this Gaussian
                     // Branch-free per lane: a lane that does not blend this Gaussian runs the same recurrences
                     // with alpha = G = 0, which leaves T and the suffix accumulators untouched and adds zeros.
@@ -608,6 +626,13 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             __builtin_amdgcn_wave_barrier();
         }
     }
+#ifdef W3D_BWD_STATS
+    if (lane == 0) {
+        uint32_t *cw = const_cast<uint32_t *>(counters);
+        atomicAdd(&cw[8], st_staged); atomicAdd(&cw[9], st_entries); atomicAdd(&cw[10], st_quads);
+        atomicAdd(&cw[11], st_exp); atomicAdd(&cw[12], st_full); atomicAdd(&cw[13], 1u);
+    }
+#endif
 }
 
 // Zeroes the 64-B gradient records of the VISIBLE Gaussians (an all-zero rect marks a culled one, whose record nobody
