@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--dropin-only", action="store_true",
                     help="run only the reference-loop measurement (for rocprofv3 --kernel-trace of that loop) and print its JSON")
     ap.add_argument("--no-extras", action="store_true", help="skip render / FlashSplat / drop-in / trained-scene measurements")
+    ap.add_argument("--trained-only", action="store_true",
+                    help="of the extra measurements keep only the trained-scene one (kernel A/B runs: profiles/ab_variants.sh)")
     ap.add_argument("--force-dist", action="store_true", help="1-rank RCCL group: exercises the exchange path on one GPU")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reporting test on CPU over gloo with a stub step (no kernels, no GPU); "
@@ -274,6 +276,10 @@ def cpu_baseline(args):
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     os.environ.setdefault("GOMP_SPINCOUNT", "0")
     _progress("cpu_baseline: C3 sample")
+    # torch's CPU loss: 16 threads (a 1600x1200 image is a fraction of a second of work; torch's pool on all 256 cores of the
+    # GPU box, next to the oracle's OpenMP team, took 10 s per call) — the rasterizer, the bulk of the work, gets every core
+    torch_threads0 = torch.get_num_threads()
+    torch.set_num_threads(min(cores, 16))
 
     def c_oracle_protocol(P, width, height, warm, timed, seed):
         sc = make_scene(P, seed=seed, **({} if P >= 100_000 else {"scale_mean": 0.012}))
@@ -304,12 +310,12 @@ def cpu_baseline(args):
     out = {"value": round(1.0 / s3, 5), "unit": "iters/s", "cores": cores, "kind": "port",
            "sample": f"render + 0.8*L1+0.2*(1-SSIM) + backward (the bracket of train_vanilla_3dgs.py:56,82; no Adam) of one "
                      f"{args.points}-Gaussian {args.width}x{args.height} view of the benchmark scene: C oracle (OpenMP over tiles, "
-                     f"{cores} threads) + torch CPU loss; 1 warm-up + 3 timed iterations, median {s3:.2f} s (forward {f3:.2f} s)",
+                     f"{cores} threads) + torch CPU loss ({min(cores, 16)} threads); 1 warm-up + 3 timed iterations, median {s3:.2f} s (forward {f3:.2f} s)",
            "render_mpix_per_s": round(args.width * args.height / 1e6 / f3, 4),
            "c1": {"workload": "C1: 10000 Gaussians, 400x300", "protocol": "3 warm-up + 10 timed, median, cameras cycled, seed 4",
                   "c_oracle_iters_per_s": round(1.0 / s1, 3), "c_oracle_render_mpix_per_s": round(0.12 / f1, 3)}}
     # the PyTorch restatement at C1 (BASELINE.md section 4 names it): float32 torch_render, backward by autograd
-    torch_threads = torch.get_num_threads()
+    torch_threads = torch_threads0
     try:
         from oracle.oracle import torch_render
         _progress("cpu_baseline: C1, PyTorch restatement")
@@ -538,7 +544,7 @@ def main():
         exchange["mode"] = trainer.exchange_mode if trainer.fused else "dense"
         exchange["selfcheck"] = selfcheck
         exchange["replicas_identical_after_timed_steps"] = replicas_identical(model, world, dev)
-    if not args.no_extras:
+    if not args.no_extras and not args.trained_only:
         _progress("extras: render / FlashSplat")
         # forward-only render throughput (reference render.py's use), same scene, views cycled
         n_r = max(4, min(args.steps, 36))
@@ -631,7 +637,7 @@ def main():
 
     # the UNMODIFIED reference loop body on the drop-in modules (single GPU: the reference is single-GPU)
     dropin = None
-    if not args.no_extras and world == 1 and not force_dist:
+    if not args.no_extras and not args.trained_only and world == 1 and not force_dist:
         _progress("drop-in loop")
         dropin = time_dropin(args, sc, cams, bg, dev, trainer.perm)
 

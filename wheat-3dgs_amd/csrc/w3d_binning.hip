@@ -228,7 +228,7 @@ gather_sorted_kernel(const uint32_t *__restrict__ ids4, const uint32_t *__restri
                      const uint32_t *__restrict__ ids3, const uint32_t *__restrict__ keys3,
                      const uint2 *__restrict__ rect, const uint4 *__restrict__ rect_mask,
                      const uint32_t *__restrict__ counters, uint32_t P,
-                     uint4 *__restrict__ rec, uint2 *__restrict__ rec_mask, uint32_t *__restrict__ rec_rows, int cull) {
+                     uint4 *__restrict__ rec, uint2 *__restrict__ rec_mask, int cull) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= P || s >= counters[0]) return;
     // the sorted (key, id) pairs sit in the buffer the LAST EXECUTED pass wrote: after three passes or after four
@@ -240,16 +240,11 @@ gather_sorted_kernel(const uint32_t *__restrict__ ids4, const uint32_t *__restri
         const uint4 b = rect_mask[g];                    // one 16-B record per Gaussian: a single random line
         rec[s] = make_uint4(g, b.x, b.y, depth_bits);
         rec_mask[s] = make_uint2(b.z, b.w);
-        rec_rows[s] = (b.x >> 16) | (b.y & 0xFFFF0000u);
     } else {
         const uint2 rc = rect[g];
         rec[s] = make_uint4(g, rc.x, rc.y, depth_bits);
         rec_mask[s] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        rec_rows[s] = (rc.x >> 16) | (rc.y & 0xFFFF0000u);
     }
-    // rec_rows = {first tile row, one past the last} in 4 bytes: a (chunk, band) walker decides from it alone whether a
-    // record concerns its band, and only then fetches the 24-B record — the bands re-stream every record (25 bands in the
-    // fill pass), and that scan ran at the L2's bandwidth with whole records (732 MB per fill at 1.2 M visible)
 }
 
 // One wave per (chunk, band of tile rows).  The wave streams the chunk's depth-ordered records, keeps the
@@ -268,13 +263,14 @@ gather_sorted_kernel(const uint32_t *__restrict__ ids4, const uint32_t *__restri
 #define W3D_WALK_SMALL 16
 #endif
 #define W3D_WALK_QUEUE 128
+
 #ifndef W3D_WW
 #define W3D_WW 4          // (chunk, band) waves per workgroup of the walk: the 4 band-waves of a chunk share its records in L1
                           // (measured fill: 1 wave 0.255 ms, 2 -> 0.198, 4 -> 0.172, 8 -> 0.202, 16 -> 0.234)
 #endif
 template <int MODE, bool CULL>
 __global__ void __launch_bounds__(64 * W3D_WW)
-chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_mask, const uint32_t *__restrict__ rec_rows,
+chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_mask,
                   const uint32_t *__restrict__ counters,
                   uint32_t chunk, uint32_t C, uint32_t T, uint32_t gx, uint32_t gy, uint32_t band_rows,
                   uint16_t *__restrict__ cnt, const uint32_t *__restrict__ off, uint32_t *__restrict__ point_list,
@@ -303,17 +299,19 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
     // the matrices for — all C chunk-waves of a band get work, each a 1/C-th of it
     chunk = min(chunk, max(64u, ((V + C - 1u) / C + 63u) & ~63u));
     const uint32_t s_beg = min(V, c * chunk), s_end = min(V, s_beg + chunk);
-    // The scan reads only the 4-B row spans of the chunk's records (NB batches of 64 in flight, requested before the LDS
-    // set-up below, which hides their latency); the 24-B record itself is fetched by the lanes whose record concerns this
-    // band — about one in eight — and lands in the ring one iteration later, so its latency overlaps the next span test.
-    constexpr int NB = 8;
-    uint32_t nx_rows[NB];
-    auto fetch_rows = [&](uint32_t from) -> uint32_t {
+    // the first records are requested before the LDS set-up below, which hides their latency; NB 64-record
+    // batches are kept in flight (rotating registers, so the loop body — and process() — exists once)
+    constexpr int NB = 4;
+    uint4 nx_rec[NB];
+    uint2 nx_mask[NB];
+    auto fetch_one = [&](uint32_t from, uint4 &r, uint2 &mk) {
         const uint32_t s = from + lane;
-        return s < s_end ? rec_rows[s] : 0u;          // (rows [0, 0): concerns no band)
+        r = make_uint4(0u, 0u, 0u, 0u);
+        mk = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (s < s_end) { r = rec[s]; if (CULL) mk = rec_mask[s]; }
     };
 #pragma unroll
-    for (int i = 0; i < NB; i++) nx_rows[i] = fetch_rows(s_beg + (uint32_t)i * 64u);
+    for (int i = 0; i < NB; i++) fetch_one(s_beg + (uint32_t)i * 64u, nx_rec[i], nx_mask[i]);
     if (MODE == 0) {
         for (uint32_t t = lane; t < Tbpad / 2; t += 64) h32[t] = 0;
     } else {
@@ -459,33 +457,26 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         __builtin_amdgcn_wave_barrier();
     };
 
-    uint4 pend_rec = make_uint4(0u, 0u, 0u, 0u);
-    uint2 pend_mask = make_uint2(0u, 0u);
-    bool pend_rel = false;
-    // (one iteration more than there are batches: it only commits the last batch's records and drains the ring)
-    for (uint32_t base = s_beg; base < s_end + 64u; base += 64u) {
-        const uint32_t cur_rows = nx_rows[0];
+    for (uint32_t base = s_beg; base < s_end; base += 64u) {
+        const uint32_t nb = min(64u, s_end - base);
+        const uint4 cur_rec = nx_rec[0];
+        const uint2 cur_mask = nx_mask[0];
 #pragma unroll
-        for (int i = 0; i + 1 < NB; i++) nx_rows[i] = nx_rows[i + 1];
-        nx_rows[NB - 1] = fetch_rows(base + 64u * NB);
+        for (int i = 0; i + 1 < NB; i++) { nx_rec[i] = nx_rec[i + 1]; nx_mask[i] = nx_mask[i + 1]; }
+        fetch_one(base + 64u * NB, nx_rec[NB - 1], nx_mask[NB - 1]);
         // rect reaches into this band?  (whether its tile mask does is settled when the record is binned)
-        const bool relevant = base + lane < s_end && (cur_rows & 0xFFFFu) < y1 && (cur_rows >> 16) > y0;
-        uint4 new_rec = make_uint4(0u, 0u, 0u, 0u);
-        uint2 new_mask = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (relevant) { new_rec = rec[base + lane]; if (CULL) new_mask = rec_mask[base + lane]; }
-        // the records requested in the previous iteration go into the ring now
-        const uint64_t bal = w3d_ballot(pend_rel);
+        const bool relevant = lane < nb && (cur_rec.y >> 16) < y1 && (cur_rec.z >> 16) > y0;
+        const uint64_t bal = w3d_ballot(relevant);
         if (bal) {
-            if (pend_rel) {
+            if (relevant) {
                 const uint32_t slot = (q_head + q_len + (uint32_t)__popcll(bal & lanemask_lt())) & (W3D_WALK_QUEUE - 1u);
-                qa[slot] = pend_rec; qb[slot] = pend_mask;
+                qa[slot] = cur_rec; qb[slot] = cur_mask;
             }
             q_len += (uint32_t)__popcll(bal);
             __builtin_amdgcn_wave_barrier();
         }
-        pend_rel = relevant; pend_rec = new_rec; pend_mask = new_mask;
-        // bin 64 queued records — or, in the draining iteration, whatever is left (the same code, so process() is instantiated once)
-        const bool last = base >= s_end;
+        // bin 64 queued records — or, after the last batch, whatever is left (the same code, so process() is instantiated once)
+        const bool last = base + 64u >= s_end;
         while (q_len >= 64u || (last && q_len)) {
             const uint32_t nq = min(q_len, 64u);
             process(nq);
@@ -515,41 +506,44 @@ seg_sum_kernel(const uint16_t *__restrict__ cnt, uint32_t C, uint32_t T, uint32_
     part[(size_t)sg * T + t] = s;
 }
 
-// one block: totals per tile -> exclusive scan -> tile_start[T+1]; counters[1] = total list length.  Every thread owns a
-// run of consecutive tiles (8 at 1600x1200), so the block scans ONCE over the 1024 run sums instead of once per 1024 tiles
-// (the serial chain of 8 block scans with their barriers was 15 us of a kernel that moves 0.5 MB).
+// one block: totals per tile -> exclusive scan -> tile_start[T+1]; counters[1] = total list length.  The totals of up to 8192
+// tiles are first summed COALESCED (thread <-> tile, all loads of a thread independent) into LDS; then every thread owns a run
+// of 8 consecutive tiles, so the block scans once over the 1024 run sums instead of once per 1024 tiles (the chain of
+// eight block scans with their barriers took 15 us to move 0.5 MB).
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, uint32_t *__restrict__ tile_start,
                  uint32_t *__restrict__ counters) {
+    constexpr uint32_t PER = 8, SPAN = 1024u * PER;
     __shared__ uint32_t wave_tot[17];
-    constexpr uint32_t MAXPER = 8;
-    const uint32_t per = (T + 1023u) / 1024u;
+    __shared__ uint32_t tot_s[SPAN];
     uint32_t carry = 0u;
-    // (images beyond 8192 tiles: the same block makes several sweeps of 8192 tiles each)
-    for (uint32_t sweep0 = 0; sweep0 < T; sweep0 += 1024u * MAXPER) {
-        const uint32_t p = min(per, MAXPER), t0 = sweep0 + threadIdx.x * p;
-        uint32_t v[MAXPER];
-        uint32_t sum = 0;
+    for (uint32_t sweep0 = 0; sweep0 < T; sweep0 += SPAN) {     // (one sweep up to 8192 tiles; 4K frames take several)
 #pragma unroll
-        for (uint32_t i = 0; i < MAXPER; i++) {
-            v[i] = 0;
-            const uint32_t t = t0 + i;
-            if (i < p && t < T && t < sweep0 + 1024u * MAXPER) {
-                uint32_t a = 0;
+        for (uint32_t i = 0; i < PER; i++) {
+            const uint32_t t = sweep0 + i * 1024u + threadIdx.x;
+            uint32_t a = 0;
+            if (t < T) {
 #pragma unroll 16
                 for (uint32_t sg = 0; sg < nseg; sg++) a += part[(size_t)sg * T + t];
-                v[i] = a;
             }
-            sum += v[i];
+            tot_s[i * 1024u + threadIdx.x] = a;
         }
+        __syncthreads();
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < PER; i++) { v[i] = tot_s[threadIdx.x * PER + i]; sum += v[i]; }
         uint32_t tot;
         uint32_t run = carry + block_exclusive_scan(sum, wave_tot, tot);
 #pragma unroll
-        for (uint32_t i = 0; i < MAXPER; i++) {
-            const uint32_t t = t0 + i;
-            if (i < p && t < T && t < sweep0 + 1024u * MAXPER) { tile_start[t] = run; run += v[i]; }
+        for (uint32_t i = 0; i < PER; i++) { tot_s[threadIdx.x * PER + i] = run; run += v[i]; }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t i = 0; i < PER; i++) {
+            const uint32_t t = sweep0 + i * 1024u + threadIdx.x;
+            if (t < T) tile_start[t] = tot_s[i * 1024u + threadIdx.x];
         }
         carry += tot;
+        __syncthreads();
     }
     if (threadIdx.x == 0) {
         tile_start[T] = carry;
@@ -641,8 +635,7 @@ int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, ch
                            reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint4 *>(state + L.o_tile_mask),
                            counters, (uint32_t)L.P,
                            reinterpret_cast<uint4 *>(scratch + L.s_rec),
-                           reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), reinterpret_cast<uint32_t *>(scratch + L.s_rec_rows),
-                           (int)v.tile_cull);
+                           reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);
     }
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;
@@ -657,15 +650,14 @@ static void launch_walk(const W3DLayout &L, const w3d_view &v, char *state, char
     const size_t lds = (size_t)wave_bytes * W3D_WW;
     const uint4 *rec = reinterpret_cast<const uint4 *>(scratch + L.s_rec);
     const uint2 *rmask = reinterpret_cast<const uint2 *>(scratch + L.s_rec_mask);
-    const uint32_t *rrows = reinterpret_cast<const uint32_t *>(scratch + L.s_rec_rows);
     const uint32_t *counters = reinterpret_cast<const uint32_t *>(state + L.o_counters);
     uint16_t *cnt = reinterpret_cast<uint16_t *>(scratch + L.s_cnt);
     const uint32_t *off = reinterpret_cast<const uint32_t *>(scratch + L.s_off);
     if (v.tile_cull)
-        hipLaunchKernelGGL((chunk_walk_kernel<MODE, true>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, rrows, counters, L.chunk, L.C,
+        hipLaunchKernelGGL((chunk_walk_kernel<MODE, true>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C,
                            (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, wave_bytes);
     else
-        hipLaunchKernelGGL((chunk_walk_kernel<MODE, false>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, rrows, counters, L.chunk, L.C,
+        hipLaunchKernelGGL((chunk_walk_kernel<MODE, false>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C,
                            (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, wave_bytes);
 }
 

@@ -51,7 +51,6 @@ struct W3DLayout {
     uint64_t s_off;        // u32[C*T] per-chunk per-tile list offsets
     uint64_t s_part;       // u32[SEGS*T]
     uint64_t s_rec, s_rec_mask; // uint4[P], uint2[P]: depth-ordered {id, rect} records and tile masks
-    uint64_t s_rec_rows;   // u32[P]: {first tile row, one past the last} of every depth-ordered record (the walkers' scan)
     uint64_t scratch_bytes;
     uint32_t sort_waves;   // waves used by the radix passes
     uint32_t sort_items;   // keys per wave per pass (multiple of 64)
@@ -106,7 +105,6 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->s_part = o;  o += w3d_align_up((uint64_t)W3D_SCAN_SEGS * T * 4);
     L->s_rec = o;   o += w3d_align_up(Pp * 16);
     L->s_rec_mask = o; o += w3d_align_up(Pp * 8);
-    L->s_rec_rows = o; o += w3d_align_up(Pp * 4);
     L->scratch_bytes = o;
     return W3D_OK;
 }
