@@ -261,42 +261,33 @@ def _median(xs):
 
 def cpu_baseline(args):
     """the oracle (kind "port": this repo's C restatement of the rasterizer, OpenMP over tiles, all host
-    cores) timed on this box beside the GPU number.  What is timed, with time.perf_counter, is the bracket of reference
-    train_vanilla_3dgs.py:56,82 — render + 0.8*L1 + 0.2*(1-SSIM) + backward (the loss and its gradient by torch on the
-    CPU; no Adam, as in that bracket) — and the forward alone (Mpix/s):
-      * `value`: ONE view of the benchmark's own C3 workload (a bounded sample: 1 warm-up + 3 timed iterations, median);
-      * `c1`: config C1 (10 k Gaussians, 400x300), 3 warm-up + 10 timed iterations, median — the C oracle and, next to
-        it, the PyTorch restatement (oracle.torch_render, float32, autograd backward)."""
+    cores) timed on this box beside the GPU number, with time.perf_counter:
+      * `value`: ONE view of the benchmark's own C3 workload — rasterizer forward + backward on a fixed dL/dcolor (the
+        rasterizer's share of the bracket of train_vanilla_3dgs.py:56,82; the loss is NOT in it: `bracket` says so) — a
+        bounded sample, 1 warm-up + 3 timed iterations, median;
+      * `c1`: config C1 (10 k Gaussians, 400x300), 3 warm-up + 10 timed iterations, median, cameras cycled — the C oracle
+        (rasterizer only) and, next to it, the PyTorch restatement (oracle.torch_render, float32, 16 threads) with the full
+        bracket: render + 0.8*L1 + 0.2*(1-SSIM) + backward by autograd."""
     import numpy as np
     from util import view_inputs, make_oracle, np_inputs
     from w3d_amd.synth import make_scene, make_cameras
     from w3d_amd.loss import photometric_loss_torch
     cores = os.cpu_count() or 1
-    # (the oracle brings its own OpenMP runtime next to torch's: neither may spin-wait on the other's cores)
-    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
-    os.environ.setdefault("GOMP_SPINCOUNT", "0")
     _progress("cpu_baseline: C3 sample")
-    # torch's CPU loss: 16 threads (a 1600x1200 image is a fraction of a second of work; torch's pool on all 256 cores of the
-    # GPU box, next to the oracle's OpenMP team, took 10 s per call) — the rasterizer, the bulk of the work, gets every core
-    torch_threads0 = torch.get_num_threads()
-    torch.set_num_threads(min(cores, 16))
 
     def c_oracle_protocol(P, width, height, warm, timed, seed):
         sc = make_scene(P, seed=seed, **({} if P >= 100_000 else {"scale_mean": 0.012}))
         cams = make_cameras(args.views, width, height)
-        g = torch.Generator().manual_seed(3)
-        gt = torch.rand(3, height, width, generator=g)
+        gc = np.random.RandomState(0).randn(3, height, width).astype(np.float32)
         fwd, step = [], []
         for i in range(warm + timed):
             cam = cams[i % len(cams)]                       # cameras cycled
             d = np_inputs(view_inputs(sc, cam))
             o = make_oracle(cam, (0.0, 0.0, 0.0), nthreads=cores)
             t0 = time.perf_counter()
-            out = o.forward(**d)
+            o.forward(**d)
             t1 = time.perf_counter()
-            img = torch.from_numpy(out["color"]).requires_grad_(True)
-            photometric_loss_torch(img, gt, 0.2).backward()
-            o.backward(img.grad.numpy(), None, None)
+            o.backward(gc, None, None)
             t2 = time.perf_counter()
             o.free()
             if i >= warm:
@@ -308,14 +299,16 @@ def cpu_baseline(args):
     _progress("cpu_baseline: C1, C oracle")
     f1, s1 = c_oracle_protocol(10_000, 400, 300, 3, 10, 4)
     out = {"value": round(1.0 / s3, 5), "unit": "iters/s", "cores": cores, "kind": "port",
-           "sample": f"render + 0.8*L1+0.2*(1-SSIM) + backward (the bracket of train_vanilla_3dgs.py:56,82; no Adam) of one "
-                     f"{args.points}-Gaussian {args.width}x{args.height} view of the benchmark scene: C oracle (OpenMP over tiles, "
-                     f"{cores} threads) + torch CPU loss ({min(cores, 16)} threads); 1 warm-up + 3 timed iterations, median {s3:.2f} s (forward {f3:.2f} s)",
+           "bracket": "rasterizer forward + backward only (no loss, no Adam)",
+           "sample": f"one {args.points}-Gaussian {args.width}x{args.height} view of the benchmark scene through the C oracle (OpenMP "
+                     f"over tiles, {cores} threads), fixed dL/dcolor; 1 warm-up + 3 timed iterations, median {s3:.2f} s "
+                     f"(forward {f3:.2f} s)",
            "render_mpix_per_s": round(args.width * args.height / 1e6 / f3, 4),
            "c1": {"workload": "C1: 10000 Gaussians, 400x300", "protocol": "3 warm-up + 10 timed, median, cameras cycled, seed 4",
-                  "c_oracle_iters_per_s": round(1.0 / s1, 3), "c_oracle_render_mpix_per_s": round(0.12 / f1, 3)}}
-    # the PyTorch restatement at C1 (BASELINE.md section 4 names it): float32 torch_render, backward by autograd
-    torch_threads = torch_threads0
+                  "c_oracle_iters_per_s": round(1.0 / s1, 3), "c_oracle_render_mpix_per_s": round(0.12 / f1, 3),
+                  "c_oracle_bracket": "rasterizer forward + backward only"}}
+    # the PyTorch restatement at C1 (BASELINE.md section 4 names it): float32 torch_render, loss, backward by autograd
+    torch_threads = torch.get_num_threads()
     try:
         from oracle.oracle import torch_render
         _progress("cpu_baseline: C1, PyTorch restatement")
@@ -339,6 +332,7 @@ def cpu_baseline(args):
                 step.append(t2 - t0)
         out["c1"].update(torch_restatement_iters_per_s=round(1.0 / _median(step), 3),
                          torch_restatement_render_mpix_per_s=round(0.12 / _median(fwd), 3),
+                         torch_restatement_bracket="render + 0.8*L1+0.2*(1-SSIM) + backward (train_vanilla_3dgs.py:56,82)",
                          torch_restatement_protocol=f"1 warm-up + 3 timed, median; {min(cores, 16)} torch threads (a per-tile Python "
                                                     "loop of small tensor ops: seconds per view)")
     except Exception as e:      # the baseline leg must never take the bench line down
@@ -671,8 +665,8 @@ def main():
             """Algorithmic HBM bytes per launch of every stage (what the stage must read and write once)."""
             return {
                 "preprocess_fwd": 236.0 * P + 64.0 * V,              # parameters read; packed per-visible records written
-                "depth_sort": 4 * 16.0 * P,                            # 4 passes x (key, id) read + written
-                "gather_sorted": 8.0 * V + 16.0 * V + 24.0 * V,        # sorted (key, id) + rect/mask gather -> 24-B records
+                # first pass reads P (key, id) pairs, the others V; the last writes 24-B records from a 16-B rect/mask gather
+                "depth_sort": 8.0 * P + 8.0 * V + 2 * 16.0 * V + (8.0 + 16.0 + 24.0) * V,
                 "tile_count_scan": 24.0 * V,                           # the records, once
                 "fill_lists": 24.0 * V + 4.0 * R,                      # the records once + the lists
                 "render_fwd": 48.0 * Rw + 36.0 * HW,                   # 4-B id + 44-B gather per walked instance; image + aux
@@ -688,7 +682,7 @@ def main():
             kb = kernel_bytes(V, R, Rw)
             pmc_name = {"preprocess_fwd": "preprocess_fwd_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
                         "render_fwd": "render_fwd_kernel", "render_bwd": "render_bwd_kernel", "fill_lists": "chunk_walk_kernel<1",
-                        "gather_sorted": "gather_sorted_kernel", "loss": "l1_ssim", "depth_sort": "radix_", "tile_count_scan": "chunk_walk_kernel<0"}
+                        "loss": "l1_ssim", "depth_sort": "radix_", "tile_count_scan": "chunk_walk_kernel<0"}
             rows = []
             for k, ms in sorted(stage_ms.items(), key=lambda kv: -kv[1]):
                 if k not in kb:

@@ -152,18 +152,26 @@ radix_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t n_runs, uint32_t *__r
     if (threadIdx.x == 0) rowtot[blockIdx.x] = carry;
 }
 
+// CAN_FINAL (passes 2 and 3): the pass that turns out to be the LAST one — the third when three suffice, else the fourth —
+// does not write (key, id) pairs any more but the depth-ordered packed records {id, rect lo, rect hi, depth} + tile mask the
+// (chunk, band) walkers stream (they re-read their chunk once per band and per pass: coalesced records instead of gathers).
+// The 16-B rect / mask line of every Gaussian is gathered one batch ahead of the ranking, the (key, id) pairs two ahead.
+template <bool CAN_FINAL>
 __global__ void __launch_bounds__(256)
 radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                      uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t items,
                      uint32_t n_runs, int pass, const uint32_t *__restrict__ offs /* row-scanned [256][n_runs] */,
                      const uint32_t *__restrict__ rowtot /* [BINS] */, uint32_t *__restrict__ num_visible,
-                     const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ ctl) {
+                     const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ ctl,
+                     const uint2 *__restrict__ rect, const uint4 *__restrict__ rect_mask, uint4 *__restrict__ rec,
+                     uint2 *__restrict__ rec_mask, int cull) {
     __shared__ uint32_t cur_all[4][W3D_RADIX_BINS];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
     if (run >= n_runs) return;
     if (pass == 3 && ctl[W3D_CTL_THREE]) return;
     const uint32_t three = pass >= 2 ? ctl[W3D_CTL_THREE] : 0u, kmin_hi = pass >= 2 ? ctl[W3D_CTL_KMIN_HI] : 0u;
+    const bool fin = CAN_FINAL && (pass == 3 || three != 0u);
     const int shift = W3D_RADIX_BITS * pass;
     // num_visible != NULL: FIRST pass — culled Gaussians (key 0xFFFFFFFF) are dropped and the number of survivors is
     // published; n_dev != NULL: later pass over those survivors only (same re-partition as radix_hist_kernel)
@@ -194,14 +202,26 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
     __builtin_amdgcn_wave_barrier();
     const uint32_t beg = min(n, run * items), end = min(n, beg + items);
     const uint64_t lt = lanemask_lt();
-    // software pipeline: the next 64 (key, id) pairs are in flight while the current ones are ranked
-    uint32_t nkey = (beg + lane < end) ? keys_in[beg + lane] : 0u;
-    uint32_t nval = (beg + lane < end) ? vals_in[beg + lane] : 0u;
+    auto gather = [&](uint32_t g) -> uint4 {
+        if (cull) return rect_mask[g];                   // one 16-B record per Gaussian: a single random line
+        const uint2 rc = rect[g];
+        return make_uint4(rc.x, rc.y, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    };
+    // software pipeline: the (key, id) pairs of the next two batches and the rect line of the next batch are in flight while
+    // the current batch is ranked
+    uint32_t k1 = (beg + lane < end) ? keys_in[beg + lane] : 0u, v1 = (beg + lane < end) ? vals_in[beg + lane] : 0u;
+    uint32_t k2 = (beg + 64 + lane < end) ? keys_in[beg + 64 + lane] : 0u, v2 = (beg + 64 + lane < end) ? vals_in[beg + 64 + lane] : 0u;
+    uint4 g1 = make_uint4(0u, 0u, 0u, 0u);
+    if (CAN_FINAL && fin && beg + lane < end) g1 = gather(v1);
     for (uint32_t base = beg; base < end; base += 64) {
         const uint32_t i = base + lane;
-        const uint32_t key = nkey, val = nval;
+        const uint32_t key = k1, val = v1;
+        const uint4 gg = g1;
         const bool valid = i < end && !(drop_invalid && key == W3D_INVALID_KEY);
-        if (i + 64 < end) { nkey = keys_in[i + 64]; nval = vals_in[i + 64]; }
+        k1 = k2; v1 = v2;
+        k2 = 0u; v2 = 0u;
+        if (i + 128 < end) { k2 = keys_in[i + 128]; v2 = vals_in[i + 128]; }
+        if (CAN_FINAL && fin && i + 64 < end) g1 = gather(v1);
         const uint32_t d = (three ? (key >> 16) - kmin_hi : (key >> shift)) & (W3D_RADIX_BINS - 1u);
         // lanes holding the same digit (stable rank = number of such lanes below me)
         uint64_t peers = w3d_ballot(valid);
@@ -216,37 +236,18 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
         __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) cur[d] = pos + (uint32_t)__popcll(peers);   // group leader advances the cursor
         __builtin_amdgcn_wave_barrier();
-        if (valid) { keys_out[pos] = key; vals_out[pos] = val; }
+        if (valid) {
+            if (CAN_FINAL && fin) {
+                rec[pos] = make_uint4(val, gg.x, gg.y, key);          // (the sort key IS the view depth)
+                rec_mask[pos] = make_uint2(gg.z, gg.w);
+            } else {
+                keys_out[pos] = key; vals_out[pos] = val;
+            }
+        }
     }
 }
 
 // ------------------------------------------------------------------------------ tile counting
-// Depth-ordered packed records {id, rect lo, rect hi, depth} + tile mask, so that the (chunk, band) walkers —
-// which re-read their chunk once per band and per pass — stream them coalesced instead of gathering.
-__global__ void __launch_bounds__(256)
-gather_sorted_kernel(const uint32_t *__restrict__ ids4, const uint32_t *__restrict__ keys4,
-                     const uint32_t *__restrict__ ids3, const uint32_t *__restrict__ keys3,
-                     const uint2 *__restrict__ rect, const uint4 *__restrict__ rect_mask,
-                     const uint32_t *__restrict__ counters, uint32_t P,
-                     uint4 *__restrict__ rec, uint2 *__restrict__ rec_mask, int cull) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= P || s >= counters[0]) return;
-    // the sorted (key, id) pairs sit in the buffer the LAST EXECUTED pass wrote: after three passes or after four
-    const bool three = counters[W3D_CTL_THREE] != 0u;
-    const uint32_t *__restrict__ sorted_ids = three ? ids3 : ids4, *__restrict__ sorted_keys = three ? keys3 : keys4;
-    const uint32_t g = sorted_ids[s];
-    const uint32_t depth_bits = sorted_keys[s];          // the sort key IS the view depth (for the depth cuts): no gather
-    if (cull) {
-        const uint4 b = rect_mask[g];                    // one 16-B record per Gaussian: a single random line
-        rec[s] = make_uint4(g, b.x, b.y, depth_bits);
-        rec_mask[s] = make_uint2(b.z, b.w);
-    } else {
-        const uint2 rc = rect[g];
-        rec[s] = make_uint4(g, rc.x, rc.y, depth_bits);
-        rec_mask[s] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-    }
-}
-
 // One wave per (chunk, band of tile rows).  The wave streams the chunk's depth-ordered records, keeps the
 // ones whose rect reaches into its band (about one in eight) in a 128-entry LDS ring, and whenever 64 are
 // queued it bins all 64 AT ONCE, one record per lane:
@@ -621,21 +622,17 @@ int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, ch
             hipLaunchKernelGGL(radix_rowscan_kernel, dim3(W3D_RADIX_BINS), dim3(256), 0, stream, hist, runs, rowtot, pass, counters,
                                minmax);
             W3D_LAUNCH_CHECK(v.debug, stream);
-            hipLaunchKernelGGL(radix_scatter_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], vals[src], keys[src ^ 1],
-                               vals[src ^ 1], n, L.sort_items, runs, pass, hist, rowtot,
-                               pass == 0 ? counters : (uint32_t *)nullptr, n_dev, counters);
+#define SCATTER_ARGS                                                                                                          \
+    keys[src], vals[src], keys[src ^ 1], vals[src ^ 1], n, L.sort_items, runs, pass, hist, rowtot,                            \
+        pass == 0 ? counters : (uint32_t *)nullptr, n_dev, counters, reinterpret_cast<const uint2 *>(state + L.o_rect),       \
+        reinterpret_cast<const uint4 *>(state + L.o_tile_mask), reinterpret_cast<uint4 *>(scratch + L.s_rec),                 \
+        reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull
+            if (pass >= 2) hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(blocks), dim3(256), 0, stream, SCATTER_ARGS);
+            else hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(blocks), dim3(256), 0, stream, SCATTER_ARGS);
+#undef SCATTER_ARGS
             W3D_LAUNCH_CHECK(v.debug, stream);
             src ^= 1;
         }
-    }
-    // four passes leave the result in buffer 0, three passes (the fourth exits at once) in buffer 1
-    {
-        W3D_PROF("gather_sorted", stream);
-        hipLaunchKernelGGL(gather_sorted_kernel, dim3((L.P + 255) / 256), dim3(256), 0, stream, vals[0], keys[0], vals[1], keys[1],
-                           reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint4 *>(state + L.o_tile_mask),
-                           counters, (uint32_t)L.P,
-                           reinterpret_cast<uint4 *>(scratch + L.s_rec),
-                           reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);
     }
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;

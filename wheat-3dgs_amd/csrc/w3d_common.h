@@ -41,6 +41,8 @@ struct W3DLayout {
     uint64_t o_tile_start; // u32[T+1]
     uint64_t o_final_T;    // float[HW]
     uint64_t o_n_contrib;  // u32[HW]
+    uint64_t o_tile_walk;  // u32[T]: entries of the tile's list the forward blended at all (max n_contrib of its pixels)
+    uint64_t o_tile_order; // u32[8 * ceil(T / 8)]: the blend backward's block -> tile map (longest walks first within each XCD)
     uint64_t state_bytes;
     // ---- scratch buffer (forward temporaries)
     uint64_t s_keys0, s_keys1, s_vals0, s_vals1; // u32[P] each (depth keys, Gaussian ids)
@@ -84,6 +86,8 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->o_tile_start = o; o += w3d_align_up((T + 1) * 4);
     L->o_final_T = o;    o += w3d_align_up(HW * 4);
     L->o_n_contrib = o;  o += w3d_align_up(HW * 4);
+    L->o_tile_walk = o;  o += w3d_align_up(T * 4);
+    L->o_tile_order = o; o += w3d_align_up((T + 7) / 8 * 8 * 4);
     L->state_bytes = o;
     // radix sort geometry: one wave per contiguous run of sort_items keys
     const uint64_t max_runs = 1024;              // one wave per SIMD (measured at P = 2 M: 512 runs 0.216 ms, 1024 0.161, 2048 0.177, 4096 0.214)

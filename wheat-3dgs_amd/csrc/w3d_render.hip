@@ -25,6 +25,12 @@ namespace {
 #define W3D_RW 1          // tile-waves per workgroup of the blend kernels: 7500 one-wave workgroups balance better over 256 CUs
                           // than 1875 four-wave ones (blend backward 0.538 -> 0.518 ms; 2 waves: 0.525)
 #endif
+#ifndef W3D_TILE_ORDER_FWD
+#define W3D_TILE_ORDER_FWD 0
+#endif
+#ifndef W3D_TILE_ORDER
+#define W3D_TILE_ORDER 1  // blend backward: every XCD takes its tiles longest walk first (tile_order_kernel)
+#endif
 #define LOG2E 1.4426950408889634f
 #define W3D_FLASH_LABELS 4     // FlashSplat: labels per tile that take the LDS row-sum path (more: one wave reduction per label and entry)
 #define W3D_ACC_SLOTS 128      // backward: (entry of a 32-entry half batch) x (16-lane row) slots per accumulated value
@@ -61,13 +67,15 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 
 // wave index -> tile index, keeping each XCD's tiles contiguous (blocks are dealt round-robin
 // over the 8 XCDs; speed only, never correctness).
-__device__ __forceinline__ uint32_t wave_to_tile(uint32_t T, uint32_t &tile) {
+__device__ __forceinline__ uint32_t wave_to_tile(uint32_t T, uint32_t &tile, const uint32_t *__restrict__ order = nullptr) {
     const uint32_t nblocks = gridDim.x;
     const uint32_t b = blockIdx.x;
     const uint32_t per_xcd = (nblocks + 7) / 8;
     const uint32_t logical_block = (b & 7u) * per_xcd + (b >> 3);
     // (an SGPR: the per-tile loads become scalar loads and every loop bound derived from them stays scalar)
     tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(logical_block * W3D_RW + (threadIdx.x >> 6)));
+    // `order` (blend backward): a permutation of each XCD's own tile range, longest walks first (tile_order_kernel)
+    if (order) tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)order[tile]);
     return tile < T;
 }
 
@@ -144,13 +152,14 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_alpha,
                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                   const float *__restrict__ gt_mask, int num_obj, int P, float *__restrict__ used_count,
-                  int32_t *__restrict__ contrib_num, uint32_t list_cap, uint32_t *__restrict__ counters) {
+                  int32_t *__restrict__ contrib_num, uint32_t list_cap, uint32_t *__restrict__ counters,
+                  uint32_t *__restrict__ tile_walk, const uint32_t *__restrict__ tile_order) {
     __shared__ StagedLDS lds[W3D_RW];
     __shared__ int s_labels[W3D_RW][FLASH ? 256 : 1];
     // FlashSplat: row sums of the per-entry, per-label weights of the current batch: [label slot][entry][16-lane row]
     __shared__ __align__(16) float s_facc[W3D_RW][FLASH ? W3D_FLASH_LABELS * 64 * 4 : 4];
     uint32_t tile;
-    if (!wave_to_tile(T, tile)) return;
+    if (!wave_to_tile(T, tile, tile_order)) return;
     // the list buffer may be smaller than the lists (speculative sizing, see w3d_forward_stage2): never read
     // past it; the capacity is published for the backward pass
     if (tile == 0 && (threadIdx.x & 63) == 0) counters[3] = list_cap;
@@ -296,6 +305,11 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     }
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const size_t HW = (size_t)H * W;
+    {
+        // how far into its list this tile blended anything: the length of the backward's reverse walk (its work)
+        const uint32_t m = wave_max_u32(max(max(last[0], last[1]), max(last[2], last[3])));
+        if (lane == 0) tile_walk[tile] = m;
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (inside[k]) {
@@ -369,7 +383,8 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                   const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
                   const float *__restrict__ dL_dalpha_px, float *__restrict__ grad2d,
-                  const uint32_t *__restrict__ counters, float *__restrict__ inst, uint32_t inst_cap) {
+                  const uint32_t *__restrict__ counters, float *__restrict__ inst, uint32_t inst_cap,
+                  const uint32_t *__restrict__ tile_order) {
     constexpr int NV = HAS_DA ? 10 : 9;
     __shared__ StagedLDS lds[W3D_RW];
     // row sums of the current half batch: acc[value][entry * 4 + row].  Every (entry, row) slot is written exactly once
@@ -377,7 +392,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     // on one address occupies the CU's LDS for ~15 cycles, nine of them per entry cost more than the entry's arithmetic)
     __shared__ __align__(16) float acc_all[W3D_RW][NV * W3D_ACC_SLOTS];
     uint32_t tile;
-    if (!wave_to_tile(T, tile)) return;
+    if (!wave_to_tile(T, tile, tile_order)) return;
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     StagedLDS &s = lds[wv];
     float *acc = acc_all[wv];
@@ -690,6 +705,64 @@ det_gather_kernel(int P, int gx, const uint2 *__restrict__ rect, const uint4 *__
     out[2] = make_float4(sum[8], sum[9], 0.f, 0.f);
 }
 
+// Block -> tile map of the blend backward.  Its waves differ a lot in length (the reverse walk of a tile is as long as the
+// forward got into its list), the chip holds only 4096 of the 7500 tile-waves at once, and whatever starts last finishes
+// last: with tiles in image order the kernel ends on a tail of half-empty SIMDs.  So every XCD processes ITS OWN contiguous
+// range of tiles (the L2 locality of the static map stays) longest walks first: a stable counting sort of the range by a
+// 6-bit quantised walk length — neighbours of similar length stay neighbours.  One workgroup per XCD; frames with more than
+// 1024 tiles per XCD keep the image order.
+__global__ void __launch_bounds__(1024)
+tile_order_kernel(const uint32_t *__restrict__ tile_walk, const uint32_t *__restrict__ tile_start, uint32_t T, uint32_t per_xcd,
+                  uint32_t *__restrict__ order) {
+    __shared__ uint32_t hist[16][64];
+    __shared__ uint32_t base_s[16][64];
+    __shared__ uint32_t red[16];
+    const uint32_t x = blockIdx.x, t0 = x * per_xcd, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (per_xcd > 1024u) {
+        for (uint32_t i = threadIdx.x; i < per_xcd; i += 1024u) order[t0 + i] = t0 + i;
+        return;
+    }
+    const uint32_t i = threadIdx.x;
+    const bool valid = i < per_xcd && t0 + i < T;
+    // work of a tile: the walk length the forward recorded (backward), or — before the forward has run — its list length
+    const uint32_t w = !valid ? 0u : (tile_start ? tile_start[t0 + i + 1] - tile_start[t0 + i] : tile_walk[t0 + i]);
+    uint32_t m = wave_max_u32(w);
+    if (lane == 0) red[wv] = m;
+    for (uint32_t b = lane; b < 64; b += 64) hist[wv][b] = 0;
+    __syncthreads();
+    uint32_t wmax = 1u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) wmax = max(wmax, red[k]);
+    // bucket 0 = longest; tiles past the end of the image (padding of the last XCD) go last
+    const uint32_t q = valid ? 63u - min(63u, (uint32_t)(((uint64_t)w * 64u) / ((uint64_t)wmax + 1u))) : 63u;
+    uint64_t peers = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 6; b++) {
+        const uint64_t mb = w3d_ballot((q >> b) & 1u);
+        peers &= ((q >> b) & 1u) ? mb : ~mb;
+    }
+    const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
+    if (rank == 0) hist[wv][q] = (uint32_t)__popcll(peers);
+    __syncthreads();
+    if (wv == 0) {
+        // lane = bucket: totals over the 16 waves, exclusive scan over the buckets, then the per-wave bases
+        uint32_t tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) tot += hist[k][lane];
+        uint32_t incl = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+            if ((int)lane >= off) incl += up;
+        }
+        uint32_t run = incl - tot;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { base_s[k][lane] = run; run += hist[k][lane]; }
+    }
+    __syncthreads();
+    if (i < per_xcd) order[t0 + base_s[wv][q] + rank] = t0 + i;
+}
+
 __global__ void copy_pixel_state_kernel(const float *__restrict__ fT, const uint32_t *__restrict__ nc, size_t n,
                                         float *__restrict__ fT_out, uint32_t *__restrict__ nc_out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -709,13 +782,20 @@ int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const 
     blocks = (blocks + 7) / 8 * 8;   // the XCD-contiguous map needs a multiple of 8 blocks
     const bool flash = (gt_mask != nullptr) || (used_count != nullptr) || (contrib_num != nullptr);
     const uint32_t *ts = reinterpret_cast<const uint32_t *>(state + L.o_tile_start);
+    uint32_t *order = nullptr;
+#if W3D_TILE_ORDER_FWD
+    if (W3D_RW == 1) {       // (the forward does not know its walk lengths yet: the list lengths stand in for them)
+        order = reinterpret_cast<uint32_t *>(state + L.o_tile_order);
+        hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, stream, (const uint32_t *)nullptr, ts, T, blocks / 8, order);
+    }
+#endif
 #define ARGS                                                                                                          \
     T, (uint32_t)L.gx, L.W, L.H, ts, point_list,                                                                      \
         reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_conic_op),     \
         reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg, out_color, out_depth, out_alpha,                    \
         reinterpret_cast<float *>(state + L.o_final_T), reinterpret_cast<uint32_t *>(state + L.o_n_contrib), gt_mask, \
         num_obj, L.P, used_count, contrib_num, (uint32_t)(list_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : list_capacity),      \
-        reinterpret_cast<uint32_t *>(state + L.o_counters)
+        reinterpret_cast<uint32_t *>(state + L.o_counters), reinterpret_cast<uint32_t *>(state + L.o_tile_walk), order
     {
         W3D_PROF("render_fwd", stream);
         if (flash) hipLaunchKernelGGL((render_fwd_kernel<true>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
@@ -733,6 +813,15 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
     uint32_t blocks = (T + W3D_RW - 1) / W3D_RW;
     blocks = (blocks + 7) / 8 * 8;
     const bool det = v.deterministic != 0;
+    // block -> tile map: longest reverse walks first within every XCD's range (tile_order_kernel)
+    uint32_t *order = nullptr;
+#if W3D_TILE_ORDER
+    if (W3D_RW == 1) {
+        order = reinterpret_cast<uint32_t *>(const_cast<char *>(state) + L.o_tile_order);
+        hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, stream,
+                           reinterpret_cast<const uint32_t *>(state + L.o_tile_walk), (const uint32_t *)nullptr, T, blocks / 8, order);
+    }
+#endif
     // deterministic mode: [P records][det_list_capacity slots] in the scratch buffer (w3d_backward_det_sizes)
     float *inst = nullptr;
     uint32_t inst_cap = 0;
@@ -754,7 +843,7 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
         reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_conic_op), \
         reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg,                                                 \
         reinterpret_cast<const float *>(state + L.o_final_T), reinterpret_cast<const uint32_t *>(state + L.o_n_contrib), \
-        dL_dcolor, dL_ddepth, dL_dalpha, grad2d, reinterpret_cast<const uint32_t *>(state + L.o_counters), inst, inst_cap
+        dL_dcolor, dL_ddepth, dL_dalpha, grad2d, reinterpret_cast<const uint32_t *>(state + L.o_counters), inst, inst_cap, order
     {
         W3D_PROF("render_bwd", stream);
         const bool da = dL_ddepth || dL_dalpha;
