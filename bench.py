@@ -538,6 +538,11 @@ def main():
         exchange["mode"] = trainer.exchange_mode if trainer.fused else "dense"
         exchange["selfcheck"] = selfcheck
         exchange["replicas_identical_after_timed_steps"] = replicas_identical(model, world, dev)
+        # one boolean for the driver: the replicas were bit-identical after the warm-up (or after the dense fallback) AND
+        # after the timed steps — nothing re-synchronises them, so this is the proof that the exchange is correct on the links
+        exchange["selfcheck_ok"] = bool((selfcheck["replicas_identical_after_warmup"] or
+                                         selfcheck.get("replicas_identical_after_fallback", False)) and
+                                        exchange["replicas_identical_after_timed_steps"])
     if not args.no_extras and not args.trained_only:
         _progress("extras: render / FlashSplat")
         # forward-only render throughput (reference render.py's use), same scene, views cycled

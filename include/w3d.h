@@ -87,6 +87,11 @@ typedef struct w3d_view {
                               * adds its slots in ascending tile order: bit-identical gradients run to run (the sanitizer
                               * mode of SURVEY.md section 5).  Needs scratch of w3d_backward_det_sizes() bytes. */
     uint64_t det_list_capacity; /* deterministic = 1: entries of point_list (= the capacity stage 2 was given) */
+    uint32_t *tile_walk_hint;   /* device, u32[tiles], nullable; speed only, never results.  The blend forward runs the tiles of
+                                 * every XCD longest first, and how long a tile takes — how far into its list it blends before
+                                 * its pixels saturate — is only known afterwards; a training loop renders the same camera again
+                                 * and again, so the caller may keep one such array per camera: stage 2 orders its tiles by the
+                                 * values it finds (zeros: image order) and overwrites them with this render's walk lengths. */
 } w3d_view;
 
 int w3d_version(void);

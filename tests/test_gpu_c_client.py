@@ -15,7 +15,11 @@ CLIENT = os.path.join(ROOT, "tests", "c_client", "_bin", "w3d_c_client")
 
 
 def test_plain_c_host_gets_the_same_bits_as_the_python_binding(tmp_path):
-    if not os.path.exists(CLIENT):          # (normally built by __graft_entry__.build(); gcc is part of the image)
+    src = os.path.join(ROOT, "tests", "c_client", "w3d_c_client.c")
+    hdr = os.path.join(ROOT, "include", "w3d.h")
+    # (normally built by __graft_entry__.build(); gcc is part of the image.  A binary older than the header it was compiled
+    #  against has the wrong struct layout: rebuild)
+    if not os.path.exists(CLIENT) or os.path.getmtime(CLIENT) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         import sys
         sys.path.insert(0, ROOT)
         import __graft_entry__

@@ -586,7 +586,13 @@ __global__ void copy_ranges_kernel(const uint32_t *__restrict__ tile_start, uint
 struct W3DBands { uint32_t rows, count, tbpad; };
 W3DBands w3d_pick_bands(const W3DLayout &L, int mode) {
     W3DBands b;
-    uint32_t band_tiles = mode == 0 ? 1024u : 320u;  // tiles per band (the fill pass holds 12 B of LDS per tile, the count pass 2 B;
+#ifndef W3D_COUNT_BAND_TILES
+#define W3D_COUNT_BAND_TILES 1024u
+#endif
+#ifndef W3D_FILL_BAND_TILES
+#define W3D_FILL_BAND_TILES 320u
+#endif
+    uint32_t band_tiles = mode == 0 ? W3D_COUNT_BAND_TILES : W3D_FILL_BAND_TILES;  // tiles per band (the fill pass holds 12 B of LDS per tile, the count pass 2 B;
                                                      // measured fill at 1600x1200: 200 -> 0.188 ms, 300 -> 0.171, 500 -> 0.179, 700 -> 0.193)
     uint32_t rows = band_tiles / (uint32_t)L.gx;
     if (rows < 1) rows = 1;

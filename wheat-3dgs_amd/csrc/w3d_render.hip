@@ -25,9 +25,6 @@ namespace {
 #define W3D_RW 1          // tile-waves per workgroup of the blend kernels: 7500 one-wave workgroups balance better over 256 CUs
                           // than 1875 four-wave ones (blend backward 0.538 -> 0.518 ms; 2 waves: 0.525)
 #endif
-#ifndef W3D_TILE_ORDER_FWD
-#define W3D_TILE_ORDER_FWD 0
-#endif
 #ifndef W3D_TILE_ORDER
 #define W3D_TILE_ORDER 1  // blend backward: every XCD takes its tiles longest walk first (tile_order_kernel)
 #endif
@@ -153,7 +150,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                   const float *__restrict__ gt_mask, int num_obj, int P, float *__restrict__ used_count,
                   int32_t *__restrict__ contrib_num, uint32_t list_cap, uint32_t *__restrict__ counters,
-                  uint32_t *__restrict__ tile_walk, const uint32_t *__restrict__ tile_order) {
+                  uint32_t *__restrict__ tile_walk, const uint32_t *__restrict__ tile_order, uint32_t *__restrict__ walk_hint) {
     __shared__ StagedLDS lds[W3D_RW];
     __shared__ int s_labels[W3D_RW][FLASH ? 256 : 1];
     // FlashSplat: row sums of the per-entry, per-label weights of the current batch: [label slot][entry][16-lane row]
@@ -308,7 +305,10 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     {
         // how far into its list this tile blended anything: the length of the backward's reverse walk (its work)
         const uint32_t m = wave_max_u32(max(max(last[0], last[1]), max(last[2], last[3])));
-        if (lane == 0) tile_walk[tile] = m;
+        if (lane == 0) {
+            tile_walk[tile] = m;
+            if (walk_hint) walk_hint[tile] = m;      // (the caller's per-camera hint for the NEXT render of this view)
+        }
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -712,8 +712,7 @@ det_gather_kernel(int P, int gx, const uint2 *__restrict__ rect, const uint4 *__
 // 6-bit quantised walk length — neighbours of similar length stay neighbours.  One workgroup per XCD; frames with more than
 // 1024 tiles per XCD keep the image order.
 __global__ void __launch_bounds__(1024)
-tile_order_kernel(const uint32_t *__restrict__ tile_walk, const uint32_t *__restrict__ tile_start, uint32_t T, uint32_t per_xcd,
-                  uint32_t *__restrict__ order) {
+tile_order_kernel(const uint32_t *__restrict__ tile_walk, uint32_t T, uint32_t per_xcd, uint32_t *__restrict__ order) {
     __shared__ uint32_t hist[16][64];
     __shared__ uint32_t base_s[16][64];
     __shared__ uint32_t red[16];
@@ -724,8 +723,7 @@ tile_order_kernel(const uint32_t *__restrict__ tile_walk, const uint32_t *__rest
     }
     const uint32_t i = threadIdx.x;
     const bool valid = i < per_xcd && t0 + i < T;
-    // work of a tile: the walk length the forward recorded (backward), or — before the forward has run — its list length
-    const uint32_t w = !valid ? 0u : (tile_start ? tile_start[t0 + i + 1] - tile_start[t0 + i] : tile_walk[t0 + i]);
+    const uint32_t w = valid ? tile_walk[t0 + i] : 0u;
     uint32_t m = wave_max_u32(w);
     if (lane == 0) red[wv] = m;
     for (uint32_t b = lane; b < 64; b += 64) hist[wv][b] = 0;
@@ -782,11 +780,13 @@ int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const 
     blocks = (blocks + 7) / 8 * 8;   // the XCD-contiguous map needs a multiple of 8 blocks
     const bool flash = (gt_mask != nullptr) || (used_count != nullptr) || (contrib_num != nullptr);
     const uint32_t *ts = reinterpret_cast<const uint32_t *>(state + L.o_tile_start);
+    // The forward does not know its walk lengths yet (list lengths are no stand-in: measured, no gain — most walks stop
+    // early); a caller that renders the same camera repeatedly hands in the lengths of its previous render (w3d.h)
     uint32_t *order = nullptr;
-#if W3D_TILE_ORDER_FWD
-    if (W3D_RW == 1) {       // (the forward does not know its walk lengths yet: the list lengths stand in for them)
+#if W3D_TILE_ORDER
+    if (W3D_RW == 1 && v.tile_walk_hint) {
         order = reinterpret_cast<uint32_t *>(state + L.o_tile_order);
-        hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, stream, (const uint32_t *)nullptr, ts, T, blocks / 8, order);
+        hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, stream, (const uint32_t *)v.tile_walk_hint, T, blocks / 8, order);
     }
 #endif
 #define ARGS                                                                                                          \
@@ -795,7 +795,8 @@ int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const 
         reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg, out_color, out_depth, out_alpha,                    \
         reinterpret_cast<float *>(state + L.o_final_T), reinterpret_cast<uint32_t *>(state + L.o_n_contrib), gt_mask, \
         num_obj, L.P, used_count, contrib_num, (uint32_t)(list_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : list_capacity),      \
-        reinterpret_cast<uint32_t *>(state + L.o_counters), reinterpret_cast<uint32_t *>(state + L.o_tile_walk), order
+        reinterpret_cast<uint32_t *>(state + L.o_counters), reinterpret_cast<uint32_t *>(state + L.o_tile_walk), order,        \
+        v.tile_walk_hint
     {
         W3D_PROF("render_fwd", stream);
         if (flash) hipLaunchKernelGGL((render_fwd_kernel<true>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
@@ -819,7 +820,7 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
     if (W3D_RW == 1) {
         order = reinterpret_cast<uint32_t *>(const_cast<char *>(state) + L.o_tile_order);
         hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, stream,
-                           reinterpret_cast<const uint32_t *>(state + L.o_tile_walk), (const uint32_t *)nullptr, T, blocks / 8, order);
+                           reinterpret_cast<const uint32_t *>(state + L.o_tile_walk), T, blocks / 8, order);
     }
 #endif
     // deterministic mode: [P records][det_list_capacity slots] in the scratch buffer (w3d_backward_det_sizes)

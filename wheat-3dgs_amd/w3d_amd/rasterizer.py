@@ -142,6 +142,19 @@ class _View:
         v.projmatrix, v.campos = self.pm.data_ptr(), self.cp.data_ptr()
         v.tile_cull = int(bool(getattr(s, "tile_cull", True)))
         self.deterministic = bool(getattr(s, "deterministic", False))
+        # per-camera walk-length hint of the blend forward (w3d_view.tile_walk_hint; speed only): kept on the camera's own
+        # view-matrix tensor — the object a training loop hands in again every time it renders that camera
+        tiles = ((v.image_width + 15) // 16) * ((v.image_height + 15) // 16)
+        owner = s.viewmatrix
+        hint = getattr(owner, "_w3d_tile_walk", None)
+        if hint is None or hint.numel() != tiles or hint.device != device:
+            hint = torch.zeros(tiles, dtype=torch.int32, device=device)
+            try:
+                owner._w3d_tile_walk = hint
+            except (AttributeError, TypeError):
+                pass
+        self.tile_walk_hint = hint
+        v.tile_walk_hint = hint.data_ptr()
         self.c = v
 
 
