@@ -88,3 +88,34 @@ def test_host_side_validation_of_the_training_step_entry_points():
     lib.w3d_adam_step.argtypes = [u64, vp, vp, vp, vp, f, f, f, f, f, f, i32, vp]
     assert lib.w3d_adam_step(0, None, None, None, None, 0.1, 0.9, 0.999, 1e-15, 0.1, 0.001, 0, None) == 0
     assert lib.w3d_adam_step(8, None, None, None, None, 0.1, 0.9, 0.999, 1e-15, 0.1, 0.001, 0, None) != 0
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The Python mirrors of the header's structs (W3DView, the raw-parameter blocks, the fused-Adam block) have the size and
+    field offsets a C compiler gives include/w3d.h — a field added on one side only shifts every pointer behind it."""
+    import subprocess
+    from w3d_amd import _lib, fused_step
+    src = tmp_path / "layout.c"
+    src.write_text('''#include <stdio.h>
+#include <stddef.h>
+#include "w3d.h"
+int main(void) {
+    printf("view %zu %zu %zu %zu %zu %zu\\n", sizeof(w3d_view), offsetof(w3d_view, bg), offsetof(w3d_view, tile_cull),
+           offsetof(w3d_view, deterministic), offsetof(w3d_view, det_list_capacity), offsetof(w3d_view, tile_walk_hint));
+    printf("raw %zu %zu\\n", sizeof(w3d_raw_params), sizeof(w3d_raw_grads));
+    printf("stats %zu\\n", sizeof(w3d_densify_stats));
+    printf("adam %zu %zu %zu %zu\\n", sizeof(w3d_adam_fused), offsetof(w3d_adam_fused, lr), offsetof(w3d_adam_fused, beta1),
+           offsetof(w3d_adam_fused, bias_correction2));
+    return 0;
+}
+''')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict((ln.split()[0], [int(x) for x in ln.split()[1:]]) for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    V = _lib.W3DView
+    assert out["view"] == [ctypes.sizeof(V), V.bg.offset, V.tile_cull.offset, V.deterministic.offset, V.det_list_capacity.offset,
+                           V.tile_walk_hint.offset]
+    assert out["raw"] == [ctypes.sizeof(fused_step.W3DRawParams), ctypes.sizeof(fused_step.W3DRawGrads)]
+    assert out["stats"] == [ctypes.sizeof(fused_step.W3DDensifyStats)]
+    A = fused_step.W3DAdamFused
+    assert out["adam"] == [ctypes.sizeof(A), A.lr.offset, A.beta1.offset, A.bias_correction2.offset]

@@ -128,3 +128,34 @@ def test_fused_adam_equals_backward_plus_sweep_without_escape_hatch():
         out.append((m.flat.clone(), m.optimizer.exp_avg.clone(), m.optimizer.exp_avg_sq.clone()))
     for x, y in zip(out[0], out[1]):
         assert torch.equal(x, y)
+
+
+def test_results_do_not_depend_on_the_tile_walk_hint():
+    """w3d_view.tile_walk_hint only orders the blend kernels' tiles (longest walk first within each XCD): the images are
+    bit-identical whatever it holds — zeros (first render of a camera), the previous render's lengths, or garbage — and in the
+    deterministic mode so are the gradients."""
+    from w3d_amd.fused_step import render_raw, backward_raw, finish
+    dev, cams, sc = _setup(P=9000, W=400, H=304)            # 25 x 19 tiles: every XCD gets a handful
+    bg = torch.tensor([0.05, 0.0, 0.1], device=dev)
+    m, _ = _model(sc, dev, **DET)
+    cam = cams[2]
+    dL = torch.randn(3, 304, 400, generator=torch.Generator().manual_seed(4)).to(dev) * 1e-3
+    outs = []
+    for fill in ("fresh", "previous", "garbage", "descending"):
+        hint = getattr(cam.world_view_transform, "_w3d_tile_walk", None)
+        if fill == "fresh":
+            assert hint is None
+        elif fill == "previous":
+            assert hint is not None and int(hint.max()) > 0          # the first render left its walk lengths behind
+        elif fill == "garbage":
+            hint.copy_(torch.randint(0, 2 ** 31 - 1, hint.shape, generator=torch.Generator().manual_seed(1)).to(dev))
+        else:
+            hint.copy_(torch.arange(hint.numel(), 0, -1, device=dev, dtype=torch.int32))
+        pkg = render_raw(cam, m, bg, 1.0, sync=True)
+        assert finish(pkg["handle"])
+        backward_raw(m, pkg["handle"], dL)
+        outs.append((pkg["render"].clone(), pkg["depth"].clone(), pkg["alpha"].clone(), pkg["radii"].clone(), m.flat_grad.clone()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+    assert float(outs[0][4].abs().max()) > 0

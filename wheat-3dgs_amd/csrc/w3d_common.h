@@ -13,7 +13,9 @@
 #define W3D_INVALID_KEY 0xFFFFFFFFu
 
 // Upper bounds of the binning geometry (see w3d_binning.hip).
+#ifndef W3D_MAX_CHUNKS
 #define W3D_MAX_CHUNKS 2048       // depth-contiguous chunks of Gaussians, one wave each
+#endif
 #define W3D_CHUNK_MAX 65472       // per-chunk Gaussian count must fit a u16 counter (multiple of 64)
 #define W3D_SCAN_SEGS 16
 #define W3D_RADIX_BITS 8          // depth sort: 4 LSD passes of 8 bits (measured: 3 x 11 bits is slower — the
