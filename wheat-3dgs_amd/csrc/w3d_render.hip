@@ -114,8 +114,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
     return m;
 }
 
-// Returns this lane's entry mask: bits 0..3 = quadrants it can touch, bit 4 = its opacity exceeds the 0.99 alpha cap (only
-// then can o * G reach the cap: the blend loops skip the min otherwise).  The masks stay in registers; the loops read
+// Returns this lane's entry mask: bits 0..3 = quadrants it can touch.  The masks stay in registers; the loops read
 // them with v_readlane and skip entries that touch no quadrant on a scalar bit scan.
 __device__ __forceinline__ uint32_t stage_entries(StagedLDS &s, uint32_t lane, uint32_t n, const uint32_t *__restrict__ list,
                                               const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
@@ -134,7 +133,6 @@ __device__ __forceinline__ uint32_t stage_entries(StagedLDS &s, uint32_t lane, u
         s.c[lane] = cd;
         s.d[lane] = make_float4(-0.5f * LOG2E * co.x, -LOG2E * co.y, -0.5f * LOG2E * co.z, co.w);
         q = quadrant_mask(p.x, p.y, co.x, co.y, co.z, pmin, tx0, ty0);
-        if (q != 0u && co.w > 0.99f) q |= 16u;
     }
     __builtin_amdgcn_wave_barrier();
     return q;
@@ -224,7 +222,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             uint32_t live = 0u;
 #pragma unroll
             for (int k = 0; k < 4; k++) live |= (w3d_ballot(hi[k] == 0.f) != 0ull) ? (1u << k) : 0u;
-            myq = (myq & live) ? (myq & (live | 16u)) : 0u;
+            myq &= live;
         }
         uint64_t todo = w3d_ballot(myq != 0u);
         // FlashSplat scatter, tiles with up to W3D_FLASH_LABELS labels (every tile of a binary mask, nearly every tile of an
@@ -250,10 +248,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 if ((w3d_ballot(power <= hi[k]) & w3d_ballot(power >= ea.z)) == 0ull) continue;   // whole quadrant untouched
                 const bool cand = power <= hi[k] && power >= ea.z;
                 float alpha = ed.w * __builtin_amdgcn_exp2f(power);
-                if (qm & 16u) {                                        // wave-uniform: o <= 0.99 can never reach the cap
-                    asm volatile("" : "+v"(alpha));                     // (keeps this a scalar branch instead of min + select)
-                    alpha = fminf(0.99f, alpha);
-                }
+                alpha = fminf(0.99f, alpha);
                 const float test_T = Tr[k] * (1.f - alpha);
                 const bool ok = cand && alpha >= (1.0f / 255.0f);
                 const bool stop = ok && test_T < 0.0001f;
@@ -441,13 +436,11 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const bool has_bg = (bg0 != 0.f) || (bg1 != 0.f) || (bg2 != 0.f);     // wave-uniform: black background skips the term
     const int nb = (int)((maxc + 63) / 64);
-    // (idx0 < last[k]) holds for every pixel of quadrant k once idx0 < minlast[k]: from there on the per-lane compare of the
-    // quadrant is replaced by one scalar compare
-    uint32_t minlast[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) minlast[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(last[k]));
-    // (a second scalar bound — skip quadrant k while idx0 >= max last[k] — was measured: 5 % SLOWER, the extra compare and
-    //  branch per quadrant cost more than the 17 % of quadrant evaluations they spare stop short of the exponential anyway)
+    // (Scalar bounds on the quadrants' walks were measured and dropped: "idx0 < last[k] holds for the whole quadrant while
+    //  idx0 < min last[k]" saved a compare per quadrant at the price of a branch — 3-4 % slower than always comparing — and
+    //  "skip quadrant k while idx0 >= max last[k]" 5 % slower.  Every wave-uniform branch in this loop costs the wave a
+    //  VALU -> SALU round trip that 2-4 resident waves do not hide: the 0.99 cap, too, is an unconditional v_min now, and
+    //  the second early exit (no lane reaches alpha >= 1/255 after the exponential) is gone — together another 3 %.)
     // where the row sums of this lane go (see the reduce-scatter below): the first lane of every bank (4 lanes) stores the
     // three values its bank ended up with
     const uint32_t l4 = (lane >> 2) & 3u, row = lane >> 4;
@@ -476,12 +469,11 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         const uint32_t n = min(64u, maxc - (uint32_t)b * 64u);
         s.a[lane] = nxt.a; s.b[lane] = nxt.b; s.c[lane] = nxt.c;
         s.d[lane] = make_float4(-0.5f * LOG2E * nxt.b.x, -LOG2E * nxt.b.y, -0.5f * LOG2E * nxt.b.z, nxt.b.w);
-        // this lane's entry: quadrant mask (bits 0..3) and "opacity above the 0.99 cap" (bit 4); they stay in the register —
-        // the walk below reads them with v_readlane and skips entries without any quadrant on a scalar bit scan
+        // this lane's entry: quadrant mask (bits 0..3); it stays in the register — the walk below reads it with v_readlane
+        // and skips entries without any quadrant on a scalar bit scan
         uint32_t myq = 0u;
         if (lane < n) {
             myq = quadrant_mask(nxt.a.x, nxt.a.y, nxt.b.x, nxt.b.y, nxt.b.z, nxt.a.z * (1.0f / LOG2E), (float)tx0, (float)ty0);
-            if (myq != 0u && nxt.b.w > 0.99f) myq |= 16u;
         }
         const uint64_t todo_all = w3d_ballot(myq != 0u);
 #ifdef W3D_BWD_STATS
@@ -527,26 +519,20 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                     bool cand = power <= 0.f;
                     uint64_t mc = w3d_ballot(cand) & w3d_ballot(power >= ea.z);
                     cand = cand && power >= ea.z;
-                    if (idx0 >= minlast[k]) {                          // (wave-uniform; false for most of the walk)
-                        mc &= w3d_ballot(idx0 < last[k]);
-                        cand = cand && idx0 < last[k];
-                    }
+                    mc &= w3d_ballot(idx0 < last[k]);
+                    cand = cand && idx0 < last[k];
                     if (mc == 0ull) continue;
 #ifdef W3D_BWD_STATS
                     st_exp++;
 #endif
                     const float Graw = __builtin_amdgcn_exp2f(power);
                     float araw = ed.w * Graw;
-                    if (qm & 16u) {                                    // wave-uniform: o <= 0.99 can never reach the cap
-                        asm volatile("" : "+v"(araw));                  // (keeps this a scalar branch instead of min + select)
-                        araw = fminf(0.99f, araw);
-                    }
+                    araw = fminf(0.99f, araw);
                     const uint64_t mk = mc & w3d_ballot(araw >= (1.0f / 255.0f));
-                    if (mk == 0ull) continue;
+                    any = any || (mk != 0ull);
 #ifdef W3D_BWD_STATS
-                    st_full++;
+                    st_full += mk != 0ull ? 1u : 0u;
 #endif
-                    any = true;                                        // wave-uniform: some lane blends this Gaussian
                     // Branch-free per lane: a lane that does not blend this Gaussian runs the same recurrences
                     // with alpha = G = 0, which leaves T and the suffix accumulators untouched and adds zeros.
                     const bool ok = cand && araw >= (1.0f / 255.0f);    // (its lane mask is mk, already in an SGPR pair)
