@@ -342,7 +342,7 @@ def cpu_baseline(args):
 
 
 # ------------------------------------------------------------------------------------------------ drop-in loop
-def reference_loop(model, opt, cams, bg, pipe, first_iter, n_steps, perm):
+def reference_loop(model, opt, cams, bg, pipe, first_iter, n_steps, perm, iter_events=None):
     """The loop body of reference train_vanilla_3dgs.py:55-115, statement by statement (logging, saving and the
     densification branch — not due in these iterations — left out; cameras cycled instead of randint), on this package's
     drop-ins for the names that script imports: render (gaussian_renderer), GaussianModel (scene), l1_loss / ssim
@@ -356,6 +356,9 @@ def reference_loop(model, opt, cams, bg, pipe, first_iter, n_steps, perm):
         if iteration % 1000 == 0:
             gaussians.oneupSHdegree()
         viewpoint_cam = cams[perm[(iteration - 1) % len(cams)]]
+        if iter_events is not None:                 # iter_start.record() of train_vanilla_3dgs.py:56
+            iter_events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            iter_events[-1][0].record()
         render_pkg = render(viewpoint_cam, gaussians, pipe, background)
         image, viewspace_point_tensor, visibility_filter, radii = (render_pkg["render"], render_pkg["viewspace_points"],
                                                                    render_pkg["visibility_filter"], render_pkg["radii"])
@@ -363,6 +366,8 @@ def reference_loop(model, opt, cams, bg, pipe, first_iter, n_steps, perm):
         Ll1 = l1_loss(image, gt_image)
         loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, gt_image))
         loss.backward()
+        if iter_events is not None:                 # iter_end.record() :82 — the reference's own `iter_time` bracket
+            iter_events[-1][1].record()
         with torch.no_grad():
             ema_loss_for_log = 0.4 * loss.item() + 0.6 * ema_loss_for_log
             if iteration < opt.densify_until_iter:
@@ -394,9 +399,17 @@ def time_dropin(args, sc, cams, bg, dev, perm):
     reference_loop(model, opt, cams, bg, pipe, 1 + w, n, perm)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the reference's own timer (TensorBoard `iter_time`, train_vanilla_3dgs.py:56,82,149): CUDA/HIP events around
+    # render + loss + backward — a separate short run, so the event pairs do not sit in the timed loop above
+    ev = []
+    reference_loop(model, opt, cams, bg, pipe, 1 + w + n, min(n, 36), perm, iter_events=ev)
+    torch.cuda.synchronize()
+    iter_ms = sorted(a.elapsed_time(b) for a, b in ev)
     del model
     torch.cuda.empty_cache()
-    return {"iters_per_s": round(n / dt, 2), "ms_per_step": round(1e3 * dt / n, 4), "steps": n}
+    return {"iters_per_s": round(n / dt, 2), "ms_per_step": round(1e3 * dt / n, 4), "steps": n,
+            "iter_time_ms_median": round(iter_ms[len(iter_ms) // 2], 4),
+            "iter_time": "HIP events around render + loss + backward, the bracket of train_vanilla_3dgs.py:56,82 (no optimizer step)"}
 
 
 # ------------------------------------------------------------------------------------------------ exchange
@@ -591,8 +604,25 @@ def main():
                 mask_iou_device(pkg_s["alpha"], cand, 0.5)
             sync()
             extras["flashsplat_subset_views_per_s"] = round(world * args.views / (time.perf_counter() - f0), 1)
+            # the reference's own formulation of the same call for comparison: activated blocks gathered with the mask
+            # (gaussian_renderer/__init__.py:151-156,168-170,186-187) through the drop-in rasterizer module, alpha to the host,
+            # numpy threshold / bbox / IoU (run_3d_seg.py:131-163) — reached here by handing the mask over as an index tensor
+            head_idx = head.nonzero(as_tuple=True)[0]
+            cand_np = cand.cpu().numpy() > 0
+            for i in range(2):
+                flashsplat_render(cams[i], model, PipelineParams(), bg, used_mask=head_idx)
+            sync()
+            f0 = time.perf_counter()
+            for i in range(12):
+                a = flashsplat_render(cams[i % len(cams)], model, PipelineParams(), bg, used_mask=head_idx)["alpha"]
+                pred = a.squeeze().detach().cpu().numpy() > 0.5
+                for m_ in cand_np:
+                    inter, union = (m_ & pred).sum(), (m_ | pred).sum()
+            sync()
+            extras["flashsplat_subset_reference_formulation_views_per_s"] = round(world * 12 / (time.perf_counter() - f0), 1)
             extras["flashsplat_subset"] = {"gaussians_in_mask": int(head.sum()), "candidate_masks": 4,
                                            "loop": "flashsplat_render(used_mask) + alpha>0.5 -> bbox -> IoU, per view (host reads 13 counters)"}
+            del head_idx, a
         del head, cand, pkg_s
         # ... and run_3d_seg.py's real loop shape: several object masks per view — one forward, the blend repeated per mask
         n_m = 8
@@ -620,7 +650,11 @@ def main():
         # (40-pixel cells: label boundaries cut through the 16x16 tiles, up to four labels per tile)
         labels = ((xx // 40) + (args.width // 40 + 1) * (yy // 40)).remainder(K + 1).float()
         with torch.no_grad():
-            flashsplat_render(cams[0], model, PipelineParams(), bg, gt_mask=labels, obj_num=K)
+            # (two warm-up views with the loop's own holding pattern — the previous view's 2.4-GB count matrix is still
+            #  referenced while the next one is allocated — so that both blocks exist in torch's allocator before the clock
+            #  starts: a first-time 2.4-GB hipMalloc inside a 4-view window costs ten times the four renders)
+            for i in range(2):
+                uc = flashsplat_render(cams[i], model, PipelineParams(), bg, gt_mask=labels, obj_num=K)["used_count"]
             sync()
             f0 = time.perf_counter()
             for i in range(4):
