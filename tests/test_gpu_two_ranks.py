@@ -95,7 +95,9 @@ def worker(rank, world, port, mode, outdir, backend="gloo_staged"):
         _install_host_staged_collectives()
     from w3d_amd.train import Trainer
     m, opt, cams = _scene_and_cams(dev)
-    tr = Trainer(m, cams, opt, torch.zeros(3, device=dev), densify=True, cameras_extent=2.0, exchange=mode)
+    # "lowrank_early": the colour-gradient all-gather is issued between the two halves of the backward
+    tr = Trainer(m, cams, opt, torch.zeros(3, device=dev), densify=True, cameras_extent=2.0,
+                 exchange="lowrank" if mode.startswith("lowrank") else mode, early_gather=mode == "lowrank_early")
     assert tr.world == world and tr.rank == rank
     snaps = {}
     for it in range(1, 8):              # densifies at iteration 4, resets the opacities at iteration 6
@@ -185,7 +187,7 @@ def _check_replicas_and_mean_gradient_step(snaps, world, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["lowrank", "dense"])
+@pytest.mark.parametrize("mode", ["lowrank", "lowrank_early", "dense"])
 def test_two_ranks_one_gpu_replicas_identical_and_equal_mean_gradient_step(mode, tmp_path):
     _check_replicas_and_mean_gradient_step(_run_ranks(2, mode, "gloo_staged", tmp_path), 2, mode)
 
@@ -196,7 +198,7 @@ def _gpus():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["lowrank", "dense"])
+@pytest.mark.parametrize("mode", ["lowrank", "lowrank_early", "dense"])
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_rccl_ranks_replicas_identical_and_equal_mean_gradient_step(world, mode, tmp_path):
     """Config C5's exchange on the real links: `world` ranks, one GPU each, backend nccl (= RCCL), no shims."""
