@@ -63,7 +63,9 @@ def parse():
     ap.add_argument("--torch-loss", action="store_true", help="use the PyTorch conv2d SSIM instead of the fused kernel")
     ap.add_argument("--autograd-path", action="store_true",
                     help="headline loop = Trainer.step through render()+autograd instead of the fused raw-parameter step")
-    ap.add_argument("--exchange", default="lowrank", choices=("lowrank", "dense"), help="view-parallel exchange (N > 1)")
+    ap.add_argument("--exchange", default="auto", choices=("auto", "rows", "lowrank", "dense"),
+                    help="view-parallel exchange (N > 1); auto: a few untimed steps of 'rows' and of 'lowrank' after the warm-up, "
+                         "the faster one (max over ranks) runs the timed steps")
     ap.add_argument("--dropin-steps", type=int, default=-1, help="steps of the reference-loop measurement (-1: = --steps, 0: skip)")
     ap.add_argument("--trained-steps", type=int, default=3000,
                     help="extra training steps before the second (trained-scene) measurement; 0: skip")
@@ -248,6 +250,27 @@ def valu_peak():
         except Exception:
             pass
     return VALU_SPEC_TFLOPS, "spec (MI355X_MICROARCH.md, Peak FP32 vector)"
+
+
+_REAL_STDOUT = None
+
+
+def _stdout_to_stderr():
+    """Everything any library prints to stdout from here on (RCCL's version banner, for one) goes to stderr; the ONE JSON
+    line is written to the real stdout by _emit()."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (line + "\n").encode())
 
 
 def _progress(msg):
@@ -456,6 +479,7 @@ def main():
         return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU fallback")
+    _stdout_to_stderr()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = args.force_dist
@@ -473,11 +497,11 @@ def main():
     if args.dropin_only:
         del model
         g = torch.Generator(device="cpu").manual_seed(0)
-        print(json.dumps({"dropin": time_dropin(args, sc, cams, bg, dev, torch.randperm(len(cams), generator=g).tolist())}))
+        _emit(json.dumps({"dropin": time_dropin(args, sc, cams, bg, dev, torch.randperm(len(cams), generator=g).tolist())}))
         return
     loss_fn = photometric_loss_torch if args.torch_loss else photometric_loss
     trainer = Trainer(model, cams, opt, bg, densify=False, loss_fn=loss_fn, fused=False if args.autograd_path else None,
-                      force_exchange=force_dist, exchange=args.exchange)
+                      force_exchange=force_dist, exchange="rows" if args.exchange == "auto" else args.exchange)
 
     def sync():
         if world > 1:
@@ -518,6 +542,25 @@ def main():
     # before anything is timed; if the low-rank exchange (replicated optimizer) fails the check, the replicas are
     # re-synchronised from rank 0 and the run falls back to the dense exchange (reduce-scatter, sharded Adam, all-gather)
     selfcheck = None
+    autotune = None
+    if world > 1 and trainer.fused and args.exchange == "auto":
+        autotune = {}
+        for mode in ("rows", "lowrank"):
+            trainer.exchange_mode = mode
+            for _ in range(2):
+                it += 1
+                trainer.step(it)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(6):
+                it += 1
+                trainer.step(it)
+            torch.cuda.synchronize()
+            dt = torch.tensor([(time.perf_counter() - t0) / 6], device=dev, dtype=torch.float64)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)                   # the same number, hence the same choice, on every rank
+            autotune[mode] = round(1e3 * float(dt), 4)
+        trainer.exchange_mode = min(autotune, key=autotune.get)
     if world > 1:
         selfcheck = {"mode_requested": trainer.exchange_mode if trainer.fused else "dense",
                      "replicas_identical_after_warmup": replicas_identical(model, world, dev)}
@@ -525,7 +568,7 @@ def main():
             for buf in (model.flat_store, model.optimizer.exp_avg, model.optimizer.exp_avg_sq, model.xyz_gradient_accum,
                         model.denom, model.max_radii2D):
                 dist.broadcast(buf, 0)
-            if trainer.fused and trainer.exchange_mode == "lowrank":
+            if trainer.fused and trainer.exchange_mode in ("lowrank", "rows"):
                 trainer.exchange_mode = "dense"
                 selfcheck["fell_back_to"] = "dense"
             for _ in range(max(2, args.warmup // 2)):
@@ -550,6 +593,11 @@ def main():
         exchange = exchange_bandwidth(model, world, dev)
         exchange["mode"] = trainer.exchange_mode if trainer.fused else "dense"
         exchange["selfcheck"] = selfcheck
+        if autotune is not None:
+            exchange["autotune_ms_per_step"] = autotune
+        if exchange["mode"] == "rows":
+            exchange["rows"] = {"steps_by_form": dict(trainer.exchange_used), "rows_per_view_last_step": getattr(trainer, "last_row_counts", None),
+                                "row_bytes": 64, "break_even_rows": trainer.rows_limit(model.num_points)}
         exchange["replicas_identical_after_timed_steps"] = replicas_identical(model, world, dev)
         # one boolean for the driver: the replicas were bit-identical after the warm-up (or after the dense fallback) AND
         # after the timed steps — nothing re-synchronises them, so this is the proof that the exchange is correct on the links
@@ -820,7 +868,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        _emit(json.dumps(out))
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

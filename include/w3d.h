@@ -21,7 +21,7 @@
  *        <- the per-mask inner call of run_3d_seg.py:88-97 / :127-134 (same view, another gt_mask)
  *   w3d_backward_raw_adam (next-row N2, single GPU)
  *        <- train_vanilla_3dgs.py:80 loss.backward() + :113-115 optimizer.step() / zero_grad()
- *   w3d_backward_raw_lowrank, w3d_sh_adam_lowrank (row e, view-parallel exchange)
+ *   w3d_backward_raw_lowrank, w3d_sh_adam_lowrank, w3d_pack_gradient_rows, w3d_apply_gradient_rows (row e, view-parallel exchange)
  *        <- no reference counterpart (the reference is single-GPU); same arithmetic as
  *           w3d_backward_raw + w3d_adam_step on the mean gradient of the views
  *   w3d_densify_compact (next-row N3)
@@ -240,6 +240,23 @@ int w3d_sh_adam_lowrank(int32_t P, int32_t n_views, int32_t sh_degree, const flo
                         float *exp_avg_rest, float *exp_avg_sq_rest, float lr_dc, float lr_rest, int32_t skip_dc,
                         int32_t skip_rest, float beta1, float beta2, float eps, float bias_correction1,
                         float bias_correction2, w3d_stream_t stream);
+
+/* The sparse ("rows") form of the same exchange.  One view gives a gradient only to the Gaussians its pixels blended (a
+ * small part of P), every other row of dcolor_out and of the geometry gradients is exactly zero, and adding zeros changes no
+ * sum — so a rank ships only its non-zero rows, 16 floats (64 B) each:
+ *     {index (u32 bits), grad2d_norm * norm_scale, dL/dRGB[3], d xyz[3], d opacity, d scaling[3], d rotation[4]}.
+ * w3d_pack_gradient_rows appends one row for every Gaussian whose 14 gradient floats and grad2d_norm (may be NULL) are not all
+ * zero to rows_out (capacity_rows rows, 16-byte aligned; order unspecified) and leaves their number in *count (device memory,
+ * zeroed by the call; rows beyond the capacity are counted but not written — P rows always suffice).  The ranks all-gather
+ * counts and rows; w3d_apply_gradient_rows, called once per view IN VIEW ORDER on buffers zeroed beforehand, stores the view's
+ * colour rows into dcolor_view (P,3) (one plane of w3d_sh_adam_lowrank's dcolor_all), ADDS its geometry rows into
+ * sums->{xyz, opacity, scaling, rotation} and its norms into norm_sum (P,) (may be NULL).  min(*count, max_rows) rows are read;
+ * count is a device pointer, so no host round trip separates the collective from the kernels.  Replaces, on the reference
+ * side, nothing: reference train_vanilla_3dgs.py is single-GPU (SURVEY.md §8e defines the view-parallel step). */
+int w3d_pack_gradient_rows(int32_t P, const float *dcolor, const w3d_raw_grads *grads, const float *grad2d_norm,
+                           float norm_scale, float *rows_out, uint32_t capacity_rows, uint32_t *count, w3d_stream_t stream);
+int w3d_apply_gradient_rows(int32_t P, const float *rows, const uint32_t *count, uint32_t max_rows, float *dcolor_view,
+                            const w3d_raw_grads *sums, float *norm_sum, w3d_stream_t stream);
 
 /* mean squared distance to the 3 nearest other points; points (N,3) -> out (N,) */
 int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream);

@@ -132,7 +132,14 @@ def _cams(n=10):
     return [SimpleNamespace(camera_center=torch.randn(3, generator=g) * 3.0) for _ in range(n)]
 
 
-def _lowrank_worker(rank, world, port, out):
+def _zero_culled_geometry(m, culled):
+    """A Gaussian a view does not reach has no gradient at all in that view: zero its geometry rows as well."""
+    from w3d_amd.fused_step import GEO_BLOCKS
+    for n in GEO_BLOCKS:
+        m.grad_view(n)[culled] = 0.0
+
+
+def _lowrank_worker(rank, world, port, out, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -140,21 +147,56 @@ def _lowrank_worker(rank, world, port, out):
     m.active_sh_degree = 2
     from w3d_amd.train import Trainer
     P = m.num_points
-    tr = Trainer(m, _cams(), opt, torch.zeros(3), densify=True)
-    assert tr.exchange_mode == "lowrank"
+    tr = Trainer(m, _cams(), opt, torch.zeros(3), densify=True, exchange=mode.split("_")[0],
+                 rows_max_fraction=0.2 if mode == "rows_fallback" else None)
+    stats = []
     for step in range(1, 4):
         dcol, geo = _lowrank_inputs(rank, step, P, m.flat.numel())
         m.flat_grad.copy_(geo / world)                       # SH blocks of the bucket are ignored by the exchange
-        gnorm = torch.rand(P) * 1e-3
         vis = dcol.abs().sum(1) > 0
-        radii = (torch.rand(P) * 30).to(torch.int32) * vis
-        tr.exchange_lowrank(dcol / world, gnorm, vis, radii)
+        _zero_culled_geometry(m, ~vis)
+        gnorm = torch.rand(P, generator=torch.Generator().manual_seed(7 * rank + step)) * 1e-3 * vis
+        radii = (torch.rand(P, generator=torch.Generator().manual_seed(9 * rank + step)) * 30).to(torch.int32) * vis
+        ex = tr.exchange_rows if mode.startswith("rows") else tr.exchange_lowrank
+        nsum, vcount, rmax = ex(dcol / world, gnorm, vis, radii)
         tr.wait_stats()
+        stats.append((nsum.clone().numpy(), vcount.float().numpy(), rmax.clone().numpy()))
         tr.optimizer_step_lowrank(step, skip=({"opacity"} if step == 2 else ()))
     out.put((rank, m.flat.detach().numpy().copy(), m.optimizer.exp_avg.numpy().copy(), m.optimizer.exp_avg_sq.numpy().copy(),
-             m.optimizer.step_count))
+             m.optimizer.step_count, stats, dict(tr.exchange_used)))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _run_lowrank(mode, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lowrank_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_rows_exchange_two_ranks_equals_lowrank_bit_for_bit():
+    """The sparse form ships only the non-zero gradient rows and adds them in view order: for two ranks that is the same
+    sum as the low-rank form's all-reduce (0 + a + b), so parameters, moments and statistics must agree BIT FOR BIT — also
+    when a step is too dense for the sparse form and falls back (rows_max_fraction 0.2 with 70 % non-zero rows)."""
+    import numpy as np
+    ref = _run_lowrank("lowrank")
+    for mode, used in (("rows", {"rows": 3, "lowrank": 0}), ("rows_fallback", {"rows": 0, "lowrank": 3})):
+        res = _run_lowrank(mode)
+        for rank in (0, 1):
+            assert res[rank][6] == used
+            for k in (1, 2, 3):
+                assert np.array_equal(res[rank][k], ref[0][k]), (mode, rank, k)
+            for got, want in zip(res[rank][5], ref[0][5]):
+                for a, b in zip(got, want):
+                    assert np.array_equal(a, b), mode
 
 
 def test_lowrank_exchange_two_ranks():
@@ -165,7 +207,7 @@ def test_lowrank_exchange_two_ranks():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_lowrank_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_lowrank_worker, args=(r, world, port, q, "lowrank")) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((_tensors(q.get(timeout=180)) for _ in range(world)), key=lambda r: r[0])
@@ -190,6 +232,9 @@ def test_lowrank_exchange_two_ranks():
         sh = torch.zeros(P, 16, 3)
         for r in range(world):
             dcol, geo = _lowrank_inputs(r, step, P, m.flat.numel())
+            m.flat_grad.copy_(geo / world)
+            _zero_culled_geometry(m, ~(dcol.abs().sum(1) > 0))
+            geo = m.flat_grad.clone() * world
             total += geo / world
             dirs = m._p["xyz"].detach() - campos[r][None]
             dirs = dirs / dirs.norm(dim=1, keepdim=True)

@@ -1,7 +1,8 @@
 """GPU, one rank: the view-parallel exchange paths of the fused step on a real RCCL process group (world_size 1 — the only
 world a 1-GPU box offers; the 2-rank logic is covered on CPU by tests/test_dist_gloo.py).  Both exchanges must reproduce the
 plain single-GPU step: "lowrank" (colour gradients gathered, SH gradient rebuilt by sh_adam_lowrank_kernel, geometry
-all-reduced, replicated Adam) and "dense" (in-place reduce-scatter, sharded Adam, in-place all-gather)."""
+all-reduced, replicated Adam), "rows" (only the non-zero gradient rows gathered, applied in view order; also with the
+per-step fall-back to "lowrank" forced) and "dense" (in-place reduce-scatter, sharded Adam, in-place all-gather)."""
 import os
 import socket
 
@@ -37,15 +38,17 @@ def test_exchange_paths_equal_single_gpu_step(one_rank_group):
     bg = torch.tensor([0.1, 0.1, 0.0], device=dev)
     sc = make_scene(6999, seed=13, scale_mean=0.02)      # odd: the SH blocks are not 16-B aligned (dword fallback paths)
     runs = {}
-    for name in ("single", "lowrank", "lowrank3", "lowrank_early", "dense"):
+    for name in ("single", "lowrank", "lowrank3", "lowrank_early", "rows", "rows_fallback", "dense"):
         m = GaussianModel(3, device=dev)
         m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
         m.active_sh_degree = 2
+        m.deterministic = True       # (run-to-run reproducible gradients: the sparse and the low-rank form are compared bit for bit)
         opt = OptimizationParams()
         m.training_setup(opt)
         tr = Trainer(m, cams, opt, bg, densify=False, force_exchange=(name != "single"))
         tr.fused_adam = False
-        tr.exchange_mode = "lowrank" if name.startswith("lowrank") else name
+        tr.exchange_mode = "lowrank" if name.startswith("lowrank") else "rows" if name.startswith("rows") else name
+        tr.rows_max_fraction = 0.0 if name == "rows_fallback" else None   # 0: every step is "too dense" for the sparse form
         tr.lowrank_chunks = 3 if name == "lowrank3" else None      # colour gradients gathered in 3 row chunks
         tr.early_gather = name == "lowrank_early"                  # ... issued between the two halves of the backward
         tr.step(1)
@@ -54,11 +57,17 @@ def test_exchange_paths_equal_single_gpu_step(one_rank_group):
         for it in range(2, 5):
             tr.step(it)
         assert m.optimizer.step_count == 4
+        if name.startswith("rows"):
+            assert tr.exchange_used == ({"rows": 0, "lowrank": 4} if name == "rows_fallback" else {"rows": 4, "lowrank": 0})
         if name != "single":
             tr.gather_moments()
         runs[name] = (one, m.flat.clone(), m)
     ref1, ref4, mref = runs["single"]
-    for name in ("lowrank", "lowrank3", "lowrank_early", "dense"):
+    # the sparse form adds the same numbers (0 + g == g): bit-identical to the low-rank form on one rank
+    for a, b in zip(runs["rows"][0], runs["lowrank"][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(runs["rows"][1], runs["lowrank"][1]) and torch.equal(runs["rows_fallback"][1], runs["lowrank"][1])
+    for name in ("lowrank", "lowrank3", "lowrank_early", "rows", "dense"):
         one, four, m = runs[name]
         for k, tol in ((1, 2e-4), (2, 4e-4)):           # moments after one step are (1-b1) g and (1-b2) g^2
             for blk, (lo, hi) in m.block_slices().items():
@@ -73,7 +82,7 @@ def test_exchange_paths_equal_single_gpu_step(one_rank_group):
         assert float((d4 > 1e-4).float().mean()) <= 2e-3 and float(d4.max()) <= 0.25, name
 
 
-@pytest.mark.parametrize("mode", ["lowrank", "dense"])
+@pytest.mark.parametrize("mode", ["lowrank", "rows", "dense"])
 def test_densifying_training_under_exchange(one_rank_group, mode):
     """The episodic host logic under the exchange paths: collectives are drained before a densification recycles the
     gradient bucket, the step is skipped / restricted in those iterations exactly as on one GPU, sharded moments (dense)
@@ -160,3 +169,84 @@ def test_sh_adam_lowrank_kernel_three_views_against_torch(P, deg):
         lo, hi = sl[name]
         assert torch.equal(b.flat[lo:hi].cpu(), a.flat[lo:hi])
     assert float(a.optimizer.exp_avg[sl["f_rest"][0]:sl["f_rest"][1]].abs().max()) > 0
+
+
+@pytest.mark.parametrize("P,frac", [(10007, 0.07), (4096, 1.0), (513, 0.0)])
+def test_gradient_row_kernels_against_torch(P, frac):
+    """w3d_pack_gradient_rows / w3d_apply_gradient_rows (the sparse exchange's two kernels): the packed rows are exactly the
+    non-zero rows (each once, any order, -0.0 counts as zero), and applying three "views" in order reproduces the dense
+    sums bit for bit — against the CPU branch of the same functions and plain torch.  P = 10007: no block is 16-B aligned."""
+    from w3d_amd.fused_step import GEO_BLOCKS, ROW_FLOATS, apply_gradient_rows, pack_gradient_rows
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.synth import make_scene
+    dev = torch.device("cuda:0")
+    sc = make_scene(P, seed=3)
+    models = {}
+    for d in ("cpu", dev):
+        m = GaussianModel(3, device=d)
+        m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+        m.training_setup(OptimizationParams())
+        models[str(d)] = m
+    mc, mg = models["cpu"], models[str(dev)]
+    g = torch.Generator().manual_seed(P)
+    views = []
+    for v in range(3):
+        keep = torch.rand(P, generator=g) < frac
+        flat = torch.randn(mc.flat.numel(), generator=g)
+        dcol = torch.randn(P, 3, generator=g) * keep[:, None]
+        gnorm = torch.rand(P, generator=g) * keep
+        mc.flat_grad.copy_(flat)
+        for n in GEO_BLOCKS:
+            mc.grad_view(n).mul_(keep.view(P, *([1] * (mc.grad_view(n).dim() - 1))))
+        if frac > 0 and v == 0:
+            # a row whose only non-zero value is the norm, one whose only non-zero is a rotation component, a row of -0.0
+            z = (~keep).nonzero()[:3, 0] if (~keep).sum() >= 3 else keep.nonzero()[:3, 0]
+            for n in GEO_BLOCKS:
+                mc.grad_view(n)[z] = 0.0
+            dcol[z] = 0.0
+            gnorm[z] = 0.0
+            gnorm[z[0]] = 0.5
+            mc.grad_view("rotation")[z[1], 3] = 1e-30
+            mc.grad_view("opacity")[z[2]] = -0.0
+        mg.flat_grad.copy_(mc.flat_grad.to(dev))
+        rows_c, cnt_c = pack_gradient_rows(mc, dcol, gnorm, norm_scale=2.0)
+        rows_g, cnt_g = pack_gradient_rows(mg, dcol.to(dev), gnorm.to(dev), norm_scale=2.0)
+        n = int(cnt_c[0])
+        assert int(cnt_g[0]) == n
+        rc, rg = rows_c[:n], rows_g[:n].cpu()
+        order = rg[:, 0].contiguous().view(torch.int32).argsort()
+        assert torch.equal(rg[order].view(torch.int32), rc.view(torch.int32))      # same rows, bit for bit (CPU branch is index-ordered)
+        views.append((rows_g[:max(n, 1)].contiguous(), cnt_g, dict(dcol=dcol, gnorm=gnorm * 2.0, geo=mc.flat_grad.clone())))
+        # capacity smaller than the row count: counted, not written past the end
+        small = torch.full((max(n // 2, 1), ROW_FLOATS), 7.0, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        from w3d_amd._lib import check, lib, ptr, stream_ptr
+        from w3d_amd.fused_step import _geo_grads
+        import ctypes
+        check(lib.w3d_pack_gradient_rows(P, ptr(dcol.to(dev)), ctypes.byref(_geo_grads(mg)), None, 1.0, ptr(small),
+                                         small.shape[0] - (1 if n > 1 else 0), ptr(cnt), stream_ptr(dev)))
+        torch.cuda.synchronize()
+        if n > 1:
+            assert bool((small[-1] == 7.0).all())
+    # apply the three views in order on both devices and against dense torch sums in the same order
+    nmax = max(r.shape[0] for r, _, _ in views)
+    for m, d in ((mc, "cpu"), (mg, dev)):
+        m.flat_grad.zero_()
+    d_all = {k: torch.zeros(3, P, 3, device=k) for k in ("cpu", dev)}
+    nsum = {k: torch.zeros(P, device=k) for k in ("cpu", dev)}
+    want_geo = torch.zeros_like(mc.flat_grad)
+    want_n = torch.zeros(P)
+    sl = mc.block_slices()
+    a, b = sl["xyz"][0], sl["rotation"][1]
+    for v, (rows, cnt, ref) in enumerate(views):
+        pad = torch.zeros(nmax, ROW_FLOATS, device=dev)
+        pad[:rows.shape[0]] = rows
+        apply_gradient_rows(mg, pad, cnt, nmax, d_all[dev][v], nsum[dev])
+        apply_gradient_rows(mc, pad.cpu(), cnt.cpu(), nmax, d_all["cpu"][v], nsum["cpu"])
+        want_geo[a:b] += ref["geo"][a:b]
+        want_n += ref["gnorm"]
+        assert torch.equal(d_all[dev][v].cpu(), ref["dcol"] + 0.0)
+    for got in (mg.flat_grad.cpu(), mc.flat_grad):
+        assert torch.equal(got[a:b], want_geo[a:b] + 0.0)
+        assert float(got[:a].abs().max() if a else 0) == 0 and float(got[b:].abs().max()) == 0      # SH blocks untouched
+    assert torch.equal(nsum[dev].cpu(), want_n) and torch.equal(nsum["cpu"], want_n)

@@ -2,14 +2,16 @@
 test box.  RCCL refuses two ranks on one device, so the process group is gloo and the three collectives the step uses are
 staged through host memory by a shim installed in the worker (test-side only); everything else — per-rank camera choice,
 1/world pre-scaling, backward_raw_lowrank / sh_adam_lowrank / the in-place Adam sweep, chunked colour-gradient gather,
-statistics reduction, the dense reduce-scatter + sharded Adam + parameter all-gather — is the product code on device
-tensors.  Asserted for both exchange modes, across a densification:
+the sparse form's row packing / count + row all-gather / in-order application, statistics reduction, the dense
+reduce-scatter + sharded Adam + parameter all-gather — is the product code on device tensors.  Asserted for every exchange
+mode, across a densification:
   * the two replicas stay BIT-identical (parameters, both moments, statistics) although nothing re-synchronises them;
   * one step equals a single process stepping Adam on the mean of the two views' gradients.
 
 test_rccl_ranks_* is the SAME test over RCCL itself: world 2 (and 4 / 8 where the box has them) rank processes, one GPU each,
-backend "nccl", NO shim — the in-place reduce-scatter / all-gather of the dense exchange and the chunked asynchronous
-colour-gradient all-gather + geometry all-reduce of the low-rank one run on the real links (config C5's exchange).  It
+backend "nccl", NO shim — the in-place reduce-scatter / all-gather of the dense exchange, the chunked asynchronous
+colour-gradient all-gather + geometry all-reduce of the low-rank one and the row all-gather + u8 / int32 statistics
+all-reduces of the sparse one run on the real links (config C5's exchange).  It
 skips on a box with fewer GPUs than ranks; bench.py's `exchange.selfcheck` repeats the replica check at benchmark size."""
 import os
 import socket
@@ -187,7 +189,7 @@ def _check_replicas_and_mean_gradient_step(snaps, world, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["lowrank", "lowrank_early", "dense"])
+@pytest.mark.parametrize("mode", ["rows", "lowrank", "lowrank_early", "dense"])
 def test_two_ranks_one_gpu_replicas_identical_and_equal_mean_gradient_step(mode, tmp_path):
     _check_replicas_and_mean_gradient_step(_run_ranks(2, mode, "gloo_staged", tmp_path), 2, mode)
 
@@ -198,7 +200,7 @@ def _gpus():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["lowrank", "lowrank_early", "dense"])
+@pytest.mark.parametrize("mode", ["rows", "lowrank", "lowrank_early", "dense"])
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_rccl_ranks_replicas_identical_and_equal_mean_gradient_step(world, mode, tmp_path):
     """Config C5's exchange on the real links: `world` ranks, one GPU each, backend nccl (= RCCL), no shims."""

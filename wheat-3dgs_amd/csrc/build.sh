@@ -6,7 +6,7 @@ mkdir -p ../lib
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -munsafe-fp-atomics -fno-slp-vectorize -Wall -Wno-unused-function"
 pids=()
-for f in w3d_preprocess w3d_binning w3d_render w3d_knn w3d_api w3d_loss w3d_adam w3d_densify w3d_mask; do
+for f in w3d_preprocess w3d_binning w3d_render w3d_knn w3d_api w3d_loss w3d_adam w3d_densify w3d_mask w3d_exchange; do
   [ -f $f.hip ] || continue
   if [ ! -f ../lib/$f.o ] || [ $f.hip -nt ../lib/$f.o ] || [ w3d_common.h -nt ../lib/$f.o ] || [ ../../include/w3d.h -nt ../lib/$f.o ]; then
     $HIPCC $FLAGS "$@" -c $f.hip -o ../lib/$f.o &

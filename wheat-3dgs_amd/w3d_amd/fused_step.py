@@ -59,6 +59,11 @@ lib.w3d_backward_blend_dcolor.restype = ctypes.c_int
 lib.w3d_sh_adam_lowrank.argtypes = [_i32, _i32, _i32] + [_vp] * 9 + [ctypes.c_float, ctypes.c_float, _i32, _i32] + \
     [ctypes.c_float] * 5 + [_vp]
 lib.w3d_sh_adam_lowrank.restype = ctypes.c_int
+lib.w3d_pack_gradient_rows.argtypes = [_i32, _vp, ctypes.POINTER(W3DRawGrads), _vp, ctypes.c_float, _vp, ctypes.c_uint32, _vp, _vp]
+lib.w3d_pack_gradient_rows.restype = ctypes.c_int
+lib.w3d_apply_gradient_rows.argtypes = [_i32, _vp, _vp, ctypes.c_uint32, _vp, ctypes.POINTER(W3DRawGrads), _vp, _vp]
+lib.w3d_apply_gradient_rows.restype = ctypes.c_int
+ROW_FLOATS = 16          # {index bits, ||dL/dmean2D||, dL/dRGB[3], d xyz[3], d opacity, d scaling[3], d rotation[4]}
 GEO_BLOCKS = ("xyz", "opacity", "scaling", "rotation")      # their gradients are all-reduced as they are (11 floats)
 SH_BLOCKS = ("f_dc", "f_rest")                               # rebuilt on every rank from the exchanged dL/dRGB
 
@@ -403,6 +408,63 @@ def sh_adam_lowrank(model, dcolor_all, campos_all, skip=(), rows=None):
                                       float(opt.lrs["f_dc"]),
                                       float(opt.lrs["f_rest"]), int("f_dc" in skip), int("f_rest" in skip), float(b1),
                                       float(b2), float(opt.eps), float(bc1), float(bc2), stream_ptr(dev)))
+
+
+def _geo_grads(model):
+    g = W3DRawGrads()
+    for n in GEO_BLOCKS:
+        setattr(g, n, model.grad_view(n).data_ptr())
+    return g
+
+
+def pack_gradient_rows(model, dcolor, grad2d_norm=None, norm_scale=1.0):
+    """The non-zero rows of this view's gradient (include/w3d.h w3d_pack_gradient_rows): dcolor (P,3) and the geometry blocks
+    of model.flat_grad as backward_raw_lowrank left them.  Returns (rows (P, 16) float32 of which the first `count` are
+    filled, count (1,) int32 on the device).  GPU: one kernel; CPU (host-logic tests): the same selection with torch ops."""
+    P = model.num_points
+    dev = model.flat.device
+    rows = torch.empty(max(P, 1), ROW_FLOATS, dtype=torch.float32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    if not model.flat.is_cuda:
+        gn = torch.zeros(P) if grad2d_norm is None else grad2d_norm.reshape(P).float() * norm_scale
+        full = torch.cat([gn[:, None], dcolor.reshape(P, 3)] + [model.grad_view(n).reshape(P, -1) for n in GEO_BLOCKS], 1)
+        idx = (full != 0).any(1).nonzero()[:, 0]
+        n = int(idx.numel())
+        rows[:n, 0] = idx.to(torch.int32).view(torch.float32)
+        rows[:n, 1:] = full[idx]
+        count[0] = n
+        return rows, count
+    g = _geo_grads(model)
+    with torch.cuda.device(dev):
+        check(lib.w3d_pack_gradient_rows(P, ptr(dcolor.contiguous()), ctypes.byref(g), ptr(grad2d_norm), float(norm_scale),
+                                         ptr(rows), rows.shape[0], ptr(count), stream_ptr(dev)))
+    return rows, count
+
+
+def apply_gradient_rows(model, rows, count, max_rows, dcolor_view, norm_sum=None):
+    """Apply ONE view's packed rows (include/w3d.h w3d_apply_gradient_rows): dcolor_view (P,3) receives the colour rows, the
+    geometry blocks of model.flat_grad and norm_sum (P,) are ADDED to.  `count` is a (1,) int32 device tensor: the kernel
+    reads it, the host does not.  Call once per view in view order on zeroed buffers."""
+    P = model.num_points
+    if not model.flat.is_cuda:
+        n = min(int(count[0]), int(max_rows))
+        r = rows[:n]
+        idx = r[:, 0].contiguous().view(torch.int32).long()
+        if norm_sum is not None:
+            norm_sum[idx] += r[:, 1]
+        dcolor_view[idx] = r[:, 2:5]
+        col = 5
+        for name in GEO_BLOCKS:
+            blk = model.grad_view(name).view(P, -1)
+            blk[idx] += r[:, col:col + blk.shape[1]]
+            col += blk.shape[1]
+        return
+    dev = model.flat.device
+    assert rows.is_contiguous() and dcolor_view.is_contiguous() and count.dtype == torch.int32
+    g = _geo_grads(model)
+    with torch.cuda.device(dev):
+        check(lib.w3d_apply_gradient_rows(P, ptr(rows), ptr(count), int(max_rows), ptr(dcolor_view), ctypes.byref(g),
+                                          ptr(norm_sum), stream_ptr(dev)))
 
 
 def flash_reblend(pkg, gt_mask, num_obj):

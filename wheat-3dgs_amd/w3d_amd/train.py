@@ -52,13 +52,17 @@ def nccl_inplace_shard(full, lo, hi, rank, world):
 class Trainer:
     def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
                  densify=True, loss_fn=photometric_loss, fused=None, force_exchange=False, fused_adam=True,
-                 exchange="lowrank", early_gather=False, lowrank_chunks=None):
+                 exchange="rows", early_gather=False, lowrank_chunks=None, rows_max_fraction=None):
         """fused_adam: single GPU — the optimizer update is applied by the backward kernel itself
         (fused_step.backward_raw_adam), except in the iterations that densify / reset opacity (there the reference
         skips the replaced parameters' update).
         exchange: view-parallel exchange of the fused step.  "lowrank" ships dL/dRGB (3 floats per Gaussian and view)
-        plus the 11 geometry gradients and replicates the optimizer; "dense" reduce-scatters the 59-float bucket, shards
-        Adam and all-gathers the parameters (also what the autograd step uses).
+        plus the 11 geometry gradients and replicates the optimizer; "rows" ships the same 14 floats but only for the
+        Gaussians that received a gradient in the view (exchange_rows; falls back to "lowrank" in a step where that would
+        be more bytes); "dense" reduce-scatters the 59-float bucket, shards Adam and all-gathers the parameters (also
+        what the autograd step uses).
+        rows_max_fraction: "rows" is used while the largest per-view row count stays below this fraction of P
+        (None: the break-even of the two byte counts for this world size, rows_limit()).
         early_gather (lowrank only): issue the colour-gradient all-gather between the blend backward and the
         per-Gaussian backward, so that it travels while that kernel runs (costs a 25-us extraction kernel).
         lowrank_chunks: row chunks of the colour-gradient all-gather (None: 4 above 256 k Gaussians)."""
@@ -83,8 +87,10 @@ class Trainer:
         # force_exchange: run the multi-rank exchange path (collectives, sharded optimizer) even in a
         # 1-rank process group — lets the RCCL code path be exercised on a single GPU
         self.force_exchange = bool(force_exchange)
-        if exchange not in ("lowrank", "dense"):
-            raise ValueError("exchange must be 'lowrank' or 'dense'")
+        if exchange not in ("rows", "lowrank", "dense"):
+            raise ValueError("exchange must be 'rows', 'lowrank' or 'dense'")
+        self.rows_max_fraction = rows_max_fraction
+        self.exchange_used = {"rows": 0, "lowrank": 0}        # steps per form actually taken (rows mode decides per step)
         self.fused_adam = bool(fused_adam)
         self.exchange_mode = exchange
         self.early_gather = bool(early_gather)
@@ -170,6 +176,70 @@ class Trainer:
         w2 = dist.all_reduce(r, op=dist.ReduceOp.MAX, async_op=True)
         self._stat_work = (w1, w2)
         return stats[0], stats[1], r
+
+    def rows_limit(self, P):
+        """Largest per-view row count for which the sparse form moves fewer bytes than the low-rank one.  Per rank and step
+        the low-rank exchange receives (N-1) * (12 + 88/N) * P bytes (all-gather of (P,3) + ring all-reduce of 11 floats),
+        the sparse one (N-1) * 64 * rows: break-even rows / P = (12 + 88/N) / 64, taken with a 10 % margin for the count
+        exchange and the host wait that sizes the collective."""
+        frac = self.rows_max_fraction
+        if frac is None:
+            frac = min(1.0, 0.9 * (12.0 + 88.0 / max(self.world, 1)) / 64.0)
+        return int(frac * P)
+
+    def exchange_rows(self, dcolor, grad2d_norm, visible, radii, tracking=True):
+        """Sparse exchange of the view-parallel step.  Contract as exchange_lowrank().  A view gives a gradient only to the
+        Gaussians its pixels blended — every other row of dcolor and of the geometry gradients is exactly zero — so the
+        ranks all-gather their NON-ZERO rows (64 B: index, ||dL/dmean2D||, dL/dRGB, 11 geometry gradients; packed by
+        w3d_pack_gradient_rows) and every rank rebuilds the dense per-view colour gradients and the sum over views of
+        the geometry gradients by applying the views' rows in VIEW ORDER (w3d_apply_gradient_rows): identical additions in
+        identical order on every rank keep the replicas bit-identical, as in the low-rank form, and the same replicated
+        optimizer step follows (optimizer_step_lowrank).  The row counts are all-gathered first and read by the host —
+        the one extra host wait of this form; it sizes the collective and decides, identically on every rank, whether
+        this step's views are sparse enough (rows_limit) or go through exchange_lowrank instead.
+        Statistics: the norms travel in the rows; visibility counts as a u8 SUM, radii as an int32 MAX all-reduce."""
+        from .fused_step import ROW_FLOATS, apply_gradient_rows, pack_gradient_rows
+        m = self.model
+        P = m.num_points
+        dev = dcolor.device
+        rows, count = pack_gradient_rows(m, dcolor, grad2d_norm if tracking else None)
+        counts = torch.empty(self.world, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(counts, count)
+        # everything that does not depend on the counts is enqueued BEFORE the host reads them, so the GPU has work while the
+        # host waits and while it issues the row collective afterwards
+        vcount = rmax = nsum = None
+        if tracking:
+            vcount = visible.to(torch.uint8)
+            w1 = dist.all_reduce(vcount, op=dist.ReduceOp.SUM, async_op=True)
+            rmax = radii.clone()
+            w2 = dist.all_reduce(rmax, op=dist.ReduceOp.MAX, async_op=True)
+            self._stat_work = (w1, w2)
+            nsum = torch.zeros(P, dtype=torch.float32, device=dev)
+        d_all = torch.zeros(self.world, P, 3, dtype=torch.float32, device=dev)
+        host_counts = counts.tolist()                             # host wait: backward + a world-int collective
+        nmax = max(host_counts)
+        self.last_row_counts = host_counts
+        if nmax > self.rows_limit(P):
+            # too dense for the sparse form: this step's gradients travel as in exchange_lowrank; the norms, which would
+            # have travelled in the rows, as one more all-reduce
+            self.exchange_used["lowrank"] += 1
+            if tracking:
+                nsum = grad2d_norm * visible
+                self._stat_work = self._stat_work + (dist.all_reduce(nsum, op=dist.ReduceOp.SUM, async_op=True),)
+            self.exchange_lowrank(dcolor, None, None, None, tracking=False)
+            return nsum, vcount, rmax
+        self.exchange_used["rows"] += 1
+        nmax = max(nmax, 1)
+        sl = m.block_slices()
+        a, b = sl["xyz"][0], sl["rotation"][1]                    # xyz | opacity | scaling | rotation: one contiguous span
+        assert b - a == 11 * P
+        m.flat_grad[a:b].zero_()                                  # (pack has read it: same stream)
+        rows_all = torch.empty(self.world, nmax, ROW_FLOATS, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(rows_all.view(-1), rows[:nmax].reshape(-1))
+        for v in range(self.world):
+            apply_gradient_rows(m, rows_all[v], counts[v:v + 1], nmax, d_all[v], nsum)
+        self._d_chunks, self._geo_work = [[(0, P), d_all, None]], []
+        return nsum, vcount, rmax
 
     def gather_colors(self, dcolor):
         """Asynchronous all-gather of the (P,3) colour gradients, in a few row chunks so that the SH update of the first
@@ -308,7 +378,8 @@ class Trainer:
         with torch.no_grad():
             tracking = iteration < opt.densify_until_iter
             single = self.world == 1 and not self.force_exchange
-            lowrank = (not single) and self.exchange_mode == "lowrank" and m.max_sh_degree == 3
+            lowrank = (not single) and self.exchange_mode in ("lowrank", "rows") and m.max_sh_degree == 3
+            rows_form = lowrank and self.exchange_mode == "rows"
             dcol = None
             use_adam = (single and self.fused_adam and iteration < opt.iterations and
                         m.max_sh_degree == 3 and not self._structure_change_due(iteration))
@@ -323,7 +394,7 @@ class Trainer:
                     dimg.mul_(1.0 / self.world)      # the bucket then holds grad/world: reduce-scatter(SUM) = mean
                 if use_adam:
                     gnorm = backward_raw_adam(m, pkg["handle"], dimg, want_norm=False, update_stats=tracking)
-                elif lowrank and self.early_gather:
+                elif lowrank and self.early_gather and not rows_form:
                     # blend backward + dL/dRGB; make sure this forward is final BEFORE a collective is issued (a rank that
                     # repeats its view must not issue it twice); then gather, then the per-Gaussian backward
                     early = backward_blend_dcolor(m, pkg["handle"], dimg)
@@ -350,7 +421,8 @@ class Trainer:
                     gnorm = gnorm * float(self.world)           # statistics use the unscaled per-view norm
                 stepped_early = False
                 if lowrank:
-                    nsum, vcount, rmax = self.exchange_lowrank(dcol, gnorm, vis, pkg["radii"], tracking=tracking)
+                    nsum, vcount, rmax = (self.exchange_rows if rows_form else self.exchange_lowrank)(
+                        dcol, gnorm, vis, pkg["radii"], tracking=tracking)
                     if self._structure_change_due(iteration):
                         self._drain_lowrank()        # densification recycles the gradient bucket
                     elif iteration < opt.iterations:
