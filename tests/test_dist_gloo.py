@@ -157,6 +157,8 @@ def _lowrank_worker(rank, world, port, out, mode):
         _zero_culled_geometry(m, ~vis)
         gnorm = torch.rand(P, generator=torch.Generator().manual_seed(7 * rank + step)) * 1e-3 * vis
         radii = (torch.rand(P, generator=torch.Generator().manual_seed(9 * rank + step)) * 30).to(torch.int32) * vis
+        if mode == "rows_overflow" and step > 1:
+            tr._rows_cap = 8                                     # far below the ~45 rows of a view: remainder all-gather
         ex = tr.exchange_rows if mode.startswith("rows") else tr.exchange_lowrank
         nsum, vcount, rmax = ex(dcol / world, gnorm, vis, radii)
         tr.wait_stats()
@@ -185,10 +187,12 @@ def _run_lowrank(mode, world=2):
 def test_rows_exchange_two_ranks_equals_lowrank_bit_for_bit():
     """The sparse form ships only the non-zero gradient rows and adds them in view order: for two ranks that is the same
     sum as the low-rank form's all-reduce (0 + a + b), so parameters, moments and statistics must agree BIT FOR BIT — also
-    when a step is too dense for the sparse form and falls back (rows_max_fraction 0.2 with 70 % non-zero rows)."""
+    when a step is too dense for the sparse form and falls back (rows_max_fraction 0.2 with 70 % non-zero rows), and when
+    the speculative size of the row collective was too small and a second all-gather carries the remainder."""
     import numpy as np
     ref = _run_lowrank("lowrank")
-    for mode, used in (("rows", {"rows": 3, "lowrank": 0}), ("rows_fallback", {"rows": 0, "lowrank": 3})):
+    for mode, used in (("rows", {"rows": 3, "lowrank": 0}), ("rows_fallback", {"rows": 0, "lowrank": 3}),
+                       ("rows_overflow", {"rows": 3, "lowrank": 0, "rows_overflow": 2})):
         res = _run_lowrank(mode)
         for rank in (0, 1):
             assert res[rank][6] == used

@@ -38,7 +38,7 @@ def test_exchange_paths_equal_single_gpu_step(one_rank_group):
     bg = torch.tensor([0.1, 0.1, 0.0], device=dev)
     sc = make_scene(6999, seed=13, scale_mean=0.02)      # odd: the SH blocks are not 16-B aligned (dword fallback paths)
     runs = {}
-    for name in ("single", "lowrank", "lowrank3", "lowrank_early", "rows", "rows_fallback", "dense"):
+    for name in ("single", "lowrank", "lowrank3", "lowrank_early", "rows", "rows_fallback", "rows_overflow", "dense"):
         m = GaussianModel(3, device=dev)
         m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
         m.active_sh_degree = 2
@@ -52,13 +52,18 @@ def test_exchange_paths_equal_single_gpu_step(one_rank_group):
         tr.lowrank_chunks = 3 if name == "lowrank3" else None      # colour gradients gathered in 3 row chunks
         tr.early_gather = name == "lowrank_early"                  # ... issued between the two halves of the backward
         tr.step(1)
+        assert name != "rows" or tr._rows_cap is not None             # later steps size the row collective speculatively
         one = (m.flat.clone(), m.optimizer.exp_avg.clone(), m.optimizer.exp_avg_sq.clone(), m.xyz_gradient_accum.clone(),
                m.denom.clone(), m.max_radii2D.clone())
         for it in range(2, 5):
+            if name == "rows_overflow":
+                tr._rows_cap = 256          # a guess far below the real row count: the remainder travels in a second all-gather
             tr.step(it)
         assert m.optimizer.step_count == 4
         if name.startswith("rows"):
-            assert tr.exchange_used == ({"rows": 0, "lowrank": 4} if name == "rows_fallback" else {"rows": 4, "lowrank": 0})
+            used = tr.exchange_used
+            assert (used["rows"], used["lowrank"]) == ((0, 4) if name == "rows_fallback" else (4, 0))
+            assert name != "rows_overflow" or used["rows_overflow"] == 3
         if name != "single":
             tr.gather_moments()
         runs[name] = (one, m.flat.clone(), m)
@@ -66,7 +71,8 @@ def test_exchange_paths_equal_single_gpu_step(one_rank_group):
     # the sparse form adds the same numbers (0 + g == g): bit-identical to the low-rank form on one rank
     for a, b in zip(runs["rows"][0], runs["lowrank"][0]):
         assert torch.equal(a, b)
-    assert torch.equal(runs["rows"][1], runs["lowrank"][1]) and torch.equal(runs["rows_fallback"][1], runs["lowrank"][1])
+    for name in ("rows", "rows_fallback", "rows_overflow"):
+        assert torch.equal(runs[name][1], runs["lowrank"][1]), name
     for name in ("lowrank", "lowrank3", "lowrank_early", "rows", "dense"):
         one, four, m = runs[name]
         for k, tol in ((1, 2e-4), (2, 4e-4)):           # moments after one step are (1-b1) g and (1-b2) g^2

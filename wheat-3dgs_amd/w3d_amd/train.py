@@ -10,8 +10,10 @@ same step; then
   * the densification statistics are exchanged BEFORE gradients are averaged — they are sums of
     per-view gradient NORMS, visibility counts and a max of radii (scene/gaussian_model.py:461-463,
     train_vanilla_3dgs.py:102-103), not functions of the averaged gradient;
-  * the 59 x P fp32 gradient bucket (GaussianModel.flat_grad, 236 B per Gaussian) is all-reduced
-    once over RCCL/xGMI and averaged;
+  * the gradients are averaged over the views — fused step: 14 floats per Gaussian and view cross the links (colour
+    gradient + 11 geometry gradients; the SH gradient is rebuilt on every rank), as packed rows of only the Gaussians the
+    view gave a gradient to (exchange_rows, default) or densely (exchange_lowrank), and the optimizer is replicated;
+    autograd step / exchange="dense": the 59 x P fp32 bucket is reduce-scattered, Adam sharded, parameters all-gathered;
   * densify/prune then run identically on every rank (same statistics, same RNG seed for the
     split samples) so the replicas stay in lock-step without a parameter broadcast.
 """
@@ -90,6 +92,8 @@ class Trainer:
         if exchange not in ("rows", "lowrank", "dense"):
             raise ValueError("exchange must be 'rows', 'lowrank' or 'dense'")
         self.rows_max_fraction = rows_max_fraction
+        self.rows_speculate = True            # size the row collective from the previous step (exchange_rows)
+        self._rows_cap = None
         self.exchange_used = {"rows": 0, "lowrank": 0}        # steps per form actually taken (rows mode decides per step)
         self.fused_adam = bool(fused_adam)
         self.exchange_mode = exchange
@@ -194,9 +198,14 @@ class Trainer:
         w3d_pack_gradient_rows) and every rank rebuilds the dense per-view colour gradients and the sum over views of
         the geometry gradients by applying the views' rows in VIEW ORDER (w3d_apply_gradient_rows): identical additions in
         identical order on every rank keep the replicas bit-identical, as in the low-rank form, and the same replicated
-        optimizer step follows (optimizer_step_lowrank).  The row counts are all-gathered first and read by the host —
-        the one extra host wait of this form; it sizes the collective and decides, identically on every rank, whether
-        this step's views are sparse enough (rows_limit) or go through exchange_lowrank instead.
+        optimizer step follows (optimizer_step_lowrank).
+        Sizing the collective.  The row counts are all-gathered too, and the apply kernels read them on the device.  The
+        first step (and every step after one that was too dense) waits for them on the host, sizes the collective exactly
+        and decides — identically on every rank — whether the views are sparse enough (rows_limit) or go through
+        exchange_lowrank.  Later steps are SPECULATIVE: the collective is sized 1.25 x the previous step's largest count and
+        enqueued together with its apply kernels before the host looks at the counts (which arrive in pinned memory in the
+        meantime); only if a view produced more rows than that does a second all-gather carry the remainder.  The host wait
+        then falls where the GPU still has the collective and the apply kernels to run, instead of leaving it idle.
         Statistics: the norms travel in the rows; visibility counts as a u8 SUM, radii as an int32 MAX all-reduce."""
         from .fused_step import ROW_FLOATS, apply_gradient_rows, pack_gradient_rows
         m = self.model
@@ -205,8 +214,19 @@ class Trainer:
         rows, count = pack_gradient_rows(m, dcolor, grad2d_norm if tracking else None)
         counts = torch.empty(self.world, dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(counts, count)
-        # everything that does not depend on the counts is enqueued BEFORE the host reads them, so the GPU has work while the
-        # host waits and while it issues the row collective afterwards
+        pinned = ev = None
+        if counts.is_cuda:                       # the counts start their way to the host now; whoever needs them waits on ev
+            pinned = torch.empty(self.world, dtype=torch.int32, pin_memory=True)
+            pinned.copy_(counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+
+        def host_counts():
+            if ev is None:
+                return counts.tolist()
+            ev.synchronize()
+            return pinned.tolist()
+        # everything that does not depend on the counts is enqueued BEFORE the host reads them
         vcount = rmax = nsum = None
         if tracking:
             vcount = visible.to(torch.uint8)
@@ -216,28 +236,48 @@ class Trainer:
             self._stat_work = (w1, w2)
             nsum = torch.zeros(P, dtype=torch.float32, device=dev)
         d_all = torch.zeros(self.world, P, 3, dtype=torch.float32, device=dev)
-        host_counts = counts.tolist()                             # host wait: backward + a world-int collective
-        nmax = max(host_counts)
-        self.last_row_counts = host_counts
-        if nmax > self.rows_limit(P):
-            # too dense for the sparse form: this step's gradients travel as in exchange_lowrank; the norms, which would
-            # have travelled in the rows, as one more all-reduce
-            self.exchange_used["lowrank"] += 1
-            if tracking:
-                nsum = grad2d_norm * visible
-                self._stat_work = self._stat_work + (dist.all_reduce(nsum, op=dist.ReduceOp.SUM, async_op=True),)
-            self.exchange_lowrank(dcolor, None, None, None, tracking=False)
-            return nsum, vcount, rmax
-        self.exchange_used["rows"] += 1
-        nmax = max(nmax, 1)
         sl = m.block_slices()
         a, b = sl["xyz"][0], sl["rotation"][1]                    # xyz | opacity | scaling | rotation: one contiguous span
         assert b - a == 11 * P
-        m.flat_grad[a:b].zero_()                                  # (pack has read it: same stream)
-        rows_all = torch.empty(self.world, nmax, ROW_FLOATS, dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(rows_all.view(-1), rows[:nmax].reshape(-1))
-        for v in range(self.world):
-            apply_gradient_rows(m, rows_all[v], counts[v:v + 1], nmax, d_all[v], nsum)
+
+        def gather_and_apply(first, n):
+            """rows [first, first + n) of every view: one all-gather, then the views in order"""
+            part = torch.empty(self.world, n, ROW_FLOATS, dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(part.view(-1), rows[first:first + n].reshape(-1))
+            left = counts if first == 0 else (counts - first).clamp_(min=0)
+            for v in range(self.world):
+                apply_gradient_rows(m, part[v], left[v:v + 1], n, d_all[v], nsum)
+
+        cap = self._rows_cap
+        if cap is not None:
+            cap = min(cap, max(P, 1))
+            m.flat_grad[a:b].zero_()                              # (pack has read it: same stream)
+            gather_and_apply(0, cap)
+            hc = host_counts()                                    # the GPU is busy with the collective meanwhile
+            nmax = max(hc)
+            if nmax > cap:                                        # a view outgrew the guess: the remainder follows
+                gather_and_apply(cap, nmax - cap)
+                self.exchange_used["rows_overflow"] = self.exchange_used.get("rows_overflow", 0) + 1
+        else:
+            hc = host_counts()                                    # host wait: backward + a world-int collective
+            nmax = max(hc)
+            if nmax > self.rows_limit(P):
+                # too dense for the sparse form: this step's gradients travel as in exchange_lowrank; the norms, which
+                # would have travelled in the rows, as one more all-reduce
+                self.last_row_counts = hc
+                self.exchange_used["lowrank"] += 1
+                if tracking:
+                    nsum = grad2d_norm * visible
+                    self._stat_work = self._stat_work + (dist.all_reduce(nsum, op=dist.ReduceOp.SUM, async_op=True),)
+                self.exchange_lowrank(dcolor, None, None, None, tracking=False)
+                return nsum, vcount, rmax
+            m.flat_grad[a:b].zero_()
+            gather_and_apply(0, max(nmax, 1))
+        self.last_row_counts = hc
+        self.exchange_used["rows"] += 1
+        # next step's guess — or back to the exact, host-sized form when the views have become too dense for this one
+        self._rows_cap = None if nmax > self.rows_limit(P) or not self.rows_speculate else \
+            min(max(P, 1), (int(1.25 * nmax) + 1024) // 1024 * 1024)
         self._d_chunks, self._geo_work = [[(0, P), d_all, None]], []
         return nsum, vcount, rmax
 
