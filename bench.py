@@ -543,7 +543,8 @@ def main():
     # re-synchronised from rank 0 and the run falls back to the dense exchange (reduce-scatter, sharded Adam, all-gather)
     selfcheck = None
     autotune = None
-    if world > 1 and trainer.fused and args.exchange == "auto":
+    multi = world > 1 or force_dist        # (--force-dist: the N > 1 code below runs on a 1-rank group, so that one GPU can test it)
+    if multi and trainer.fused and args.exchange == "auto":
         autotune = {}
         for mode in ("rows", "lowrank"):
             trainer.exchange_mode = mode
@@ -561,7 +562,7 @@ def main():
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)                   # the same number, hence the same choice, on every rank
             autotune[mode] = round(1e3 * float(dt), 4)
         trainer.exchange_mode = min(autotune, key=autotune.get)
-    if world > 1:
+    if multi:
         selfcheck = {"mode_requested": trainer.exchange_mode if trainer.fused else "dense",
                      "replicas_identical_after_warmup": replicas_identical(model, world, dev)}
         if not selfcheck["replicas_identical_after_warmup"]:
@@ -589,7 +590,7 @@ def main():
 
     extras = {}
     exchange = None
-    if world > 1:
+    if multi:
         exchange = exchange_bandwidth(model, world, dev)
         exchange["mode"] = trainer.exchange_mode if trainer.fused else "dense"
         exchange["selfcheck"] = selfcheck
