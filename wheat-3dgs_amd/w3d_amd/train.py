@@ -518,7 +518,9 @@ class Trainer:
         return loss.detach()
 
 
-RENDER_STREAMS = 2      # frames in flight of render_views (independent frames overlap each other's latency-bound stages)
+RENDER_STREAMS = 3      # frames in flight of render_views (independent frames overlap each other's latency-bound stages;
+                        # 2 M Gaussians at 1600x1200, profiles/render_host_probe.py: 1 stream 0.741 ms per frame, 2: 0.661, 3: 0.649,
+                        # 4: 0.644 — the host needs 0.185 ms to enqueue a frame, so the loop is GPU-bound)
 
 
 def render_views(model, cameras, background, pipe=None):
