@@ -608,8 +608,8 @@ def main():
     if not args.no_extras and not args.trained_only:
         _progress("extras: render / FlashSplat")
         # forward-only render throughput (reference render.py's use), same scene, views cycled
-        n_r = max(4, min(args.steps, 36))
-        render_views(model, cams[:2], bg)
+        n_r = max(4, min(args.steps, 72))
+        render_views(model, cams[:6], bg)          # (every stream of render_views has allocated its frame buffers once)
         sync()
         r0 = time.perf_counter()
         render_views(model, [cams[i % len(cams)] for i in range(n_r)], bg)

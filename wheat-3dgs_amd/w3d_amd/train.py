@@ -518,9 +518,10 @@ class Trainer:
         return loss.detach()
 
 
-RENDER_STREAMS = 3      # frames in flight of render_views (independent frames overlap each other's latency-bound stages;
-                        # 2 M Gaussians at 1600x1200, profiles/render_host_probe.py: 1 stream 0.741 ms per frame, 2: 0.661, 3: 0.649,
-                        # 4: 0.644 — the host needs 0.185 ms to enqueue a frame, so the loop is GPU-bound)
+RENDER_STREAMS = 2      # frames in flight of render_views (independent frames overlap each other's latency-bound stages;
+                        # 2 M Gaussians at 1600x1200, profiles/render_host_probe.py, two boxes: 1 stream 0.741 / 0.745 ms per frame,
+                        # 2: 0.661 / 0.643, 3: 0.649 / 0.673, 4: 0.644 / 0.639 — more than two is within the noise; the host
+                        # needs 0.19 ms to enqueue a frame, so the loop is GPU-bound)
 
 
 def render_views(model, cameras, background, pipe=None):
@@ -540,7 +541,12 @@ def render_views(model, cameras, background, pipe=None):
         # consecutive frames go to alternating streams: sort and binning are latency-bound kernels that leave most of the
         # chip idle, so two independent frames in flight overlap them (frames do not depend on each other)
         main = torch.cuda.current_stream(model.flat.device)
-        streams = [torch.cuda.Stream(device=model.flat.device) for _ in range(RENDER_STREAMS)] if RENDER_STREAMS > 1 else [main]
+        if RENDER_STREAMS > 1:
+            streams = getattr(model, "_render_streams", None)       # (kept on the model: creating a HIP stream costs ~0.2 ms)
+            if streams is None or len(streams) != RENDER_STREAMS or streams[0].device != model.flat.device:
+                streams = model._render_streams = [torch.cuda.Stream(device=model.flat.device) for _ in range(RENDER_STREAMS)]
+        else:
+            streams = [main]
         for st in streams:
             st.wait_stream(main)
 
