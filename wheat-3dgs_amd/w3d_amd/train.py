@@ -52,6 +52,8 @@ def nccl_inplace_shard(full, lo, hi, rank, world):
 
 
 class Trainer:
+    ROWS_RETRY = 16          # exchange="rows": steps in the low-rank form after one that was too dense, before rows are counted again
+
     def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
                  densify=True, loss_fn=photometric_loss, fused=None, force_exchange=False, fused_adam=True,
                  exchange="rows", early_gather=False, lowrank_chunks=None, rows_max_fraction=None):
@@ -94,6 +96,7 @@ class Trainer:
         self.rows_max_fraction = rows_max_fraction
         self.rows_speculate = True            # size the row collective from the previous step (exchange_rows)
         self._rows_cap = None
+        self._rows_skip = 0
         self.exchange_used = {"rows": 0, "lowrank": 0}        # steps per form actually taken (rows mode decides per step)
         self.fused_adam = bool(fused_adam)
         self.exchange_mode = exchange
@@ -211,6 +214,12 @@ class Trainer:
         m = self.model
         P = m.num_points
         dev = dcolor.device
+        if self._rows_skip > 0:
+            # a recent step was too dense for this form: the next ROWS_RETRY steps take the low-rank form without counting
+            # their rows first (same state on every rank: it derives from the gathered counts)
+            self._rows_skip -= 1
+            self.exchange_used["lowrank"] += 1
+            return self.exchange_lowrank(dcolor, grad2d_norm, visible, radii, tracking=tracking)
         rows, count = pack_gradient_rows(m, dcolor, grad2d_norm if tracking else None)
         counts = torch.empty(self.world, dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(counts, count)
@@ -266,6 +275,7 @@ class Trainer:
                 # would have travelled in the rows, as one more all-reduce
                 self.last_row_counts = hc
                 self.exchange_used["lowrank"] += 1
+                self._rows_skip = self.ROWS_RETRY
                 if tracking:
                     nsum = grad2d_norm * visible
                     self._stat_work = self._stat_work + (dist.all_reduce(nsum, op=dist.ReduceOp.SUM, async_op=True),)
