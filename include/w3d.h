@@ -21,7 +21,8 @@
  *        <- the per-mask inner call of run_3d_seg.py:88-97 / :127-134 (same view, another gt_mask)
  *   w3d_backward_raw_adam (next-row N2, single GPU)
  *        <- train_vanilla_3dgs.py:80 loss.backward() + :113-115 optimizer.step() / zero_grad()
- *   w3d_backward_raw_lowrank, w3d_sh_adam_lowrank, w3d_pack_gradient_rows, w3d_apply_gradient_rows (row e, view-parallel exchange)
+ *   w3d_backward_raw_lowrank, w3d_sh_adam_lowrank, w3d_pack_gradient_rows, w3d_apply_gradient_rows,
+ *   w3d_index_gradient_rows, w3d_rows_norm_sum, w3d_rows_adam (row e, view-parallel exchange)
  *        <- no reference counterpart (the reference is single-GPU); same arithmetic as
  *           w3d_backward_raw + w3d_adam_step on the mean gradient of the views
  *   w3d_densify_compact (next-row N3)
@@ -257,6 +258,21 @@ int w3d_pack_gradient_rows(int32_t P, const float *dcolor, const w3d_raw_grads *
                            float norm_scale, float *rows_out, uint32_t capacity_rows, uint32_t *count, w3d_stream_t stream);
 int w3d_apply_gradient_rows(int32_t P, const float *rows, const uint32_t *count, uint32_t max_rows, float *dcolor_view,
                             const w3d_raw_grads *sums, float *norm_sum, w3d_stream_t stream);
+/* The optimizer step straight from the gathered rows, without dense per-view arrays.  rows_all: (n_views, cap_rows, 16) as
+ * all-gathered, counts: (n_views) device.  w3d_index_gradient_rows zeroes viewmask (P u32) and, for every row r <
+ * min(counts[v], cap_rows) of view v with Gaussian index g, sets bit v of viewmask[g] and slots[v*P + g] = r (slots: n_views*P
+ * u32, only the marked entries are written or ever read; at most 32 views).  w3d_rows_norm_sum writes norm_sum[g] = sum in view
+ * order of the rows' norms (0 where no view holds a row).  w3d_rows_adam walks every Gaussian's set bits in view order, rebuilds
+ * the SH gradient (as w3d_sh_adam_lowrank) and the sum of the geometry gradients, and applies torch.optim.Adam's update to all
+ * six parameter blocks and their moments in place — one pass; `adam` as in w3d_backward_raw_adam (per-block step sizes, skips
+ * and bias corrections).  Same additions in the same order on every rank: replicas stay bit-identical. */
+int w3d_index_gradient_rows(int32_t P, int32_t n_views, const float *rows_all, const uint32_t *counts, uint32_t cap_rows,
+                            uint32_t *viewmask, uint32_t *slots, w3d_stream_t stream);
+int w3d_rows_norm_sum(int32_t P, int32_t n_views, const float *rows_all, uint32_t cap_rows, const uint32_t *viewmask,
+                      const uint32_t *slots, float *norm_sum, w3d_stream_t stream);
+int w3d_rows_adam(int32_t P, int32_t n_views, int32_t sh_degree, const float *campos_all, const float *rows_all, uint32_t cap_rows,
+                  const uint32_t *viewmask, const uint32_t *slots, const w3d_raw_blocks *params, const w3d_adam_fused *adam,
+                  w3d_stream_t stream);
 
 /* mean squared distance to the 3 nearest other points; points (N,3) -> out (N,) */
 int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream);

@@ -256,3 +256,70 @@ def test_gradient_row_kernels_against_torch(P, frac):
         assert torch.equal(got[a:b], want_geo[a:b] + 0.0)
         assert float(got[:a].abs().max() if a else 0) == 0 and float(got[b:].abs().max()) == 0      # SH blocks untouched
     assert torch.equal(nsum[dev].cpu(), want_n) and torch.equal(nsum["cpu"], want_n)
+
+
+@pytest.mark.parametrize("P,deg,skip", [(10007, 3, ()), (4096, 1, ("opacity",)), (700, 2, ("f_dc", "xyz"))])
+def test_rows_adam_equals_dense_pipeline_three_views(P, deg, skip):
+    """w3d_index_gradient_rows + w3d_rows_norm_sum + w3d_rows_adam (the optimizer step straight from the gathered rows) against
+    the dense pipeline — w3d_apply_gradient_rows per view, w3d_sh_adam_lowrank, the Adam sweep over the geometry blocks — on
+    three views with overlapping row sets: parameters, both moments and the norm sums must agree BIT FOR BIT, after two
+    consecutive steps (second step: moments non-zero, one view empty)."""
+    from w3d_amd.fused_step import (GEO_BLOCKS, ROW_FLOATS, SH_BLOCKS, GatheredRows, apply_gradient_rows, pack_gradient_rows,
+                                    rows_adam, sh_adam_lowrank)
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.synth import make_scene
+    dev = torch.device("cuda:0")
+    sc = make_scene(P, seed=5)
+    ms = []
+    for _ in range(3):                       # [0] packs the views' rows, [1] rows_adam, [2] dense pipeline
+        m = GaussianModel(3, device=dev)
+        m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+        m.active_sh_degree = deg
+        m.training_setup(OptimizationParams())
+        ms.append(m)
+    packer, ma, mb = ms
+    gen = torch.Generator().manual_seed(P + deg)
+    campos = (torch.randn(3, 3, generator=gen) * 3.0).to(dev)
+    for step in (1, 2):
+        rows_v, cnt_v = [], []
+        for v in range(3):
+            keep = (torch.rand(P, generator=gen) < (0.0 if (step == 2 and v == 1) else 0.3)).to(dev)
+            packer.flat_grad.copy_(torch.randn(packer.flat.numel(), generator=gen).to(dev) * 1e-2)
+            for n in GEO_BLOCKS:
+                gv = packer.grad_view(n)
+                gv.mul_(keep.view(P, *([1] * (gv.dim() - 1))))
+            dcol = torch.randn(P, 3, generator=gen).to(dev) * 1e-2 * keep[:, None]
+            dcol[::7] = 0.0                                                   # rows whose colour gradient is fully clamped
+            gnorm = torch.rand(P, generator=gen).to(dev) * keep
+            r, c = pack_gradient_rows(packer, dcol, gnorm)
+            rows_v.append(r)
+            cnt_v.append(c)
+        counts = torch.cat(cnt_v)
+        cap = max(int(counts.max()), 1) + 5                                   # (slack rows beyond the counts hold garbage)
+        rows_all = torch.full((3, cap, ROW_FLOATS), float("nan"), device=dev)
+        for v in range(3):
+            n = int(counts[v])
+            rows_all[v, :n] = rows_v[v][:n]
+        # A: indexed rows, one optimizer kernel
+        ga = GatheredRows(ma, rows_all, counts)
+        nsum_a = ga.norm_sum()
+        ma.optimizer.advance(GEO_BLOCKS + SH_BLOCKS, skip)
+        rows_adam(ma, ga, campos, skip)
+        # B: dense arrays, low-rank SH step, Adam sweep over the geometry blocks
+        d_all = torch.zeros(3, P, 3, device=dev)
+        nsum_b = torch.zeros(P, device=dev)
+        mb.flat_grad.zero_()
+        for v in range(3):
+            apply_gradient_rows(mb, rows_all[v], counts[v:v + 1], cap, d_all[v], nsum_b)
+        mb.optimizer.advance(GEO_BLOCKS + SH_BLOCKS, skip)
+        sh_adam_lowrank(mb, d_all, campos, skip=skip)
+        mb.optimizer.step(only=GEO_BLOCKS, skip=skip, advance=False, respect_none_grads=False)
+        assert torch.equal(nsum_a, nsum_b)
+        assert ma.optimizer.steps == mb.optimizer.steps
+        for name, x, y in (("flat", ma.flat, mb.flat), ("exp_avg", ma.optimizer.exp_avg, mb.optimizer.exp_avg),
+                           ("exp_avg_sq", ma.optimizer.exp_avg_sq, mb.optimizer.exp_avg_sq)):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (step, name)
+        assert torch.isfinite(ma.flat).all()
+    for n in skip:                                                            # a skipped block was left alone
+        lo, hi = ma.block_slices()[n]
+        assert float(ma.optimizer.exp_avg[lo:hi].abs().max()) == 0.0

@@ -199,6 +199,9 @@ int w3d_launch_knn(int32_t N, const float *points, float *out, hipStream_t strea
 uint64_t w3d_knn_scratch_bytes(int32_t N);
 int w3d_launch_knn_grid(int32_t N, const float *points, float *out, char *scratch, hipStream_t stream);
 int w3d_launch_dcolor_extract(const W3DLayout &L, const char *state, const float *grad2d, float *dcolor_out, hipStream_t stream);
+int w3d_launch_rows_adam(int32_t P, int32_t nviews, int32_t sh_degree, const float *campos_all, const float *rows_all, uint32_t cap,
+                         const uint32_t *viewmask, const uint32_t *slots, const w3d_raw_blocks &pw, const w3d_adam_fused &a,
+                         hipStream_t stream);
 int w3d_launch_sh_adam_lowrank(int32_t P, int32_t nviews, int32_t sh_degree, const float *campos_all, const float *xyz,
                                const float *dcolor_all, float *f_dc, float *f_rest, float *m_dc, float *v_dc, float *m_rest,
                                float *v_rest, float lr_dc, float lr_rest, int skip_dc, int skip_rest, float beta1, float beta2,

@@ -88,6 +88,35 @@ apply_rows_kernel(int P, const float4 *__restrict__ rows, const uint32_t *__rest
     srot[4 * (size_t)g] += d.x; srot[4 * (size_t)g + 1] += d.y; srot[4 * (size_t)g + 2] += d.z; srot[4 * (size_t)g + 3] += d.w;
 }
 
+// (view, row) -> "Gaussian g has row r in view v": slots[v][g] = r and bit v of viewmask[g].  The indices of one view are
+// distinct; different views meet in the mask word only (atomic OR: order-independent).
+__global__ void __launch_bounds__(256)
+index_rows_kernel(int P, const float4 *__restrict__ rows_all, const uint32_t *__restrict__ counts, uint32_t cap,
+                  uint32_t *__restrict__ viewmask, uint32_t *__restrict__ slots) {
+    const uint32_t v = blockIdx.y, r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= min(counts[v], cap)) return;
+    const uint32_t g = __float_as_uint(rows_all[4 * ((size_t)v * cap + r)].x);
+    if (g >= (uint32_t)P) return;
+    slots[(size_t)v * P + g] = r;
+    atomicOr(&viewmask[g], 1u << v);
+}
+
+// norm_sum[g] = sum over the views that hold a row of g, in view order, of the row's ||dL/dmean2D|| (0 where none does)
+__global__ void __launch_bounds__(256)
+rows_norm_sum_kernel(int P, const float4 *__restrict__ rows_all, uint32_t cap, const uint32_t *__restrict__ viewmask,
+                     const uint32_t *__restrict__ slots, float *__restrict__ norm_sum) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P) return;
+    uint32_t mask = viewmask[g];
+    float s = 0.f;
+    while (mask) {
+        const uint32_t v = (uint32_t)__ffs((int)mask) - 1u;
+        mask &= mask - 1u;
+        s += rows_all[4 * ((size_t)v * cap + slots[(size_t)v * P + g])].y;
+    }
+    norm_sum[g] = s;
+}
+
 bool geo_ok(const w3d_raw_grads *g) {
     return g && g->xyz && g->opacity && g->scaling && g->rotation;
 }
@@ -128,4 +157,49 @@ extern "C" int w3d_apply_gradient_rows(int32_t P, const float *rows, const uint3
                        sums->scaling, sums->rotation, norm_sum);
     W3D_HIP_CHECK(hipGetLastError());
     return W3D_OK;
+}
+
+extern "C" int w3d_index_gradient_rows(int32_t P, int32_t n_views, const float *rows_all, const uint32_t *counts,
+                                       uint32_t cap_rows, uint32_t *viewmask, uint32_t *slots, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (P < 0 || n_views < 1 || n_views > 32) { w3d_set_error("index_gradient_rows: 1..32 views"); return W3D_ERR_INVALID; }
+    if (P == 0) return W3D_OK;
+    if (!viewmask || !slots || !counts || (cap_rows && (!rows_all || (reinterpret_cast<uintptr_t>(rows_all) & 15)))) {
+        w3d_set_error("index_gradient_rows: NULL buffer, or rows not 16-byte aligned");
+        return W3D_ERR_INVALID;
+    }
+    W3D_HIP_CHECK(hipMemsetAsync(viewmask, 0, (size_t)P * sizeof(uint32_t), stream));
+    if (cap_rows == 0) return W3D_OK;
+    W3D_PROF("index_gradient_rows", stream);
+    hipLaunchKernelGGL(index_rows_kernel, dim3((cap_rows + 255u) / 256u, (unsigned)n_views), dim3(256), 0, stream, P,
+                       reinterpret_cast<const float4 *>(rows_all), counts, cap_rows, viewmask, slots);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}
+
+extern "C" int w3d_rows_norm_sum(int32_t P, int32_t n_views, const float *rows_all, uint32_t cap_rows, const uint32_t *viewmask,
+                                 const uint32_t *slots, float *norm_sum, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (P < 0 || n_views < 1 || n_views > 32) { w3d_set_error("rows_norm_sum: 1..32 views"); return W3D_ERR_INVALID; }
+    if (P == 0) return W3D_OK;
+    if (!viewmask || !slots || !norm_sum || !rows_all) { w3d_set_error("rows_norm_sum: NULL buffer"); return W3D_ERR_INVALID; }
+    hipLaunchKernelGGL(rows_norm_sum_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, P,
+                       reinterpret_cast<const float4 *>(rows_all), cap_rows, viewmask, slots, norm_sum);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}
+
+extern "C" int w3d_rows_adam(int32_t P, int32_t n_views, int32_t sh_degree, const float *campos_all, const float *rows_all,
+                             uint32_t cap_rows, const uint32_t *viewmask, const uint32_t *slots, const w3d_raw_blocks *params,
+                             const w3d_adam_fused *adam, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (P < 0 || n_views < 1 || n_views > 32 || sh_degree < 0 || sh_degree > 3) { w3d_set_error("rows_adam: bad sizes"); return W3D_ERR_INVALID; }
+    if (P == 0) return W3D_OK;
+    if (!campos_all || !rows_all || !viewmask || !slots || !params || !adam) { w3d_set_error("rows_adam: NULL buffer"); return W3D_ERR_INVALID; }
+    for (int i = 0; i < 6; i++)
+        if (!adam->skip[i] && (!(adam->bias_correction1[i] > 0.f) || !(adam->bias_correction2[i] > 0.f))) {
+            w3d_set_error("rows_adam: bias corrections must be positive (step >= 1)");
+            return W3D_ERR_INVALID;
+        }
+    return w3d_launch_rows_adam(P, n_views, sh_degree, campos_all, rows_all, cap_rows, viewmask, slots, *params, *adam, stream);
 }

@@ -904,7 +904,104 @@ sh_adam_lowrank_kernel(int P, int nviews, int deg, const float *__restrict__ cam
     if (!(raw.skip_mask & 4u)) coop_adam<45, 4>(raw, 2, g0, rows, sh_stage, W3D_SHROW, 3);
 }
 
+// The replicated optimizer step of the SPARSE exchange (w3d_exchange.hip): the views' gradients arrive as packed 64-B rows
+// (rows_all: (nviews, cap, 16) floats), indexed per Gaussian by a view bit mask and, for every set bit, the row's position
+// (slots: (nviews, P)).  One lane per Gaussian walks its set bits in VIEW ORDER — the same additions in the same order on
+// every rank — rebuilding the SH gradient as sh_adam_lowrank_kernel does and summing the 11 geometry gradients; then the
+// workgroup applies torch.optim.Adam's update to all six parameter blocks through the LDS stage, exactly as the fused
+// single-GPU backward does.  Gaussians no view touched (most of them) cost one mask word on top of their optimizer traffic;
+// no dense per-view plane is zero-filled, scattered into or read.
+__global__ void __launch_bounds__(256)
+rows_adam_kernel(int P, int nviews, int deg, const float *__restrict__ campos_all, const float4 *__restrict__ rows_all, uint32_t cap,
+                 const uint32_t *__restrict__ viewmask, const uint32_t *__restrict__ slots, RawBwd raw) {
+    __shared__ float sh_stage[256 * W3D_SHROW];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = gid < P;
+    const int g = active ? gid : P - 1;
+    const int ncoef = (deg + 1) * (deg + 1);
+    float acc[48], geo[11];
+#pragma unroll
+    for (int i = 0; i < 48; i++) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 11; i++) geo[i] = 0.f;
+    uint32_t mask = active ? viewmask[g] : 0u;
+    // (the pre-update position: read before this kernel's own Adam phase for the xyz block)
+    const float *xyz = raw.pw[0];
+    const float p[3] = {xyz[3 * (size_t)g], xyz[3 * (size_t)g + 1], xyz[3 * (size_t)g + 2]};
+    while (mask) {
+        const int vw = __ffs((int)mask) - 1;
+        mask &= mask - 1u;
+        if (vw >= nviews) break;
+        const uint32_t r = slots[(size_t)vw * P + g];
+        const float4 *row = rows_all + 4 * ((size_t)vw * cap + r);
+        const float4 a = row[0], b = row[1], c = row[2], d = row[3];
+        geo[0] += b.y; geo[1] += b.z; geo[2] += b.w; geo[3] += c.x;
+        geo[4] += c.y; geo[5] += c.z; geo[6] += c.w;
+        geo[7] += d.x; geo[8] += d.y; geo[9] += d.z; geo[10] += d.w;
+        const float dr = a.z, dg = a.w, db = b.x;
+        if (dr == 0.f && dg == 0.f && db == 0.f) continue;      // (fully clamped in that view)
+        const float d0 = p[0] - campos_all[3 * vw], d1 = p[1] - campos_all[3 * vw + 1], d2 = p[2] - campos_all[3 * vw + 2];
+        const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        const float x = d0 / len, y = d1 / len, z = d2 / len;
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        float B[16];
+        B[0] = SH_C0;
+        B[1] = -SH_C1 * y; B[2] = SH_C1 * z; B[3] = -SH_C1 * x;
+        B[4] = SH_C2[0] * xy; B[5] = SH_C2[1] * yz; B[6] = SH_C2[2] * (2.f * zz - xx - yy);
+        B[7] = SH_C2[3] * xz; B[8] = SH_C2[4] * (xx - yy);
+        B[9] = SH_C3[0] * y * (3.f * xx - yy); B[10] = SH_C3[1] * xy * z; B[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+        B[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); B[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+        B[14] = SH_C3[5] * z * (xx - yy); B[15] = SH_C3[6] * x * (xx - 3.f * yy);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float bk = (k < ncoef) ? B[k] : 0.f;
+            acc[3 * k] += bk * dr; acc[3 * k + 1] += bk * dg; acc[3 * k + 2] += bk * db;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 48; i++) sh_stage[threadIdx.x * W3D_SHROW + i] = acc[i];
+    __syncthreads();
+    const size_t g0 = (size_t)blockIdx.x * 256;
+    const int rows = (int)min((size_t)256, (size_t)P - g0);
+    if (!(raw.skip_mask & 2u)) coop_adam<3, 1>(raw, 1, g0, rows, sh_stage, W3D_SHROW, 0);
+    if (!(raw.skip_mask & 4u)) coop_adam<45, 4>(raw, 2, g0, rows, sh_stage, W3D_SHROW, 3);
+    // the narrow blocks through the (now free) stage: row = [dxyz 3 | dopacity 1 | dscaling 3 | drotation 4], stride 15
+    __syncthreads();
+    float *st2 = sh_stage + threadIdx.x * 15;
+#pragma unroll
+    for (int i = 0; i < 11; i++) st2[i] = geo[i];
+    __syncthreads();
+    if (!(raw.skip_mask & 1u)) coop_adam<3, 1>(raw, 0, g0, rows, sh_stage, 15, 0);
+    if (!(raw.skip_mask & 8u)) coop_adam<1, 1>(raw, 3, g0, rows, sh_stage, 15, 3);
+    if (!(raw.skip_mask & 16u)) coop_adam<3, 1>(raw, 4, g0, rows, sh_stage, 15, 4);
+    if (!(raw.skip_mask & 32u)) coop_adam<4, 1>(raw, 5, g0, rows, sh_stage, 15, 7);
+}
+
 }  // namespace
+
+int w3d_launch_rows_adam(int32_t P, int32_t nviews, int32_t sh_degree, const float *campos_all, const float *rows_all, uint32_t cap,
+                         const uint32_t *viewmask, const uint32_t *slots, const w3d_raw_blocks &pw, const w3d_adam_fused &a,
+                         hipStream_t stream) {
+    if (P == 0) return W3D_OK;
+    RawBwd raw = {};
+    float *const pws[6] = {pw.xyz, pw.f_dc, pw.f_rest, pw.opacity, pw.scaling, pw.rotation};
+    float *const ms[6] = {a.exp_avg.xyz, a.exp_avg.f_dc, a.exp_avg.f_rest, a.exp_avg.opacity, a.exp_avg.scaling, a.exp_avg.rotation};
+    float *const vs[6] = {a.exp_avg_sq.xyz, a.exp_avg_sq.f_dc, a.exp_avg_sq.f_rest, a.exp_avg_sq.opacity, a.exp_avg_sq.scaling,
+                          a.exp_avg_sq.rotation};
+    for (int i = 0; i < 6; i++) {
+        if (!pws[i] || !ms[i] || !vs[i]) { w3d_set_error("rows_adam: NULL parameter / moment block"); return W3D_ERR_INVALID; }
+        raw.pw[i] = pws[i]; raw.m[i] = ms[i]; raw.v[i] = vs[i];
+        if (a.skip[i]) { raw.skip_mask |= 1u << i; continue; }
+        raw.step_size[i] = a.lr[i] / a.bias_correction1[i];
+        raw.inv_sqrt_bc2[i] = 1.0f / sqrtf(a.bias_correction2[i]);
+    }
+    raw.b1 = a.beta1; raw.b2 = a.beta2; raw.eps = a.eps;
+    W3D_PROF("rows_adam", stream);
+    hipLaunchKernelGGL(rows_adam_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, nviews, sh_degree, campos_all,
+                       reinterpret_cast<const float4 *>(rows_all), cap, viewmask, slots, raw);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}
 
 int w3d_launch_dcolor_extract(const W3DLayout &L, const char *state, const float *grad2d, float *dcolor_out, hipStream_t stream) {
     if (L.P == 0) return W3D_OK;

@@ -63,6 +63,13 @@ lib.w3d_pack_gradient_rows.argtypes = [_i32, _vp, ctypes.POINTER(W3DRawGrads), _
 lib.w3d_pack_gradient_rows.restype = ctypes.c_int
 lib.w3d_apply_gradient_rows.argtypes = [_i32, _vp, _vp, ctypes.c_uint32, _vp, ctypes.POINTER(W3DRawGrads), _vp, _vp]
 lib.w3d_apply_gradient_rows.restype = ctypes.c_int
+lib.w3d_index_gradient_rows.argtypes = [_i32, _i32, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp]
+lib.w3d_index_gradient_rows.restype = ctypes.c_int
+lib.w3d_rows_norm_sum.argtypes = [_i32, _i32, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp]
+lib.w3d_rows_norm_sum.restype = ctypes.c_int
+lib.w3d_rows_adam.argtypes = [_i32, _i32, _i32, _vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.POINTER(W3DRawGrads),
+                              ctypes.POINTER(W3DAdamFused), _vp]
+lib.w3d_rows_adam.restype = ctypes.c_int
 ROW_FLOATS = 16          # {index bits, ||dL/dmean2D||, dL/dRGB[3], d xyz[3], d opacity, d scaling[3], d rotation[4]}
 GEO_BLOCKS = ("xyz", "opacity", "scaling", "rotation")      # their gradients are all-reduced as they are (11 floats)
 SH_BLOCKS = ("f_dc", "f_rest")                               # rebuilt on every rank from the exchanged dL/dRGB
@@ -465,6 +472,61 @@ def apply_gradient_rows(model, rows, count, max_rows, dcolor_view, norm_sum=None
     with torch.cuda.device(dev):
         check(lib.w3d_apply_gradient_rows(P, ptr(rows), ptr(count), int(max_rows), ptr(dcolor_view), ctypes.byref(g),
                                           ptr(norm_sum), stream_ptr(dev)))
+
+
+class GatheredRows:
+    """The all-gathered gradient rows of one iteration, indexed per Gaussian (GPU path of the sparse exchange): rows_all
+    (V, cap, 16), counts (V,) int32 on the device, viewmask (P,) / slots (V, P) int32 built by w3d_index_gradient_rows."""
+
+    def __init__(self, model, rows_all, counts):
+        self.rows_all, self.counts = rows_all, counts
+        self.V, self.cap = int(rows_all.shape[0]), int(rows_all.shape[1])
+        P, dev = model.num_points, model.flat.device
+        assert rows_all.is_contiguous() and rows_all.shape[2] == ROW_FLOATS and counts.dtype == torch.int32
+        self.P = P
+        self.viewmask = torch.empty(max(P, 1), dtype=torch.int32, device=dev)
+        self.slots = torch.empty(self.V, max(P, 1), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.w3d_index_gradient_rows(P, self.V, ptr(rows_all), ptr(counts), self.cap, ptr(self.viewmask), ptr(self.slots),
+                                              stream_ptr(dev)))
+
+    def norm_sum(self):
+        """(P,) sum over the views, in view order, of the rows' ||dL/dmean2D||."""
+        dev = self.rows_all.device
+        out = torch.empty(max(self.P, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.w3d_rows_norm_sum(self.P, self.V, ptr(self.rows_all), self.cap, ptr(self.viewmask), ptr(self.slots), ptr(out),
+                                        stream_ptr(dev)))
+        return out[:self.P]
+
+
+def rows_adam(model, gathered, campos_all, skip=()):
+    """Replicated optimizer step of ALL six blocks from the gathered rows (include/w3d.h w3d_rows_adam): SH gradient rebuilt
+    per view direction, geometry gradients summed, both in view order, torch.optim.Adam's update in place — one kernel.
+    The optimizer's step counters must already be advanced for this iteration (FlatAdam.advance)."""
+    opt = model.optimizer
+    if model.max_sh_degree != 3:
+        raise RuntimeError("the row exchange is written for 16 SH coefficients")
+    if model.num_points != gathered.P:
+        raise RuntimeError("model was resized between the exchange and the optimizer step")
+    dev = model.flat.device
+    prm, ad = W3DRawGrads(), W3DAdamFused()
+    sl = model.block_slices()
+    b1, b2 = opt.betas
+    for i, n in enumerate(_BLOCK_ORDER):
+        a, _ = sl[n]
+        setattr(prm, n, model._p[n].data_ptr())
+        setattr(ad.exp_avg, n, opt.exp_avg.data_ptr() + 4 * a)
+        setattr(ad.exp_avg_sq, n, opt.exp_avg_sq.data_ptr() + 4 * a)
+        ad.lr[i] = float(opt.lrs[n])
+        ad.skip[i] = int(n in skip)
+        ad.bias_correction1[i], ad.bias_correction2[i] = (1.0, 1.0) if n in skip else opt.bias_corrections(n)
+    ad.beta1, ad.beta2, ad.eps = float(b1), float(b2), float(opt.eps)
+    cp = campos_all.to(device=dev, dtype=torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        check(lib.w3d_rows_adam(model.num_points, gathered.V, int(model.active_sh_degree), ptr(cp), ptr(gathered.rows_all),
+                                gathered.cap, ptr(gathered.viewmask), ptr(gathered.slots), ctypes.byref(prm), ctypes.byref(ad),
+                                stream_ptr(dev)))
 
 
 def flash_reblend(pkg, gt_mask, num_obj):

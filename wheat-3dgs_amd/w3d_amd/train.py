@@ -97,6 +97,7 @@ class Trainer:
         self.rows_speculate = True            # size the row collective from the previous step (exchange_rows)
         self._rows_cap = None
         self._rows_skip = 0
+        self._rows = None                     # fused_step.GatheredRows of the current iteration (GPU path of exchange_rows)
         self.exchange_used = {"rows": 0, "lowrank": 0}        # steps per form actually taken (rows mode decides per step)
         self.fused_adam = bool(fused_adam)
         self.exchange_mode = exchange
@@ -210,7 +211,7 @@ class Trainer:
         meantime); only if a view produced more rows than that does a second all-gather carry the remainder.  The host wait
         then falls where the GPU still has the collective and the apply kernels to run, instead of leaving it idle.
         Statistics: the norms travel in the rows; visibility counts as a u8 SUM, radii as an int32 MAX all-reduce."""
-        from .fused_step import ROW_FLOATS, apply_gradient_rows, pack_gradient_rows
+        from .fused_step import ROW_FLOATS, GatheredRows, apply_gradient_rows, pack_gradient_rows
         m = self.model
         P = m.num_points
         dev = dcolor.device
@@ -236,6 +237,7 @@ class Trainer:
             ev.synchronize()
             return pinned.tolist()
         # everything that does not depend on the counts is enqueued BEFORE the host reads them
+        gpu = dcolor.is_cuda
         vcount = rmax = nsum = None
         if tracking:
             vcount = visible.to(torch.uint8)
@@ -243,30 +245,31 @@ class Trainer:
             rmax = radii.clone()
             w2 = dist.all_reduce(rmax, op=dist.ReduceOp.MAX, async_op=True)
             self._stat_work = (w1, w2)
-            nsum = torch.zeros(P, dtype=torch.float32, device=dev)
-        d_all = torch.zeros(self.world, P, 3, dtype=torch.float32, device=dev)
         sl = m.block_slices()
         a, b = sl["xyz"][0], sl["rotation"][1]                    # xyz | opacity | scaling | rotation: one contiguous span
         assert b - a == 11 * P
 
-        def gather_and_apply(first, n):
-            """rows [first, first + n) of every view: one all-gather, then the views in order"""
+        def gather(first, n):
+            """rows [first, first + n) of every view: one all-gather -> (world, n, 16)"""
             part = torch.empty(self.world, n, ROW_FLOATS, dtype=torch.float32, device=dev)
             dist.all_gather_into_tensor(part.view(-1), rows[first:first + n].reshape(-1))
-            left = counts if first == 0 else (counts - first).clamp_(min=0)
-            for v in range(self.world):
-                apply_gradient_rows(m, part[v], left[v:v + 1], n, d_all[v], nsum)
+            return part
 
         cap = self._rows_cap
+        gathered = None
         if cap is not None:
             cap = min(cap, max(P, 1))
-            m.flat_grad[a:b].zero_()                              # (pack has read it: same stream)
-            gather_and_apply(0, cap)
+            first = gather(0, cap)
+            if gpu:
+                gathered = GatheredRows(m, first, counts)         # (indexing kernel enqueued behind the collective)
             hc = host_counts()                                    # the GPU is busy with the collective meanwhile
             nmax = max(hc)
+            parts = [first]
             if nmax > cap:                                        # a view outgrew the guess: the remainder follows
-                gather_and_apply(cap, nmax - cap)
+                parts.append(gather(cap, nmax - cap))
                 self.exchange_used["rows_overflow"] = self.exchange_used.get("rows_overflow", 0) + 1
+                if gpu:
+                    gathered = GatheredRows(m, torch.cat(parts, 1).contiguous(), counts)
         else:
             hc = host_counts()                                    # host wait: backward + a world-int collective
             nmax = max(hc)
@@ -281,13 +284,32 @@ class Trainer:
                     self._stat_work = self._stat_work + (dist.all_reduce(nsum, op=dist.ReduceOp.SUM, async_op=True),)
                 self.exchange_lowrank(dcolor, None, None, None, tracking=False)
                 return nsum, vcount, rmax
-            m.flat_grad[a:b].zero_()
-            gather_and_apply(0, max(nmax, 1))
+            parts = [gather(0, max(nmax, 1))]
+            if gpu:
+                gathered = GatheredRows(m, parts[0], counts)
         self.last_row_counts = hc
         self.exchange_used["rows"] += 1
         # next step's guess — or back to the exact, host-sized form when the views have become too dense for this one
         self._rows_cap = None if nmax > self.rows_limit(P) or not self.rows_speculate else \
             min(max(P, 1), (int(1.25 * nmax) + 1024) // 1024 * 1024)
+        if gpu:
+            # the optimizer kernel reads the rows through the per-Gaussian index (optimizer_step_lowrank -> w3d_rows_adam):
+            # no dense per-view array is zero-filled, scattered into or read
+            if tracking:
+                nsum = gathered.norm_sum()
+            self._rows, self._d_chunks, self._geo_work = gathered, [], []
+            return nsum, vcount, rmax
+        # host-logic path (CPU tensors, tests/test_dist_gloo.py): the same sums through dense arrays and the low-rank step
+        if tracking:
+            nsum = torch.zeros(P, dtype=torch.float32, device=dev)
+        d_all = torch.zeros(self.world, P, 3, dtype=torch.float32, device=dev)
+        m.flat_grad[a:b].zero_()
+        first = 0
+        for part in parts:
+            left = counts if first == 0 else (counts - first).clamp_(min=0)
+            for v in range(self.world):
+                apply_gradient_rows(m, part[v], left[v:v + 1], part.shape[1], d_all[v], nsum)
+            first += part.shape[1]
         self._d_chunks, self._geo_work = [[(0, P), d_all, None]], []
         return nsum, vcount, rmax
 
@@ -309,10 +331,15 @@ class Trainer:
         """Replicated optimizer step after exchange_lowrank: SH blocks from the gathered colour gradients (needs the
         pre-update xyz, so it runs first, while the geometry all-reduces are still in flight), then the geometry blocks
         from the reduced bucket.  Identical inputs and a fixed view order keep the replicas bit-identical."""
-        from .fused_step import GEO_BLOCKS, SH_BLOCKS, sh_adam_lowrank
+        from .fused_step import GEO_BLOCKS, SH_BLOCKS, rows_adam, sh_adam_lowrank
         m = self.model
         m.optimizer.advance(GEO_BLOCKS + SH_BLOCKS, skip)
         campos = self.campos_of_all_ranks(iteration).to(m.flat.device)
+        if self._rows is not None:           # sparse exchange on the GPU: all six blocks in one kernel, straight from the rows
+            rows_adam(m, self._rows, campos, skip)
+            m._bucket_claimed = False
+            self._rows = None
+            return
         whole = len(self._d_chunks) == 1
         for rows, d_all, work in self._d_chunks:
             if work is not None:
@@ -332,6 +359,7 @@ class Trainer:
         for w in self._geo_work or ():
             w.wait()
         self._geo_work = None
+        self._rows = None
 
     def wait_stats(self):
         """Make the current stream wait for the statistics all-reduces of exchange()."""
