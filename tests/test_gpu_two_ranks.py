@@ -99,7 +99,8 @@ def worker(rank, world, port, mode, outdir, backend="gloo_staged"):
     m, opt, cams = _scene_and_cams(dev)
     # "lowrank_early": the colour-gradient all-gather is issued between the two halves of the backward
     tr = Trainer(m, cams, opt, torch.zeros(3, device=dev), densify=True, cameras_extent=2.0,
-                 exchange="lowrank" if mode.startswith("lowrank") else mode, early_gather=mode == "lowrank_early")
+                 exchange="lowrank" if mode.startswith("lowrank") else mode, early_gather=mode == "lowrank_early",
+                 rows_max_fraction=1.0)   # (small dense test views: take the sparse form however many rows a view has)
     assert tr.world == world and tr.rank == rank
     snaps = {}
     for it in range(1, 8):              # densifies at iteration 4, resets the opacities at iteration 6
@@ -109,7 +110,8 @@ def worker(rank, world, port, mode, outdir, backend="gloo_staged"):
             snaps[it] = dict(flat=m.flat.detach().cpu().numpy(), m=m.optimizer.exp_avg.cpu().numpy(),
                              v=m.optimizer.exp_avg_sq.cpu().numpy(), accum=m.xyz_gradient_accum.cpu().numpy(),
                              denom=m.denom.cpu().numpy(), radii=m.max_radii2D.cpu().numpy(), P=np.array(m.num_points))
-    np.savez(os.path.join(outdir, f"rank{rank}_{mode}.npz"), **{f"{k}_{it}": v for it, s in snaps.items() for k, v in s.items()})
+    used = np.array([tr.exchange_used.get("rows", 0), tr.exchange_used.get("lowrank", 0)])
+    np.savez(os.path.join(outdir, f"rank{rank}_{mode}.npz"), used=used, **{f"{k}_{it}": v for it, s in snaps.items() for k, v in s.items()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -147,6 +149,8 @@ def _check_replicas_and_mean_gradient_step(snaps, world, mode):
         for k in a.files:                # replicas bit-identical, before and after the densification and the opacity reset
             assert np.array_equal(a[k], b[k]), f"{mode}: rank {r} differs from rank 0 in {k}"
     assert int(a["P_7"]) != P            # the schedule really densified
+    if mode == "rows":                   # ... and every iteration went through the sparse form (none was too dense)
+        assert a["used"].tolist() == [7, 0], a["used"]
 
     # single-process reference of step 1: Adam on the MEAN of the ranks' views' gradients, statistics summed / maxed
     from w3d_amd.fused_step import backward_raw, render_raw

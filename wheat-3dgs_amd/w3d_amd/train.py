@@ -340,6 +340,8 @@ class Trainer:
             m._bucket_claimed = False
             self._rows = None
             return
+        if not self._d_chunks:
+            raise RuntimeError("optimizer_step_lowrank: no exchanged gradients to step from (exchange_lowrank / exchange_rows first)")
         whole = len(self._d_chunks) == 1
         for rows, d_all, work in self._d_chunks:
             if work is not None:
@@ -359,7 +361,8 @@ class Trainer:
         for w in self._geo_work or ():
             w.wait()
         self._geo_work = None
-        self._rows = None
+        # (self._rows — the sparse form's gathered rows — needs no wait: its collectives were synchronous on this stream; an
+        #  opacity-reset iteration still steps from it after _post_backward)
 
     def wait_stats(self):
         """Make the current stream wait for the statistics all-reduces of exchange()."""
@@ -525,6 +528,7 @@ class Trainer:
                 else:
                     # (the reference's step skips every replaced parameter in a densification iteration)
                     self._drain_lowrank()
+                    self._rows, self._d_chunks = None, []
             elif iteration < opt.iterations:
                 # the next backward overwrites the whole bucket: no zeroing pass needed
                 self.optimizer_step_and_gather(zero_grad=bool(skip), skip=skip)
