@@ -100,6 +100,8 @@ class Trainer:
         self._rows = None                     # fused_step.GatheredRows of the current iteration (GPU path of exchange_rows)
         self.exchange_used = {"rows": 0, "lowrank": 0}        # steps per form actually taken (rows mode decides per step)
         self.fused_adam = bool(fused_adam)
+        if exchange == "rows" and self.world > 32:
+            exchange = "lowrank"              # (the per-Gaussian view mask of the sparse form is one 32-bit word)
         self.exchange_mode = exchange
         self.early_gather = bool(early_gather)
         self._d_chunks, self._geo_work = [], None
