@@ -56,9 +56,12 @@ def test_subset_render_small_matches_reference_formulation_and_oracle():
         cam = cams[1].to(dev)
         with torch.no_grad():
             fast = flashsplat_render(cam, m, PipelineParams(), bg, used_mask=used)
+            assert hasattr(used, "_w3d_rows")           # the kernel-side path ran (it leaves its cached row list on the mask)
             # an index tensor selects the same rows but is not the fast path's input type: the reference's formulation,
             # gathered activated blocks through the drop-in module
-            slow = flashsplat_render(cam, m, PipelineParams(), bg, used_mask=used.nonzero(as_tuple=True)[0])
+            idx = used.nonzero(as_tuple=True)[0]
+            slow = flashsplat_render(cam, m, PipelineParams(), bg, used_mask=idx)
+            assert not hasattr(idx, "_w3d_rows")        # ... and this one went through the gathered blocks
         n = int(sel_np.sum())
         assert set(fast) == set(KEYS) == set(slow), case
         for k in KEYS:
@@ -145,6 +148,7 @@ def test_subset_render_c4_size_against_oracle(kind):
         cam = cams[vi]
         with torch.no_grad():
             pkg = flashsplat_render(cam.to(dev), m, PipelineParams(), bg, used_mask=used)
+            assert hasattr(used, "_w3d_rows")           # (kernel-side subset path)
             pkg2 = flashsplat_render(cam.to(dev), m, PipelineParams(), bg, used_mask=used)     # speculative list size now
         assert torch.equal(pkg["alpha"], pkg2["alpha"]) and torch.equal(pkg["radii"], pkg2["radii"])
         o = make_oracle(cam, (0.0, 0.0, 0.0), nthreads=NTHREADS)
