@@ -562,10 +562,12 @@ class Trainer:
         return loss.detach()
 
 
-RENDER_STREAMS = 2      # frames in flight of render_views (independent frames overlap each other's latency-bound stages;
-                        # 2 M Gaussians at 1600x1200, profiles/render_host_probe.py, two boxes: 1 stream 0.741 / 0.745 ms per frame,
-                        # 2: 0.661 / 0.643, 3: 0.649 / 0.673, 4: 0.644 / 0.639 — more than two is within the noise; the host
-                        # needs 0.19 ms to enqueue a frame, so the loop is GPU-bound)
+RENDER_STREAMS = 3      # frames in flight of render_views (independent frames overlap each other's latency-bound stages).
+                        # 2 M Gaussians at 1600x1200: 1 stream 0.74 ms per frame, 2-4 streams 0.62-0.66 (profiles/render_host_probe.py;
+                        # the host needs 0.19 ms to enqueue a frame, so the loop is GPU-bound).  Three, not two: HIP streams share
+                        # a handful of hardware queues, and WHICH two pool streams a process gets decides whether they overlap at
+                        # all — the same loop ran at 2550 Mpix/s on one pair and 3050 on another within one process, and at
+                        # 2940-3100 with any three (profiles/r03/render_stream_pairs.json).
 
 
 def render_views(model, cameras, background, pipe=None):
