@@ -201,17 +201,19 @@ class Trainer:
         """Sparse exchange of the view-parallel step.  Contract as exchange_lowrank().  A view gives a gradient only to the
         Gaussians its pixels blended — every other row of dcolor and of the geometry gradients is exactly zero — so the
         ranks all-gather their NON-ZERO rows (64 B: index, ||dL/dmean2D||, dL/dRGB, 11 geometry gradients; packed by
-        w3d_pack_gradient_rows) and every rank rebuilds the dense per-view colour gradients and the sum over views of
-        the geometry gradients by applying the views' rows in VIEW ORDER (w3d_apply_gradient_rows): identical additions in
-        identical order on every rank keep the replicas bit-identical, as in the low-rank form, and the same replicated
-        optimizer step follows (optimizer_step_lowrank).
-        Sizing the collective.  The row counts are all-gathered too, and the apply kernels read them on the device.  The
+        w3d_pack_gradient_rows).  On the GPU nothing dense is rebuilt from them: w3d_index_gradient_rows leaves a per-Gaussian
+        view mask + row positions (fused_step.GatheredRows) and the replicated optimizer step reads the rows through it,
+        every Gaussian's views IN VIEW ORDER (optimizer_step_lowrank -> w3d_rows_adam) — identical additions in identical
+        order on every rank keep the replicas bit-identical, as in the low-rank form.  (CPU tensors, the host-logic tests:
+        the same sums through dense arrays, w3d_apply_gradient_rows' torch twin, and the low-rank step.)
+        Sizing the collective.  The row counts are all-gathered too, and the kernels read them on the device.  The
         first step (and every step after one that was too dense) waits for them on the host, sizes the collective exactly
         and decides — identically on every rank — whether the views are sparse enough (rows_limit) or go through
-        exchange_lowrank.  Later steps are SPECULATIVE: the collective is sized 1.25 x the previous step's largest count and
-        enqueued together with its apply kernels before the host looks at the counts (which arrive in pinned memory in the
-        meantime); only if a view produced more rows than that does a second all-gather carry the remainder.  The host wait
-        then falls where the GPU still has the collective and the apply kernels to run, instead of leaving it idle.
+        exchange_lowrank (as do the ROWS_RETRY steps after such a one, without counting rows).  Later steps are SPECULATIVE:
+        the collective is sized 1.25 x the previous step's largest count and enqueued together with the indexing kernel
+        before the host looks at the counts (which arrive in pinned memory in the meantime); only if a view produced more
+        rows than that does a second all-gather carry the remainder.  The host wait then falls where the GPU still has the
+        collective to run, instead of leaving it idle.
         Statistics: the norms travel in the rows; visibility counts as a u8 SUM, radii as an int32 MAX all-reduce."""
         from .fused_step import ROW_FLOATS, GatheredRows, apply_gradient_rows, pack_gradient_rows
         m = self.model
@@ -261,12 +263,11 @@ class Trainer:
         gathered = None
         if cap is not None:
             cap = min(cap, max(P, 1))
-            first = gather(0, cap)
+            parts = [gather(0, cap)]
             if gpu:
-                gathered = GatheredRows(m, first, counts)         # (indexing kernel enqueued behind the collective)
+                gathered = GatheredRows(m, parts[0], counts)      # (indexing kernel enqueued behind the collective)
             hc = host_counts()                                    # the GPU is busy with the collective meanwhile
             nmax = max(hc)
-            parts = [first]
             if nmax > cap:                                        # a view outgrew the guess: the remainder follows
                 parts.append(gather(cap, nmax - cap))
                 self.exchange_used["rows_overflow"] = self.exchange_used.get("rows_overflow", 0) + 1
@@ -306,12 +307,12 @@ class Trainer:
             nsum = torch.zeros(P, dtype=torch.float32, device=dev)
         d_all = torch.zeros(self.world, P, 3, dtype=torch.float32, device=dev)
         m.flat_grad[a:b].zero_()
-        first = 0
+        done = 0
         for part in parts:
-            left = counts if first == 0 else (counts - first).clamp_(min=0)
+            left = counts if done == 0 else (counts - done).clamp_(min=0)
             for v in range(self.world):
                 apply_gradient_rows(m, part[v], left[v:v + 1], part.shape[1], d_all[v], nsum)
-            first += part.shape[1]
+            done += part.shape[1]
         self._d_chunks, self._geo_work = [[(0, P), d_all, None]], []
         return nsum, vcount, rmax
 
