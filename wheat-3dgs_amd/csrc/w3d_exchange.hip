@@ -5,9 +5,12 @@
 // scene a few hundred thousand.  Every other row of the (P,3) colour gradient and of the 11 geometry gradients is exactly
 // zero, and adding zeros changes no sum — so a rank ships ONLY the non-zero rows, 64 B each:
 //     {index, ||dL/dmean2D|| * norm_scale, dL/dRGB[3], d xyz[3], d opacity, d scaling[3], d rotation[4]}
-// (all-gather of the packed rows, train.Trainer.exchange_rows), and every rank rebuilds the per-view dense colour gradients
-// and the SUM over views of the geometry gradients by applying the views' rows in view order: the same additions in the same
-// order on every rank, so the replicas stay bit-identical without any parameter traffic.
+// (all-gather of the packed rows, train.Trainer.exchange_rows).  Nothing dense is rebuilt from them: index_rows_kernel leaves,
+// per Gaussian, a bit mask of the views that hold a row of it and the row's position in each, and the replicated optimizer
+// step (rows_adam_kernel, w3d_preprocess.hip) walks every Gaussian's set bits in VIEW ORDER — the same additions in the same
+// order on every rank, so the replicas stay bit-identical without any parameter traffic.  apply_rows_kernel is the dense
+// materialisation of the same sums (one launch per view): the checker of the indexed path and the form a caller uses who
+// wants the (V,P,3) colour planes and the summed geometry gradients themselves.
 #include "w3d_common.h"
 
 namespace {
