@@ -93,6 +93,13 @@ typedef struct w3d_view {
                                  * its pixels saturate — is only known afterwards; a training loop renders the same camera again
                                  * and again, so the caller may keep one such array per camera: stage 2 orders its tiles by the
                                  * values it finds (zeros: image order) and overwrites them with this render's walk lengths. */
+    int32_t records_kept_clean; /* backward only, deterministic = 0.  The first P * 64 bytes of the backward scratch are the
+                                 * per-Gaussian records the blend backward adds to; they must start at zero.  0: the backward
+                                 * zeroes the visible Gaussians' records itself (a pass of its own).  1: the caller promises they
+                                 * ARE zero on entry — a scratch buffer it keeps from call to call, zero-filled once — and the
+                                 * per-Gaussian backward, which consumes every record it reads, writes zeros back: no zeroing
+                                 * pass, and the buffer is clean again when the call (for the two-call form: the second call)
+                                 * has run. */
 } w3d_view;
 
 int w3d_version(void);

@@ -640,3 +640,80 @@ def test_two_views_in_one_backward_pass_add_up():
     m.optimizer.zero_grad(set_to_none=True)
     (render(cams[2], m, PipelineParams(), bg)["render"] * wts[0]).sum().backward()
     assert all(p.grad.data_ptr() == m.grad_view(n).data_ptr() for n, p in m._p.items())
+
+
+def test_kept_backward_scratch_is_handed_back_clean_and_changes_no_gradient(monkeypatch):
+    """w3d_view.records_kept_clean: a model keeps its backward scratch from call to call, the blend backward skips its zeroing
+    pass and the per-Gaussian backward writes zeros over every record it consumed.  Invariant: after EVERY backward flavour
+    (gradient-writing, fused Adam, low-rank in one call and in two, alternating views with different visible sets) the buffer
+    is all zero bits again; and the gradients equal those of the same calls on a fresh scratch zeroed by the library.  A
+    backward abandoned half way (first half of the two-call form only) leaves the buffer dirty and marked so: the next call
+    zero-fills it."""
+    import w3d_amd.fused_step as FS
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    dev = torch.device("cuda:0")
+    W, H = 208, 160
+    cams = [c.to(dev) for c in make_cameras(5, W, H)]
+    sc = make_scene(7001, seed=41, scale_mean=0.03)
+    bg = torch.zeros(3, device=dev)
+    g = torch.Generator().manual_seed(3)
+    dimgs = [torch.randn(3, H, W, generator=g).to(dev) * 1e-2 for _ in cams]
+
+    def model():
+        m = GaussianModel(3, device=dev)
+        m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+        m.active_sh_degree = 3
+        m.training_setup(OptimizationParams())
+        return m
+
+    def clean(m):
+        k = m._w3d_bwd_scratch
+        return k.clean and int(torch.count_nonzero(k.buf)) == 0
+
+    def run(m, kept):
+        if not kept:     # the library zeroes a fresh buffer per call (records_kept_clean = 0)
+            monkeypatch.setattr(FS, "backward_scratch", lambda view, P, pl, d, owner=None: real(view, P, pl, d, None))
+        else:
+            monkeypatch.setattr(FS, "backward_scratch", real)
+        out = []
+        with torch.no_grad():
+            for i, cam in enumerate(cams):
+                pkg = FS.render_raw(cam, m, bg, sync=True)
+                if i % 3 == 0:
+                    gn, m2d = FS.backward_raw(m, pkg["handle"], dimgs[i], want_norm=True, want_means2D=True)
+                    out.append((m.flat_grad.clone(), gn.clone(), m2d.clone()))
+                elif i % 3 == 1:
+                    gn, dcol = FS.backward_raw_lowrank(m, pkg["handle"], dimgs[i])
+                    out.append((m.flat_grad.clone(), gn.clone(), dcol.clone()))
+                else:
+                    early = FS.backward_blend_dcolor(m, pkg["handle"], dimgs[i])
+                    if kept:
+                        assert not m._w3d_bwd_scratch.clean            # between the halves: dirty, and marked so
+                    gn, _ = FS.backward_raw_lowrank(m, pkg["handle"], None)
+                    out.append((m.flat_grad.clone(), gn.clone(), early.clone()))
+                if kept:
+                    assert clean(m), i
+        return out
+    real = FS.backward_scratch
+    a, b = run(model(), True), run(model(), False)
+    for i, (xa, xb) in enumerate(zip(a, b)):
+        for ta, tb in zip(xa, xb):
+            scale = float(tb.abs().max()) + 1e-30
+            assert float((ta - tb).abs().max()) <= 2e-5 * scale, (i, float((ta - tb).abs().max()) / scale)
+    # abandoned first half -> dirty; the next complete backward zero-fills, computes the same gradient and leaves it clean
+    monkeypatch.setattr(FS, "backward_scratch", real)
+    m = model()
+    with torch.no_grad():
+        pkg = FS.render_raw(cams[0], m, bg, sync=True)
+        FS.backward_blend_dcolor(m, pkg["handle"], dimgs[0] * 3.0)
+        assert not m._w3d_bwd_scratch.clean and int(torch.count_nonzero(m._w3d_bwd_scratch.buf)) > 0
+        pkg = FS.render_raw(cams[0], m, bg, sync=True)
+        gn, m2d = FS.backward_raw(m, pkg["handle"], dimgs[0], want_norm=True, want_means2D=True)
+        assert clean(m)
+        scale = float(a[0][0].abs().max())
+        assert float((m.flat_grad - a[0][0]).abs().max()) <= 2e-5 * scale
+        # ... and the fused-Adam flavour (reads the same records) hands it back clean as well
+        pkg = FS.render_raw(cams[1], m, bg, sync=True)
+        FS.backward_raw_adam(m, pkg["handle"], dimgs[1])
+        assert clean(m)

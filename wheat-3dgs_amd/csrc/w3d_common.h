@@ -188,7 +188,7 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
                                hipStream_t stream);
 int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,
                                    const float *colors_precomp, const float *scales, const float *rotations,
-                                   const float *cov3D_precomp, const char *state, const float *grad2d,
+                                   const float *cov3D_precomp, const char *state, float *grad2d,
                                    float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors, float *dL_dshs,
                                    float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
                                    const struct W3DRawBwdArgs *rawargs, hipStream_t stream);

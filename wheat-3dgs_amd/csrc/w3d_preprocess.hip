@@ -535,7 +535,7 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *means3D, const float *shs,
                       // the fused-Adam flavour updates the same memory through raw.pw[] later in the kernel; the workgroup
                       // barrier before the update is the only ordering it relies on)
                       const ushort4 *__restrict__ rect, const uint8_t *__restrict__ clamped,
-                      const float *__restrict__ grad2d,
+                      float *grad2d /* read; written back as zeros under records_kept_clean */,
                       float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dcolors,
                       float *__restrict__ dL_dshs, float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
                       float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D) {
@@ -580,8 +580,14 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *means3D, const float *shs,
     } else {
         Cam cam;
         load_cam(v, cam);
-        const float4 *rec = reinterpret_cast<const float4 *>(grad2d + (size_t)g * W3D_G2D_STRIDE);
+        float4 *rec = reinterpret_cast<float4 *>(grad2d + (size_t)g * W3D_G2D_STRIDE);
         const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        if (v.records_kept_clean && !v.deterministic) {
+            // this lane is the record's only reader: hand the buffer back zeroed (w3d_view.records_kept_clean) instead of
+            // running a zeroing pass in front of every blend backward (the blend adds to floats 0..9 only)
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            rec[0] = z; rec[1] = z; rec[2] = z;
+        }
         dm2[0] = r0.x; dm2[1] = r0.y;
         const float dconic[3] = {r0.z, r0.w, r1.x};
         dop = r1.y;
@@ -1067,7 +1073,7 @@ int w3d_launch_flash_extras(const W3DLayout &L, const w3d_view &v, const int32_t
 
 int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const float *means3D, const float *shs,
                                    const float *colors_precomp, const float *scales, const float *rotations,
-                                   const float *cov3D_precomp, const char *state, const float *grad2d,
+                                   const float *cov3D_precomp, const char *state, float *grad2d,
                                    float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dcolors, float *dL_dshs,
                                    float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
                                    const W3DRawBwdArgs *rawargs, hipStream_t stream) {

@@ -830,8 +830,9 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
         inst_cap = (uint32_t)cap;
         // entries the reverse walk never reaches contribute nothing: their slots stay zero
         if (cap) W3D_HIP_CHECK(hipMemsetAsync(inst, 0, cap * W3D_G2D_STRIDE * sizeof(float), stream));
-    } else if (Pz) {
-        // the records the atomics add to start at zero (own kernel rather than hipMemsetAsync: strictly stream-ordered)
+    } else if (Pz && !v.records_kept_clean) {
+        // the records the atomics add to start at zero (own kernel rather than hipMemsetAsync: strictly stream-ordered);
+        // records_kept_clean: the caller's buffer is zero already and preprocess_bwd_kernel leaves it so (w3d.h)
         hipLaunchKernelGGL(zero_visible_records_kernel, dim3((unsigned)((4 * Pz + 255) / 256)), dim3(256), 0, stream,
                            reinterpret_cast<float4 *>(grad2d), reinterpret_cast<const uint2 *>(state + L.o_rect), Pz);
     }

@@ -27,7 +27,8 @@ class W3DView(ctypes.Structure):
                 ("bg", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
                 ("projmatrix", ctypes.c_void_p), ("campos", ctypes.c_void_p),
                 ("tile_cull", ctypes.c_int32), ("deterministic", ctypes.c_int32),
-                ("det_list_capacity", ctypes.c_uint64), ("tile_walk_hint", ctypes.c_void_p)]
+                ("det_list_capacity", ctypes.c_uint64), ("tile_walk_hint", ctypes.c_void_p),
+                ("records_kept_clean", ctypes.c_int32)]
 
 
 def _load():

@@ -13,7 +13,7 @@ import math
 import torch
 
 from ._lib import W3DView, check, lib, ptr, stream_ptr
-from .rasterizer import GaussianRasterizationSettings, _View, backward_scratch, list_capacity
+from .rasterizer import GaussianRasterizationSettings, _View, backward_scratch, list_capacity, scratch_done
 
 _vp, _i32 = ctypes.c_void_p, ctypes.c_int32
 
@@ -210,10 +210,11 @@ def backward_raw(model, handle, dL_dimage, dL_ddepth=None, dL_dalpha=None, updat
         st.xyz_gradient_accum, st.denom = model.xyz_gradient_accum.data_ptr(), model.denom.data_ptr()
         st.max_radii2D = model.max_radii2D.data_ptr()
     with torch.cuda.device(dev):
-        scratch = backward_scratch(view, P, handle["point_list"], dev)
+        scratch = backward_scratch(view, P, handle["point_list"], dev, owner=model)
         check(lib.w3d_backward_raw(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(handle["state"]),
                                    ptr(handle["point_list"]), ptr(dL_dimage.contiguous()), ptr(dL_ddepth), ptr(dL_dalpha),
                                    ctypes.byref(g), ctypes.byref(st), ptr(scratch), stream_ptr(dev)))
+        scratch_done(view, model)
     return gnorm, m2d
 
 
@@ -313,10 +314,11 @@ def backward_raw_adam(model, handle, dL_dimage, skip=(), want_norm=True, update_
         st.xyz_gradient_accum, st.denom = model.xyz_gradient_accum.data_ptr(), model.denom.data_ptr()
         st.max_radii2D = model.max_radii2D.data_ptr()
     with torch.cuda.device(dev):
-        scratch = backward_scratch(view, P, handle["point_list"], dev)
+        scratch = backward_scratch(view, P, handle["point_list"], dev, owner=model)
         check(lib.w3d_backward_raw_adam(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(handle["state"]),
                                         ptr(handle["point_list"]), ptr(dL_dimage.contiguous()), None, None,
                                         ctypes.byref(ad), ctypes.byref(st), ptr(scratch), stream_ptr(dev)))
+        scratch_done(view, model)
     return gnorm
 
 
@@ -330,7 +332,7 @@ def backward_blend_dcolor(model, handle, dL_dimage):
         raise RuntimeError("model was resized between forward and backward")
     dcol = torch.empty(P, 3, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        scratch = backward_scratch(view, P, handle["point_list"], dev)
+        scratch = backward_scratch(view, P, handle["point_list"], dev, owner=model)      # (clean again after the second half)
         check(lib.w3d_backward_blend_dcolor(ctypes.byref(view.c), P, ptr(handle["state"]), ptr(handle["point_list"]),
                                             ptr(dL_dimage.contiguous()), None, None, ptr(dcol), ptr(scratch), stream_ptr(dev)))
     handle["bwd_scratch"] = scratch
@@ -361,12 +363,14 @@ def backward_raw_lowrank(model, handle, dL_dimage, want_norm=True):
             check(lib.w3d_backward_raw_lowrank(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(handle["state"]),
                                                ptr(handle["point_list"]), None, None, None, ctypes.byref(g), None,
                                                ctypes.byref(st), ptr(scratch), stream_ptr(dev)))
+            scratch_done(view, model)
             return gnorm, None
         dcol = torch.empty(P, 3, dtype=torch.float32, device=dev)
-        scratch = backward_scratch(view, P, handle["point_list"], dev)
+        scratch = backward_scratch(view, P, handle["point_list"], dev, owner=model)
         check(lib.w3d_backward_raw_lowrank(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(handle["state"]),
                                            ptr(handle["point_list"]), ptr(dL_dimage.contiguous()), None, None,
                                            ctypes.byref(g), ptr(dcol), ctypes.byref(st), ptr(scratch), stream_ptr(dev)))
+        scratch_done(view, model)
     return gnorm, dcol
 
 

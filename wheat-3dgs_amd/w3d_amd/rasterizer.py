@@ -256,9 +256,33 @@ def _forward_impl(settings, means3D, shs, colors_precomp, opacities, scales, rot
     return color, radii, depth, alpha, saved, extras
 
 
-def backward_scratch(view, P, point_list, dev):
-    """The scratch buffer of a backward call; selects the deterministic mode in the C struct when `view` asks for it."""
+class KeptScratch:
+    """A backward scratch buffer an owner (a GaussianModel) keeps from call to call, so that the per-Gaussian gradient records
+    at its start need no zeroing pass (include/w3d.h, w3d_view.records_kept_clean): zero-filled once, then every backward
+    hands it back clean.  `clean` is False while a backward that dirtied it has not been followed by the call that
+    consumes (and clears) the records — begin() then zero-fills again."""
+
+    def __init__(self):
+        self.buf, self.clean = None, False
+
+    def begin(self, nbytes, dev):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != dev:
+            self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        elif not self.clean:
+            self.buf.zero_()
+        self.clean = False            # dirty from now on; done() after the consuming call
+        return self.buf
+
+    def done(self):
+        self.clean = True
+
+
+def backward_scratch(view, P, point_list, dev, owner=None):
+    """The scratch buffer of a backward call; selects the deterministic mode in the C struct when `view` asks for it.
+    owner: an object that keeps the buffer between calls (KeptScratch on owner._w3d_bwd_scratch) — the backward then skips
+    its zeroing pass; the caller must call owner._w3d_bwd_scratch.done() once the per-Gaussian backward has been enqueued."""
     sb = ctypes.c_uint64()
+    view.c.records_kept_clean = 0
     if view.deterministic:
         cap = int(point_list.numel())
         view.c.deterministic, view.c.det_list_capacity = 1, cap
@@ -266,7 +290,19 @@ def backward_scratch(view, P, point_list, dev):
     else:
         view.c.deterministic, view.c.det_list_capacity = 0, 0
         check(lib.w3d_backward_sizes(P, ctypes.byref(sb)))
+        if owner is not None:
+            kept = getattr(owner, "_w3d_bwd_scratch", None)
+            if kept is None:
+                kept = owner._w3d_bwd_scratch = KeptScratch()
+            view.c.records_kept_clean = 1
+            return kept.begin(sb.value, dev)
     return torch.empty(sb.value, dtype=torch.uint8, device=dev)
+
+
+def scratch_done(view, owner):
+    """The per-Gaussian backward that consumes the records has been enqueued: the kept buffer is clean again."""
+    if owner is not None and view.c.records_kept_clean:
+        owner._w3d_bwd_scratch.done()
 
 
 def _backward_impl(saved, grad_color, grad_depth, grad_alpha):
