@@ -626,9 +626,16 @@ def main():
         from w3d_amd.train import PipelineParams
         yy, xx = torch.meshgrid(torch.arange(args.height, device=dev), torch.arange(args.width, device=dev), indexing="ij")
         mask = (((xx - args.width // 2) ** 2 + (yy - args.height // 2) ** 2) < (args.height // 3) ** 2).float()
-        n_f = 8
+        n_f = 16
         with torch.no_grad():
-            flashsplat_render(cams[0], model, PipelineParams(), bg, gt_mask=mask, obj_num=1)
+            # (warm-up with the loop's own holding pattern — view, running sum, next view — so that every block the loop
+            #  needs exists in torch's allocator before the clock starts: the 16 timed views take ~15 ms, one first-time
+            #  hipMalloc 1-2 ms)
+            counts = None
+            for i in range(3):
+                uc = flashsplat_render(cams[i], model, PipelineParams(), bg, gt_mask=mask, obj_num=1)["used_count"]
+                counts = uc if counts is None else counts + uc
+            del counts, uc
             sync()
             f0 = time.perf_counter()
             counts = None
