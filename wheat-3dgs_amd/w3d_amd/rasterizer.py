@@ -260,7 +260,9 @@ class KeptScratch:
     """A backward scratch buffer an owner (a GaussianModel) keeps from call to call, so that the per-Gaussian gradient records
     at its start need no zeroing pass (include/w3d.h, w3d_view.records_kept_clean): zero-filled once, then every backward
     hands it back clean.  `clean` is False while a backward that dirtied it has not been followed by the call that
-    consumes (and clears) the records — begin() then zero-fills again."""
+    consumes (and clears) the records — begin() then zero-fills again.  One backward at a time per owner: successive
+    backwards of a model are ordered by the stream they are enqueued on (autograd and the trainer both use the current
+    stream); backwards of ONE model enqueued on different streams at once would share the records."""
 
     def __init__(self):
         self.buf, self.clean = None, False
