@@ -436,18 +436,23 @@ def time_dropin(args, sc, cams, bg, dev, perm):
 
 
 # ------------------------------------------------------------------------------------------------ exchange
-def exchange_bandwidth(model, world, dev):
-    """The step's two gradient collectives alone (N > 1): achieved bus bandwidth per GPU.
-    all-gather of the (P,3) colour gradients: every rank receives (world-1)*12P bytes;
-    all-reduce of the 11-float geometry span: ring model 2*(world-1)/world * 44P bytes per rank."""
+def exchange_bandwidth(model, world, dev, rows=0):
+    """The step's gradient collectives alone (N > 1): achieved bus bandwidth per GPU.
+    Low-rank form — all-gather of the (P,3) colour gradients: every rank receives (world-1)*12P bytes; all-reduce of the
+    11-float geometry span: ring model 2*(world-1)/world * 44P bytes per rank.  Sparse form (rows > 0: the largest per-view
+    row count of the last step) — all-gather of `rows` 64-byte rows per rank: (world-1)*64*rows bytes received."""
     P = model.num_points
     d = torch.randn(P, 3, device=dev)
     d_all = torch.empty(world, P, 3, device=dev)
     geo = torch.randn(11 * P, device=dev)
     out = {}
-    for name, fn, nbytes in (("all_gather_dcolor", lambda: dist.all_gather_into_tensor(d_all.view(-1), d.view(-1)),
-                              (world - 1) * 12.0 * P),
-                             ("all_reduce_geometry", lambda: dist.all_reduce(geo), 2.0 * (world - 1) / world * 44.0 * P)):
+    cases = [("all_gather_dcolor", lambda: dist.all_gather_into_tensor(d_all.view(-1), d.view(-1)), (world - 1) * 12.0 * P),
+             ("all_reduce_geometry", lambda: dist.all_reduce(geo), 2.0 * (world - 1) / world * 44.0 * P)]
+    if rows > 0:
+        r_own = torch.randn(rows, 16, device=dev)
+        r_all = torch.empty(world, rows, 16, device=dev)
+        cases.append(("all_gather_rows", lambda: dist.all_gather_into_tensor(r_all.view(-1), r_own.view(-1)), (world - 1) * 64.0 * rows))
+    for name, fn, nbytes in cases:
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -591,7 +596,7 @@ def main():
     extras = {}
     exchange = None
     if multi:
-        exchange = exchange_bandwidth(model, world, dev)
+        exchange = exchange_bandwidth(model, world, dev, rows=max(getattr(trainer, "last_row_counts", None) or [0]))
         exchange["mode"] = trainer.exchange_mode if trainer.fused else "dense"
         exchange["selfcheck"] = selfcheck
         if autotune is not None:
