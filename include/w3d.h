@@ -65,6 +65,10 @@ enum {
 
 /* GaussianRasterizationSettings of the reference (gaussian_renderer/__init__.py:40-53), flattened. */
 typedef struct w3d_view {
+    uint32_t struct_size;    /* = sizeof(w3d_view) of the header the CALLER was built against.  Every entry point that takes a
+                              * view refuses one whose size differs from the library's own (W3D_ERR_INVALID, "w3d_view size"):
+                              * fields were appended to this struct in the past (tile_walk_hint, records_kept_clean), and a
+                              * client compiled against a shorter struct would make the library read past it. */
     int32_t image_height, image_width;
     float tanfovx, tanfovy;
     float scale_modifier;
@@ -102,6 +106,9 @@ typedef struct w3d_view {
                                  * has run. */
 } w3d_view;
 
+/* Version of this ABI: major * 100 + minor.  The major number changes whenever a struct of this header changes its layout or
+ * an entry point its signature; a binding must refuse a library whose major number differs from the header it mirrors. */
+#define W3D_ABI_VERSION 200
 int w3d_version(void);
 const char *w3d_last_error(void);
 

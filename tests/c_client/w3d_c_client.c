@@ -76,6 +76,8 @@ int main(int argc, char **argv) {
 
     w3d_view v;
     memset(&v, 0, sizeof v);
+    v.struct_size = (uint32_t)sizeof v;
+    if (w3d_version() / 100 != W3D_ABI_VERSION / 100) { fprintf(stderr, "libw3d_hip ABI %d, header %d\n", w3d_version(), W3D_ABI_VERSION); return 3; }
     v.image_height = H; v.image_width = W;
     v.tanfovx = fl[0]; v.tanfovy = fl[1]; v.scale_modifier = fl[2];
     v.sh_degree = hdr[3]; v.sh_coeffs = M;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     from w3d_amd import _lib
     for name in declared_functions():
         assert hasattr(_lib.lib, name), f"{name} declared in include/w3d.h but not exported"
-    assert _lib.lib.w3d_version() >= 100
+    assert _lib.lib.w3d_version() // 100 == _lib.ABI_MAJOR
     assert len(_lib.loaded_hip_runtimes()) == 1          # shares torch's HIP runtime
 
 
@@ -44,6 +44,14 @@ def test_host_side_validation_without_a_device():
     assert b"view is NULL" in lib.w3d_last_error()
     bs = ctypes.c_uint64()
     assert lib.w3d_backward_sizes(1000, ctypes.byref(bs)) == 0 and bs.value == 1000 * 64
+    # a view built against another header (shorter struct: the two fields round 3 appended are missing) is refused before
+    # any of its fields is trusted
+    v = _lib.W3DView()
+    assert v.struct_size == ctypes.sizeof(_lib.W3DView)
+    v.struct_size -= 16
+    v.image_height = v.image_width = 16
+    assert lib.w3d_forward_stage1(ctypes.byref(v), 0, None, None, None, None, None, None, None, None, None, None, None, None) == 1
+    assert b"w3d_view size" in lib.w3d_last_error()
 
 
 def test_product_path_has_no_cpu_fallback():
@@ -100,8 +108,9 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
 #include <stddef.h>
 #include "w3d.h"
 int main(void) {
-    printf("view %zu %zu %zu %zu %zu %zu\\n", sizeof(w3d_view), offsetof(w3d_view, bg), offsetof(w3d_view, tile_cull),
-           offsetof(w3d_view, deterministic), offsetof(w3d_view, det_list_capacity), offsetof(w3d_view, tile_walk_hint));
+    printf("view %zu %zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(w3d_view), offsetof(w3d_view, bg), offsetof(w3d_view, tile_cull),
+           offsetof(w3d_view, deterministic), offsetof(w3d_view, det_list_capacity), offsetof(w3d_view, tile_walk_hint),
+           offsetof(w3d_view, records_kept_clean), offsetof(w3d_view, struct_size), W3D_ABI_VERSION);
     printf("raw %zu %zu\\n", sizeof(w3d_raw_params), sizeof(w3d_raw_grads));
     printf("stats %zu\\n", sizeof(w3d_densify_stats));
     printf("adam %zu %zu %zu %zu\\n", sizeof(w3d_adam_fused), offsetof(w3d_adam_fused, lr), offsetof(w3d_adam_fused, beta1),
@@ -114,7 +123,8 @@ int main(void) {
     out = dict((ln.split()[0], [int(x) for x in ln.split()[1:]]) for ln in subprocess.check_output([str(exe)], text=True).splitlines())
     V = _lib.W3DView
     assert out["view"] == [ctypes.sizeof(V), V.bg.offset, V.tile_cull.offset, V.deterministic.offset, V.det_list_capacity.offset,
-                           V.tile_walk_hint.offset]
+                           V.tile_walk_hint.offset, V.records_kept_clean.offset, V.struct_size.offset, _lib.lib.w3d_version()]
+    assert V().struct_size == ctypes.sizeof(V) and out["view"][-1] // 100 == _lib.ABI_MAJOR
     assert out["raw"] == [ctypes.sizeof(fused_step.W3DRawParams), ctypes.sizeof(fused_step.W3DRawGrads)]
     assert out["stats"] == [ctypes.sizeof(fused_step.W3DDensifyStats)]
     A = fused_step.W3DAdamFused

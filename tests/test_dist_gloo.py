@@ -139,11 +139,27 @@ def _zero_culled_geometry(m, culled):
         m.grad_view(n)[culled] = 0.0
 
 
+def _densified_model():
+    """_model() after one densify_and_prune: every parameter tensor has been re-bound, so every .grad is None — the state the
+    exchange paths run in for the rest of a training run (round-3 advisor finding: the CPU twin of sh_adam_lowrank consulted
+    .grad and silently skipped f_dc / f_rest from then on)."""
+    m, opt = _model()
+    g = torch.Generator().manual_seed(31)
+    m.xyz_gradient_accum += (torch.rand(m.num_points, 1, generator=g) * 6e-4)
+    m.denom += 1.0
+    torch.manual_seed(1234)
+    m.densify_and_prune(2e-4, 0.005, 10.0, None)
+    assert m.num_points > 64 and all(p.grad is None for p in m._p.values())
+    return m, opt
+
+
 def _lowrank_worker(rank, world, port, out, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    m, opt = _model()
+    densified = mode.endswith("@densified")
+    mode = mode.split("@")[0]
+    m, opt = _densified_model() if densified else _model()
     m.active_sh_degree = 2
     from w3d_amd.train import Trainer
     P = m.num_points
@@ -207,24 +223,27 @@ def test_lowrank_exchange_two_ranks():
     """exchange_lowrank + optimizer_step_lowrank on 2 gloo ranks == one process stepping Adam on the mean over the two views
     of the DENSE gradient (SH gradient = basis(direction to that view's camera) x dcolor), and the replicas stay bit-identical
     although no parameters are ever exchanged."""
+    _check_against_single_process("lowrank", _model)
+
+
+def test_lowrank_and_rows_exchange_after_a_densification():
+    """The same check on a model that has been densified first (every .grad None, as in every iteration of a real run after the
+    first densify_and_prune), for the low-rank and the sparse form: ALL six blocks must have stepped."""
+    _check_against_single_process("lowrank@densified", _densified_model)
+    _check_against_single_process("rows@densified", _densified_model)
+
+
+def _check_against_single_process(mode, make_model):
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_lowrank_worker, args=(r, world, port, q, "lowrank")) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted((_tensors(q.get(timeout=180)) for _ in range(world)), key=lambda r: r[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = [_tensors(r) for r in _run_lowrank(mode, world)]
     for k in (1, 2, 3):
         assert torch.equal(res[0][k], res[1][k])
     assert res[0][4] == 3
     # single-process reference
     from w3d_amd.sh import sh_basis
     from w3d_amd.train import Trainer
-    m, opt = _model()
+    m, opt = make_model()
+    start = m.flat.detach().clone()
     m.active_sh_degree = 2
     tr = Trainer(m, _cams(), opt, torch.zeros(3), densify=True)
     tr.world = world                                        # only to enumerate the two views of each iteration
@@ -247,7 +266,11 @@ def test_lowrank_exchange_two_ranks():
         m.flat_grad.copy_(total)
         m.flat_grad[sl["f_dc"][0]:sl["f_dc"][1]] = sh[:, :1].reshape(-1)
         m.flat_grad[sl["f_rest"][0]:sl["f_rest"][1]] = sh[:, 1:].reshape(-1)
-        m.optimizer.step(skip=({"opacity"} if step == 2 else ()))
+        m.optimizer.step(skip=({"opacity"} if step == 2 else ()), respect_none_grads=False)
+    for name, (a, b) in sl.items():                          # every block moved (none was silently skipped) ...
+        assert float((m.flat[a:b] - start[a:b]).abs().max()) > 0, name
+        assert float((res[0][1][a:b] - start[a:b]).abs().max()) > 0, name
+    assert m.optimizer.steps == {"xyz": 3, "f_dc": 3, "f_rest": 3, "opacity": 2, "scaling": 3, "rotation": 3}
     assert torch.allclose(m.flat, res[0][1], rtol=0, atol=2e-7)
     assert torch.allclose(m.optimizer.exp_avg, res[0][2], rtol=1e-5, atol=1e-9)
     assert torch.allclose(m.optimizer.exp_avg_sq, res[0][3], rtol=1e-5, atol=1e-12)

@@ -717,3 +717,12 @@ def test_kept_backward_scratch_is_handed_back_clean_and_changes_no_gradient(monk
         pkg = FS.render_raw(cams[1], m, bg, sync=True)
         FS.backward_raw_adam(m, pkg["handle"], dimgs[1])
         assert clean(m)
+        # another backward of the same model between the two halves wipes the first half's records: the second half must
+        # refuse instead of returning zero geometry gradients
+        pkg_a = FS.render_raw(cams[2], m, bg, sync=True)
+        FS.backward_blend_dcolor(m, pkg_a["handle"], dimgs[2])
+        pkg_b = FS.render_raw(cams[3], m, bg, sync=True)
+        FS.backward_raw(m, pkg_b["handle"], dimgs[3])
+        with pytest.raises(RuntimeError, match="between backward_blend_dcolor"):
+            FS.backward_raw_lowrank(m, pkg_a["handle"], None)
+        assert clean(m)

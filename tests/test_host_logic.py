@@ -514,3 +514,39 @@ def test_inplace_collective_aliasing_is_checked():
     assert nccl_inplace_shard(full, 512, 1000, 1, 2) is None          # uneven shard
     assert nccl_inplace_shard(full[::2], 0, 256, 0, 2) is None        # strided buffer
     assert nccl_inplace_shard(full[:1000], 500, 1000, 1, 2) is not None
+
+
+def test_structure_change_schedule_follows_the_reference_loop():
+    """Trainer's densify / opacity-reset schedule against the conditions of reference train_vanilla_3dgs.py:100-110 evaluated
+    literally, with and without the dataset's white_background flag (:109 resets the opacities once more at
+    iteration == densify_from_iter), and opt.random_background (:71) draws a fresh colour per iteration."""
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.synth import make_scene
+    from w3d_amd.train import Trainer
+
+    class Opt(OptimizationParams):
+        densify_from_iter = 50
+        densify_until_iter = 400
+        densification_interval = 20
+        opacity_reset_interval = 150
+    sc = make_scene(32, seed=0, scale_mean=0.05)
+    m = GaussianModel(3, device="cpu")
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    opt = Opt()
+    m.training_setup(opt)
+    for white in (False, True):
+        tr = Trainer(m, [0, 1, 2], opt, torch.zeros(3), densify=True, fused=False, white_background=white)
+        for it in range(1, 450):
+            densify = reset = False
+            if it < opt.densify_until_iter:                                    # reference lines 100-110
+                if it > opt.densify_from_iter and it % opt.densification_interval == 0:
+                    densify = True
+                if it % opt.opacity_reset_interval == 0 or (white and it == opt.densify_from_iter):
+                    reset = True
+            assert tr._structure_change_due(it) == (densify or reset), (white, it)
+            if it < opt.densify_until_iter:
+                assert tr._opacity_reset_due(it) == reset, (white, it)
+    assert tr.background_for(1) is tr.bg
+    opt.random_background = True
+    a, b = tr.background_for(1), tr.background_for(2)
+    assert a.shape == (3,) and not torch.equal(a, b) and float(a.min()) >= 0.0 and float(a.max()) < 1.0

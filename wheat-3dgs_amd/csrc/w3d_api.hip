@@ -55,6 +55,11 @@ int w3d_debug_pixel_state_impl(const W3DLayout &L, const char *state, float *fin
 
 static int check_view(const w3d_view *v) {
     if (!v) { w3d_set_error("view is NULL"); return W3D_ERR_INVALID; }
+    if (v->struct_size != sizeof(w3d_view)) {
+        w3d_set_error("w3d_view size %u, this library expects %zu: the caller was built against another include/w3d.h "
+                      "(ABI %d)", v->struct_size, sizeof(w3d_view), W3D_ABI_VERSION);
+        return W3D_ERR_INVALID;
+    }
     if (v->image_height <= 0 || v->image_width <= 0) { w3d_set_error("image size must be positive"); return W3D_ERR_INVALID; }
     if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos) { w3d_set_error("view holds a NULL device pointer"); return W3D_ERR_INVALID; }
     if (v->sh_degree < 0 || v->sh_degree > 3) { w3d_set_error("sh_degree %d unsupported (0..3)", v->sh_degree); return W3D_ERR_UNSUPPORTED; }
@@ -94,7 +99,7 @@ static int finish_stage1(const W3DLayout &L, const w3d_view &view, char *st, cha
 
 extern "C" {
 
-int w3d_version(void) { return 100; }
+int w3d_version(void) { return W3D_ABI_VERSION; }
 
 int w3d_profile_enable(const char *kernel_substr) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);

@@ -19,7 +19,8 @@ c_u32p = ctypes.c_void_p
 
 class W3DView(ctypes.Structure):
     """Mirror of ``w3d_view`` (include/w3d.h)."""
-    _fields_ = [("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32),
+    _fields_ = [("struct_size", ctypes.c_uint32),
+                ("image_height", ctypes.c_int32), ("image_width", ctypes.c_int32),
                 ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float),
                 ("scale_modifier", ctypes.c_float),
                 ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32),
@@ -29,6 +30,13 @@ class W3DView(ctypes.Structure):
                 ("tile_cull", ctypes.c_int32), ("deterministic", ctypes.c_int32),
                 ("det_list_capacity", ctypes.c_uint64), ("tile_walk_hint", ctypes.c_void_p),
                 ("records_kept_clean", ctypes.c_int32)]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = ctypes.sizeof(W3DView)      # checked by every entry point (include/w3d.h)
+
+
+ABI_MAJOR = 2       # W3D_ABI_VERSION // 100 of the include/w3d.h these ctypes mirrors were written against
 
 
 def _load():
@@ -40,6 +48,10 @@ def _load():
     lib = ctypes.CDLL(path)
     vp, i32, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64
     lib.w3d_version.restype = ctypes.c_int
+    ver = int(lib.w3d_version())
+    if ver // 100 != ABI_MAJOR:
+        raise ImportError(f"{path} reports ABI version {ver}, this binding mirrors ABI {ABI_MAJOR}xx of include/w3d.h: a stale "
+                          "library (or a stale binding) — rebuild with wheat-3dgs_amd/csrc/build.sh")
     lib.w3d_last_error.restype = ctypes.c_char_p
     lib.w3d_forward_sizes.argtypes = [i32, i32, i32, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     lib.w3d_forward_stage1.argtypes = [ctypes.POINTER(W3DView), i32] + [vp] * 7 + [vp, vp, vp, vp, vp]

@@ -336,6 +336,8 @@ def backward_blend_dcolor(model, handle, dL_dimage):
         check(lib.w3d_backward_blend_dcolor(ctypes.byref(view.c), P, ptr(handle["state"]), ptr(handle["point_list"]),
                                             ptr(dL_dimage.contiguous()), None, None, ptr(dcol), ptr(scratch), stream_ptr(dev)))
     handle["bwd_scratch"] = scratch
+    kept = getattr(model, "_w3d_bwd_scratch", None) if view.c.records_kept_clean else None
+    handle["bwd_scratch_token"] = None if kept is None else (kept, kept.generation)
     return dcol
 
 
@@ -360,6 +362,11 @@ def backward_raw_lowrank(model, handle, dL_dimage, want_norm=True):
         if dL_dimage is None:
             # second half: backward_blend_dcolor already ran the blend backward into the handle's scratch
             scratch = handle.pop("bwd_scratch")
+            token = handle.pop("bwd_scratch_token", None)
+            if token is not None and token[0].generation != token[1]:
+                raise RuntimeError("backward_raw_lowrank: another backward of this model ran between backward_blend_dcolor and "
+                                   "its second half and reused the kept gradient records (rasterizer.KeptScratch): the blend "
+                                   "records of this view are gone — run the two halves back to back")
             check(lib.w3d_backward_raw_lowrank(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(handle["state"]),
                                                ptr(handle["point_list"]), None, None, None, ctypes.byref(g), None,
                                                ctypes.byref(st), ptr(scratch), stream_ptr(dev)))
@@ -400,7 +407,8 @@ def sh_adam_lowrank(model, dcolor_all, campos_all, skip=(), rows=None):
             grad[:, :basis.shape[1]] += basis[:, :, None] * dcolor_all[v][:, None, :]
         model.grad_view("f_dc").copy_(grad[:, :1])
         model.grad_view("f_rest").copy_(grad[:, 1:])
-        opt.step(only=SH_BLOCKS, skip=skip, advance=False)
+        # (the bucket was written directly just above: .grad is not consulted — after a densification every p.grad is None)
+        opt.step(only=SH_BLOCKS, skip=skip, advance=False, respect_none_grads=False)
         return
     sl = model.block_slices()
     assert opt.steps["f_dc"] == opt.steps["f_rest"] or "f_dc" in skip or "f_rest" in skip

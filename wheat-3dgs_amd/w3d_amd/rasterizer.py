@@ -266,8 +266,10 @@ class KeptScratch:
 
     def __init__(self):
         self.buf, self.clean = None, False
+        self.generation = 0           # counts begin() calls: the token of the backward that currently owns the records
 
     def begin(self, nbytes, dev):
+        self.generation += 1
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != dev:
             self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         elif not self.clean:

@@ -56,8 +56,10 @@ class Trainer:
 
     def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
                  densify=True, loss_fn=photometric_loss, fused=None, force_exchange=False, fused_adam=True,
-                 exchange="rows", early_gather=False, lowrank_chunks=None, rows_max_fraction=None):
-        """fused_adam: single GPU — the optimizer update is applied by the backward kernel itself
+                 exchange="rows", early_gather=False, lowrank_chunks=None, rows_max_fraction=None, white_background=False):
+        """white_background: the dataset flag of reference train_vanilla_3dgs.py:109 — with it the opacities are ALSO reset once at
+        iteration == opt.densify_from_iter (besides every opacity_reset_interval).
+        fused_adam: single GPU — the optimizer update is applied by the backward kernel itself
         (fused_step.backward_raw_adam), except in the iterations that densify / reset opacity (there the reference
         skips the replaced parameters' update).
         exchange: view-parallel exchange of the fused step.  "lowrank" ships dL/dRGB (3 floats per Gaussian and view)
@@ -75,6 +77,7 @@ class Trainer:
         self.pipe = pipe or PipelineParams()
         self.extent = cameras_extent
         self.densify = densify
+        self.white_background = bool(white_background)
         self.loss_fn = loss_fn
         # fused=None: use the fused raw-parameter step whenever the model lives on the GPU, the
         # default pipeline flags are in force and the loss is the standard photometric one
@@ -419,7 +422,18 @@ class Trainer:
         if not (iteration < opt.densify_until_iter and self.densify):
             return False
         return (iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0) or \
-            iteration % opt.opacity_reset_interval == 0
+            self._opacity_reset_due(iteration)
+
+    def _opacity_reset_due(self, iteration):
+        """reference train_vanilla_3dgs.py:109"""
+        opt = self.opt
+        return iteration % opt.opacity_reset_interval == 0 or (self.white_background and iteration == opt.densify_from_iter)
+
+    def background_for(self, iteration):
+        """reference train_vanilla_3dgs.py:71: a fresh uniform colour per iteration when opt.random_background is set"""
+        if getattr(self.opt, "random_background", False):
+            return torch.rand(3, device=self.bg.device)
+        return self.bg
 
     def _post_backward(self, iteration, nsum, vcount, rmax, stats_done):
         """Densification bookkeeping + optimizer step shared by both step flavours."""
@@ -439,7 +453,7 @@ class Trainer:
                     torch.manual_seed(1234 + iteration)     # identical split samples on every rank
                     m.densify_and_prune(opt.densify_grad_threshold, 0.005, self.extent, size_threshold)
                     skip = {"xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"}
-                if iteration % opt.opacity_reset_interval == 0:
+                if self._opacity_reset_due(iteration):
                     self.gather_moments()
                     m.reset_opacity()
                     skip.add("opacity")
@@ -459,6 +473,7 @@ class Trainer:
         if iteration % 1000 == 0:
             m.oneupSHdegree()
         cam = self.camera_for(iteration)
+        bg = self.background_for(iteration)
         with torch.no_grad():
             tracking = iteration < opt.densify_until_iter
             single = self.world == 1 and not self.force_exchange
@@ -472,7 +487,7 @@ class Trainer:
                 attempts += 1
                 if attempts > 4:      # one repeat sizes the list buffer exactly; more means the counters are corrupt
                     raise RuntimeError("fused step: the forward keeps reporting an overflowing list buffer")
-                pkg = render_raw(cam, m, self.bg, sync=False)
+                pkg = render_raw(cam, m, bg, sync=False)
                 loss, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
                 if not single and self.world > 1:
                     dimg.mul_(1.0 / self.world)      # the bucket then holds grad/world: reduce-scatter(SUM) = mean
@@ -546,7 +561,7 @@ class Trainer:
         if iteration % 1000 == 0:
             m.oneupSHdegree()
         cam = self.camera_for(iteration)
-        pkg = render(cam, m, self.pipe, self.bg)
+        pkg = render(cam, m, self.pipe, self.background_for(iteration))
         image = pkg["render"]
         loss = self.loss_fn(image, cam.original_image, opt.lambda_dssim)
         (loss / self.world if self.world > 1 else loss).backward()
