@@ -46,7 +46,7 @@ VALU_SPEC_TFLOPS = 157.3
 FLOP_PER_VALU_INSTR = 128.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -55,9 +55,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1600)
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--views", type=int, default=36)
-    ap.add_argument("--profile", default="preprocess_bwd",
-                    help="stage timed with HIP events INSIDE the timed region for the `roofline` object (default: the step's "
-                         "dominant kernel, per-Gaussian backward + Adam)")
+    ap.add_argument("--profile", default="auto",
+                    help="stage timed with HIP events INSIDE the timed region for the `roofline` object; auto (default): the "
+                         "longest stage of the scene being measured, found by a short untimed probe with every stage timed")
     ap.add_argument("--all-stages", action="store_true", help="also print per-stage event times to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-loss", action="store_true", help="use the PyTorch conv2d SSIM instead of the fused kernel")
@@ -71,14 +71,29 @@ def parse():
                     help="extra training steps before the second (trained-scene) measurement; 0: skip")
     ap.add_argument("--dropin-only", action="store_true",
                     help="run only the reference-loop measurement (for rocprofv3 --kernel-trace of that loop) and print its JSON")
-    ap.add_argument("--no-extras", action="store_true", help="skip render / FlashSplat / drop-in / trained-scene measurements")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip render / FlashSplat / drop-in / modules-only / trained-scene / densified-scene measurements")
+    ap.add_argument("--densify-iterations", type=int, default=6000,
+                    help="iterations of the compressed C3 schedule that grows the densified scene (densified_scene leg); 0: skip")
+    ap.add_argument("--densify-grad-threshold", type=float, default=1.5e-5,
+                    help="densify_grad_threshold of that schedule (reference default 2e-4, arguments/__init__.py:88, tuned for "
+                         "photographs: the smooth synthetic views only grow to ~0.26 M Gaussians with it; stated in the line)")
+    ap.add_argument("--densified-only", action="store_true",
+                    help="of the extra measurements keep only the densified-scene one")
+    ap.add_argument("--modules-only-steps", type=int, default=-1,
+                    help="steps of the INTEGRATION.md section 1 measurement (rasterizer modules only; -1: = min(--steps, 60), 0: skip)")
     ap.add_argument("--trained-only", action="store_true",
                     help="of the extra measurements keep only the trained-scene one (kernel A/B runs: profiles/ab_variants.sh)")
     ap.add_argument("--force-dist", action="store_true", help="1-rank RCCL group: exercises the exchange path on one GPU")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reporting test on CPU over gloo with a stub step (no kernels, no GPU); "
                          "the line says so in `data`")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def parse_defaults():
+    """the default arguments (profiles/scene_step.py builds bench.py's scenes with them)"""
+    return parse([])
 
 
 # ------------------------------------------------------------------------------------------------ launch
@@ -209,27 +224,48 @@ def _newest(pattern):
     return files[-1] if files else None
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
-    (profiles/rNN/pmc_hbm_traffic.csv: FETCH_SIZE x2 + WRITE_SIZE, collected in separate --pmc passes);
-    None when no summary exists.  The counters cannot be read live from inside the process."""
+# kernels of every stage of the step (names as rocprofv3 prints them, template arguments included where they matter)
+STAGE_KERNELS = {
+    "preprocess_fwd": ("preprocess_fwd_kernel",),
+    "depth_sort": ("radix_hist_kernel", "radix_rowscan_kernel", "radix_scatter_kernel", "onesweep_", "depth_"),
+    "tile_count_scan": ("chunk_walk_kernel<0", "seg_sum_kernel", "tile_scan_kernel", "chunk_off_kernel", "tile_count_", "band_"),
+    "fill_lists": ("chunk_walk_kernel<1", "fill_"),
+    "render_fwd": ("render_fwd_kernel", "tile_order_kernel"),
+    "loss": ("ssim_pass_a", "ssim_pass_b", "loss_finalize"),
+    "render_bwd": ("render_bwd_kernel", "zero_visible_records_kernel", "det_gather_kernel"),
+    "preprocess_bwd": ("preprocess_bwd_kernel",),
+}
+
+
+def _scene_csv(prefix, scene):
+    """newest profiles/rNN/<prefix>_<scene>.csv (per-step sums inside the marker window of profiles/scene_step.py)"""
+    return _newest(f"{prefix}_{scene}.csv")
+
+
+def pmc_traffic(stage, scene="untrained"):
+    """HBM-side bytes ONE STEP of `scene` moves in `stage`: the SUM over every kernel of the stage (STAGE_KERNELS) and over
+    all its launches in a step, from the newest committed profiles/rNN/pmc_hbm_traffic_<scene>.csv (FETCH_SIZE x2 +
+    WRITE_SIZE collected in separate rocprofv3 --pmc passes over profiles/scene_step.py, whose K steps sit between two
+    marker kernels; profiles/summarize_pmc.py --window).  (bytes, [kernel rows]) or (None, None) when no summary exists —
+    the counters cannot be read live from inside the process."""
     import csv
-    f = _newest("pmc_hbm_traffic.csv")
+    f = _scene_csv("pmc_hbm_traffic", scene)
     if not f:
-        return None
-    best = None
+        return None, None
+    tot, used = 0.0, []
     for r in csv.DictReader(open(f)):
-        if kernel in r["kernel"] and "<true>" not in r["kernel"].replace("<true, true>", ""):
+        if any(r["kernel"].startswith(k) for k in STAGE_KERNELS.get(stage, (stage,))):
             mib = float(r["hbm_read_MiB_corrected_x2"]) + float(r["hbm_write_MiB"])
-            best = max(best or 0.0, mib)
-    return None if best is None else int(best * 1024 * 1024)
+            tot += mib
+            used.append({"kernel": r["kernel"], "launches_per_step": float(r["launches_per_step"]), "MiB_per_step": round(mib, 2)})
+    return (int(tot * 1024 * 1024), used) if used else (None, None)
 
 
-def valu_instructions(kernel):
-    """wave64 VALU instructions one launch of `kernel` issues (SQ_INSTS_VALU of the newest committed
-    profiles/rNN/sq_counters.csv, mean over the benchmark's full-size dispatches); (count, file) or (None, None)."""
+def valu_instructions(kernel, scene="untrained"):
+    """wave64 VALU instructions `kernel` issues per step of `scene` (SQ_INSTS_VALU summed over its launches inside the marker
+    window, newest committed profiles/rNN/sq_counters_<scene>.csv); (count, file) or (None, None)."""
     import csv
-    f = _newest("sq_counters.csv")
+    f = _scene_csv("sq_counters", scene)
     if not f:
         return None, None
     for r in csv.DictReader(open(f)):
@@ -282,8 +318,11 @@ def _median(xs):
     return xs[len(xs) // 2]
 
 
-def cpu_baseline(args):
-    """the oracle (kind "port": this repo's C restatement of the rasterizer, OpenMP over tiles, all host
+def cpu_baseline(args, own_view0=None):
+    """own_view0: (colour, depth, alpha, gt) numpy images of camera 0 of the benchmark scene rendered by the HIP path BEFORE
+    any training step — compared with the oracle's render of the same view (the `psnr` entry of the result: BASELINE.json's
+    "PSNR vs ref", reference utils/image_utils.py:17-19).
+    BASELINE.md section 4: the oracle (kind "port": this repo's C restatement of the rasterizer, OpenMP over tiles, all host
     cores) timed on this box beside the GPU number, with time.perf_counter:
       * `value`: ONE view of the benchmark's own C3 workload — rasterizer forward + backward on a fixed dL/dcolor (the
         rasterizer's share of the bracket of train_vanilla_3dgs.py:56,82; the loss is NOT in it: `bracket` says so) — a
@@ -298,6 +337,8 @@ def cpu_baseline(args):
     cores = os.cpu_count() or 1
     _progress("cpu_baseline: C3 sample")
 
+    first_view = {}
+
     def c_oracle_protocol(P, width, height, warm, timed, seed):
         sc = make_scene(P, seed=seed, **({} if P >= 100_000 else {"scale_mean": 0.012}))
         cams = make_cameras(args.views, width, height)
@@ -308,8 +349,10 @@ def cpu_baseline(args):
             d = np_inputs(view_inputs(sc, cam))
             o = make_oracle(cam, (0.0, 0.0, 0.0), nthreads=cores)
             t0 = time.perf_counter()
-            o.forward(**d)
+            ref = o.forward(**d)
             t1 = time.perf_counter()
+            if i == 0 and (P, width, height) not in first_view:
+                first_view[(P, width, height)] = {k: ref[k].copy() for k in ("color", "depth", "alpha")}
             o.backward(gc, None, None)
             t2 = time.perf_counter()
             o.free()
@@ -330,6 +373,20 @@ def cpu_baseline(args):
            "c1": {"workload": "C1: 10000 Gaussians, 400x300", "protocol": "3 warm-up + 10 timed, median, cameras cycled, seed 4",
                   "c_oracle_iters_per_s": round(1.0 / s1, 3), "c_oracle_render_mpix_per_s": round(0.12 / f1, 3),
                   "c_oracle_bracket": "rasterizer forward + backward only"}}
+    if own_view0 is not None:
+        # "PSNR vs ref": the HIP render of camera 0 of the benchmark scene against the oracle's render of the same inputs
+        # (psnr of reference utils/image_utils.py:17-19: 20 log10(1 / sqrt(mse)), per image here)
+        from util import psnr as _psnr
+        ref0 = first_view[(args.points, args.width, args.height)]
+        own_c, own_d, own_a, gt0 = own_view0
+        pg_own, pg_ref = _psnr(own_c, gt0), _psnr(ref0["color"], gt0)
+        dmax, amax = float(ref0["depth"].max()) or 1.0, 1.0
+        out["psnr"] = {"view": "camera 0 of the benchmark scene, initial parameters", "own_vs_gt_db": round(pg_own, 6),
+                       "oracle_vs_gt_db": round(pg_ref, 6), "delta_db": float(f"{pg_own - pg_ref:.3e}"),
+                       "own_vs_oracle_db": {"color": round(_psnr(own_c, ref0["color"]), 2),
+                                            "depth": round(_psnr(own_d / dmax, ref0["depth"] / dmax), 2),
+                                            "alpha": round(_psnr(own_a / amax, ref0["alpha"] / amax), 2)},
+                       "bar_db": 1e-3, "formula": "utils/image_utils.py:17-19"}
     # the PyTorch restatement at C1 (BASELINE.md section 4 names it): float32 torch_render, loss, backward by autograd
     torch_threads = torch.get_num_threads()
     try:
@@ -365,13 +422,15 @@ def cpu_baseline(args):
 
 
 # ------------------------------------------------------------------------------------------------ drop-in loop
-def reference_loop(model, opt, cams, bg, pipe, first_iter, n_steps, perm, iter_events=None):
+def reference_loop(model, opt, cams, bg, pipe, first_iter, n_steps, perm, iter_events=None, loss_fns=None):
     """The loop body of reference train_vanilla_3dgs.py:55-115, statement by statement (logging, saving and the
     densification branch — not due in these iterations — left out; cameras cycled instead of randint), on this package's
     drop-ins for the names that script imports: render (gaussian_renderer), GaussianModel (scene), l1_loss / ssim
     (utils.loss_utils).  Returns the last loss value."""
     from w3d_amd.gaussian_renderer import render
     from w3d_amd.loss import l1_loss, ssim
+    if loss_fns is not None:                        # (time_modules_only: the reference's torch formulas)
+        l1_loss, ssim = loss_fns
     gaussians, background = model, bg
     ema_loss_for_log = 0.0
     for iteration in range(first_iter, first_iter + n_steps):
@@ -435,6 +494,376 @@ def time_dropin(args, sc, cams, bg, dev, perm):
             "iter_time": "HIP events around render + loss + backward, the bracket of train_vanilla_3dgs.py:56,82 (no optimizer step)"}
 
 
+
+# ------------------------------------------------------------------------------------------------ roofline helpers
+def kernel_bytes(P, V, R, Rw, HW, fused_adam):
+    """Algorithmic HBM bytes per launch of every stage (what the stage must read and write once)."""
+    return {
+        "preprocess_fwd": 236.0 * P + 64.0 * V,              # parameters read; packed per-visible records written
+        # first pass reads P (key, id) pairs, the others V; the last writes 24-B records from a 16-B rect/mask gather
+        "depth_sort": 8.0 * P + 8.0 * V + 2 * 16.0 * V + (8.0 + 16.0 + 24.0) * V,
+        "tile_count_scan": 24.0 * V,                           # the records, once
+        "fill_lists": 24.0 * V + 4.0 * R,                      # the records once + the lists
+        "render_fwd": 48.0 * Rw + 36.0 * HW,                   # 4-B id + 44-B gather per walked instance; image + aux
+        "loss": 2 * 12.0 * HW + 12.0 * HW,                     # image + gt read, gradient written
+        "render_bwd": 84.0 * Rw + 20.0 * HW,                   # gather + one 40-B record update; dL/dpixel + aux
+        # fused Adam: parameters + both moments read and written, 2-D records read / otherwise gradients written
+        "preprocess_bwd": (6 * 236.0 * P + 104.0 * V) if fused_adam else (236.0 * P + 64.0 * V + 252.0 * P),
+    }
+
+
+def kernel_table(stage_ms, kb, scene):
+    """Per stage: event-timed ms, algorithmic bytes, achieved GB/s and fraction of the HBM peak, and the PMC-counter traffic of
+    the stage on THIS scene — summed over all its kernels and launches (pmc_traffic) — with its ratio to the algorithmic bytes
+    (wasted re-reads show up there)."""
+    rows = []
+    for k, ms in sorted(stage_ms.items(), key=lambda kv: -kv[1]):
+        if k not in kb:
+            continue
+        gbs = kb[k] / (ms * 1e-3) / 1e9
+        tr, used = pmc_traffic(k, scene)
+        rows.append({"stage": k, "ms": ms, "algorithmic_bytes": int(kb[k]), "achieved_GBps": round(gbs, 1),
+                     "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "pmc_traffic_bytes": tr,
+                     "traffic_ratio": None if not tr else round(tr / kb[k], 2),
+                     "pmc_GBps": None if not tr else round(tr / (ms * 1e-3) / 1e9, 1), "pmc_kernels": used})
+    return rows
+
+
+def step_roofline(P, V, R, HW, it_per_s, stage_ms, kb):
+    """SURVEY.md section 8(d) / BASELINE.md section 5 as written: (B_f + B_b + B_adam) * iters/s / peak with the MEASURED
+    V and R, and the same with this design's own byte count (sum of the stages' algorithmic bytes — fusion removed the
+    gradient round trip and the 64-bit key sort, so it is smaller)."""
+    B_f = 236.0 * P + 56.0 * V + 80.0 * R + 28.0 * HW
+    B_b = 484.0 * P + 80.0 * V + 84.0 * R + 20.0 * HW
+    B_adam = 1652.0 * P
+    tot = B_f + B_b + B_adam
+    own = sum(kb[k] for k in kb if k in stage_ms)
+    return {"formula": "B_f + B_b + B_adam, B_f = 236P + 56V + 80R + 28HW, B_b = 484P + 80V + 84R + 20HW, B_adam = 1652P",
+            "P": P, "V": int(V), "R": int(R), "HW": HW, "B_f": int(B_f), "B_b": int(B_b), "B_adam": int(B_adam),
+            "algorithmic_bytes": int(tot), "achieved_GBps": round(tot * it_per_s / 1e9, 1),
+            "frac": round(tot * it_per_s / 1e9 / HBM_PEAK_GBS, 4),
+            "design_bytes": int(own), "design_achieved_GBps": round(own * it_per_s / 1e9, 1),
+            "design_frac": round(own * it_per_s / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+VALU_BOUND_STAGES = {"render_bwd": "render_bwd_kernel", "render_fwd": "render_fwd_kernel"}
+
+
+def valu_object(stage, ms, scene):
+    """`stage` (a blend kernel) against the VALU issue roof: wave64 VALU instructions per launch from
+    the committed SQ counter summary of THIS scene x 128 flop-equivalents / the measured launch time."""
+    n_valu, src = valu_instructions(VALU_BOUND_STAGES[stage], scene)
+    if not n_valu:
+        return None
+    peak, peak_src = valu_peak()
+    ach = n_valu * FLOP_PER_VALU_INSTR / (ms * 1e-3) / 1e12
+    return {"bound": "valu", "kernel": stage, "achieved": round(ach, 2), "peak": VALU_SPEC_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / VALU_SPEC_TFLOPS, 4), "peak_measured": round(peak, 1), "frac_of_measured": round(ach / peak, 4),
+            "avg_launch_ms": round(ms, 4), "valu_wave_instr_per_launch": int(n_valu), "valu_instr_source": src,
+            "peak_source": peak_src, "flop_equiv_per_wave_instr": FLOP_PER_VALU_INSTR}
+
+
+def roofline_object(meas, P, ws, HW, fused_adam, it_per_s, scene):
+    """The `roofline` object of one scene: its DOMINANT stage (the longest one, found by the probe; timed with HIP events on
+    its launch stream inside the timed region) against the roof that bounds it — HBM for the per-Gaussian and binning
+    stages, VALU issue for the blend kernels (their HBM view is kept beside it) — plus the whole-step formula of SURVEY
+    section 8(d) and the per-stage table."""
+    V, R, Rw = ws["V"], ws["R"], ws["R_walk"]
+    kb = kernel_bytes(P, V, R, Rw, HW, fused_adam)
+    dom = meas["dominant"]
+    if dom not in kb or not meas.get("live") or meas["live"][0] <= 0:
+        return None
+    cnt, ms = meas["live"]
+    avg_ms = ms / cnt
+    hbm_ach = kb[dom] / (avg_ms * 1e-3) / 1e9
+    tr, used = pmc_traffic(dom, scene)
+    label = "preprocess_bwd+adam" if (dom == "preprocess_bwd" and fused_adam) else dom
+    roof = {"bound": "hbm", "kernel": label, "achieved": round(hbm_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(hbm_ach / HBM_PEAK_GBS, 4), "traffic": tr, "traffic_ratio": None if not tr else round(tr / kb[dom], 2),
+            "avg_launch_ms": round(avg_ms, 4), "launches": cnt, "algorithmic_bytes_per_launch": int(kb[dom]),
+            "scene": scene, "chosen": meas["chosen_by"], "probe_stage_ms": meas["probe_ms"]}
+    if dom in VALU_BOUND_STAGES:
+        vo = valu_object(dom, avg_ms, scene)
+        if vo is not None:
+            hbm_view = {k: roof[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_ratio",
+                                             "algorithmic_bytes_per_launch")}
+            roof.update(vo)
+            roof["kernel"] = label
+            roof["hbm_view"] = hbm_view
+        else:
+            roof["note"] = ("a blend kernel: VALU-issue-bound (DESIGN.md section 2.1); no SQ counter summary of this scene is "
+                            "committed, so only its HBM view is given")
+    roof["step"] = step_roofline(P, V, R, HW, it_per_s, meas["stage_ms"], kb)
+    roof["kernels"] = kernel_table(meas["stage_ms"], kb, scene)
+    return roof
+
+
+class StepMeter:
+    """Trainer steps between barrier + synchronize brackets (max over ranks), with the library's per-stage event timing."""
+
+    def __init__(self, trainer, world, dev):
+        from w3d_amd import _lib
+        self.trainer, self.world, self.dev, self.lib = trainer, world, dev, _lib.lib
+        self.lib.w3d_profile_enable.argtypes = [ctypes.c_char_p]
+        self.lib.w3d_profile_collect.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
+
+    def sync(self):
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, n_steps, it, prof_sel):
+        """n_steps trainer steps; returns (seconds, it, {stage: (launches, total ms)})."""
+        self.sync()
+        self.lib.w3d_profile_enable(prof_sel)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            it += 1
+            self.trainer.step(it)
+        self.sync()
+        t1 = time.perf_counter()
+        self.lib.w3d_profile_enable(None)
+        buf = ctypes.create_string_buffer(1 << 16)
+        self.lib.w3d_profile_collect(buf, len(buf))
+        stages = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            stages[name] = (int(cnt), float(ms))
+        el = torch.tensor([t1 - t0], device=self.dev, dtype=torch.float64)
+        if self.world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el), it, stages
+
+    def measure(self, n_steps, it, profile="auto", all_stages=False, probe_steps=10, stage_steps=20):
+        """The measurement protocol of one scene: (1) an untimed probe with every stage timed finds the dominant stage;
+        (2) n_steps timed steps with ONLY that stage's events inside the timed region (an event pair around every stage costs
+        ~4 % of the step); (3) stage_steps more steps with every stage timed, for the per-stage table."""
+        _, it, pr = self.timed(probe_steps, it, b"*")
+        probe_ms = {k: round(ms / c, 4) for k, (c, ms) in pr.items() if c > 0}
+        known = kernel_bytes(1, 1, 1, 1, 1, True)
+        if profile == "auto":
+            cand = {k: v for k, v in probe_ms.items() if k in known}
+            dominant = max(cand, key=cand.get) if cand else "preprocess_bwd"
+            chosen_by = f"longest stage of a {probe_steps}-step probe with every stage timed"
+        else:
+            dominant, chosen_by = profile, "--profile"
+        el, it, st = self.timed(n_steps, it, b"*" if all_stages else dominant.encode())
+        if all_stages:
+            stage_ms = {k: round(ms / c, 4) for k, (c, ms) in st.items() if c > 0}
+        else:
+            _, it, st2 = self.timed(stage_steps, it, b"*")
+            stage_ms = {k: round(ms / c, 4) for k, (c, ms) in st2.items() if c > 0}
+        return {"elapsed": el, "it": it, "dominant": dominant, "chosen_by": chosen_by, "probe_ms": probe_ms,
+                "live": st.get(dominant), "stages": st, "stage_ms": stage_ms}
+
+
+def mean_workload(model, cams, bg, dev):
+    ws = [workload_stats(model, cams[i], bg, dev) for i in (0, len(cams) // 2)]
+    return {k: sum(w[k] for w in ws) / len(ws) for k in ("V", "R", "R_walk", "mean_contrib")}
+
+
+# ------------------------------------------------------------------------------------------------ densified scene
+def _psnr_db(a, b):
+    """reference utils/image_utils.py:17-19 on one image"""
+    mse = float(((a - b) ** 2).mean())
+    return 99.0 if mse == 0 else 20.0 * math.log10(1.0 / math.sqrt(mse))
+
+
+DENSIFIED_GT_POINTS = 600_000
+
+
+def densified_views(args, dev, bg):
+    """(training views, held-out views, ground-truth scene) of the densified-scene leg: 36 renders of a 600 k-Gaussian scene,
+    cameras 11-12 of every dozen held out (the reference's split, scene/dataset_readers.py:181-193)."""
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel
+    from w3d_amd.train import render_views
+    cams = [c.to(dev) for c in make_cameras(36, args.width, args.height)]
+    gt_sc = make_scene(DENSIFIED_GT_POINTS, seed=1, scale_mean=0.009)
+    gt = GaussianModel(3, device=dev)
+    gt.create_from_tensors(gt_sc.xyz, gt_sc.features_dc, gt_sc.features_rest, gt_sc.scaling, gt_sc.rotation, gt_sc.opacity)
+    gt.active_sh_degree = 3
+    for cam, img in zip(cams, render_views(gt, cams, bg)):
+        cam.original_image = img.clamp(0.0, 1.0).contiguous()
+    del gt
+    torch.cuda.empty_cache()
+    return [c for i, c in enumerate(cams) if i % 12 < 10], [c for i, c in enumerate(cams) if i % 12 >= 10], gt_sc
+
+
+def grow_densified_model(args, dev, bg, iterations=None, log=None):
+    """Config C3's regime: a model GROWN by the reference's densification schedule instead of a random one of the final size.
+    A synthetic wheat-plot scene (600 k Gaussians, SURVEY section 8d generator) is rendered to the 36 views — 30 for training,
+    cameras 11-12 of every dozen held out, the reference's split (scene/dataset_readers.py:181-193); a 250 k-point cloud of
+    it goes through create_from_pcd (distCUDA2 scales) and is trained the way train_vanilla_3dgs.py:55-115 does, with the
+    iteration counts compressed: densify_and_prune every 100 iterations from 300 until 70 % of `iterations`, opacity reset
+    every max(1000, iterations/3), SH degree raised every 1000 — every one of these on the HIP path.
+    Returns (model, opt, train_cams, held_cams, report)."""
+    from collections import namedtuple
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.train import Trainer, render_views
+    iterations = iterations or args.densify_iterations
+    gt_points, init_points = DENSIFIED_GT_POINTS, 250_000
+    train, held, gt_sc = densified_views(args, dev, bg)
+    g = torch.Generator().manual_seed(2)
+    sel = torch.randperm(gt_points, generator=g)[:init_points]
+    pts = gt_sc.xyz[sel] + 0.004 * torch.randn(init_points, 3, generator=g)
+    col = (0.28209479177387814 * gt_sc.features_dc[sel, 0] + 0.5).clamp(0, 1)
+    PCD = namedtuple("BasicPointCloud", ["points", "colors", "normals"])
+
+    opt = OptimizationParams()                # (instance attributes override the class defaults)
+    opt.iterations = iterations
+    opt.densify_from_iter = 300
+    opt.densify_until_iter = int(0.7 * iterations)
+    opt.densification_interval = 100
+    opt.opacity_reset_interval = max(1000, iterations // 3)
+    opt.position_lr_max_steps = iterations
+    opt.densify_grad_threshold = args.densify_grad_threshold
+    m = GaussianModel(3, device=dev)
+    m.create_from_pcd(PCD(pts.numpy(), col.numpy(), None), 1.0)
+    m.training_setup(opt)
+    tr = Trainer(m, train, opt, bg, densify=True, cameras_extent=2.0)
+
+    def quality(views):
+        return sum(_psnr_db(i, v.original_image) for i, v in zip(render_views(m, views, bg), views)) / len(views)
+    q0 = (quality(train), quality(held))
+    trace = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(1, iterations + 1):
+        tr.step(it)
+        if it % 500 == 0 or it == iterations:
+            torch.cuda.synchronize()
+            trace.append([it, m.num_points, round(time.perf_counter() - t0, 2)])
+            if log:
+                log(f"densified scene: iteration {it}, {m.num_points} Gaussians")
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t0
+    q1 = (quality(train), quality(held))
+    report = {"schedule": {"iterations": iterations, "densify_from_iter": opt.densify_from_iter,
+                           "densify_until_iter": opt.densify_until_iter, "densification_interval": opt.densification_interval,
+                           "opacity_reset_interval": opt.opacity_reset_interval,
+                           "densify_grad_threshold": opt.densify_grad_threshold,
+                           "reference_densify_grad_threshold": 0.0002, "initial_points": init_points,
+                           "views": "30 training + 6 held out of 36"},
+              "gaussians": m.num_points, "peak_gaussians": max(t[1] for t in trace), "train_seconds": round(t_train, 2),
+              "iters_per_s_overall": round(iterations / t_train, 1),
+              "psnr_train_db_before_after": [round(q0[0], 2), round(q1[0], 2)],
+              "psnr_heldout_db_before_after": [round(q0[1], 2), round(q1[1], 2)],
+              "parameters_finite": bool(torch.isfinite(m.flat).all()), "trace_iteration_gaussians_seconds": trace}
+    return m, opt, train, held, report
+
+
+def densified_scene(args, dev, bg, log):
+    """The headline measurement on the densified model: --steps fixed-P steps (no densification inside the timed region,
+    iteration numbers continue after the schedule), with its own dominant-kernel roofline, stage table and workload."""
+    from w3d_amd.train import Trainer
+    m, opt, train, held, rep = grow_densified_model(args, dev, bg, log=log)
+    tr = Trainer(m, train, opt, bg, densify=False)
+    meter = StepMeter(tr, 1, dev)
+    it = opt.iterations
+    opt.iterations = 10 ** 9                       # (the step past `iterations` skips the optimizer: keep stepping)
+    opt.densify_until_iter = 10 ** 9                # statistics tracked as in the headline; Trainer(densify=False) keeps P fixed
+    for _ in range(max(5, args.warmup)):
+        it += 1
+        tr.step(it)
+    meas = meter.measure(args.steps, it, args.profile, args.all_stages)
+    ws = mean_workload(m, train, bg, dev)
+    P, HW = m.num_points, args.width * args.height
+    ips = args.steps / meas["elapsed"]
+    rep.update(value=round(ips, 3), ms_per_step=round(1e3 * meas["elapsed"] / args.steps, 4), steps=args.steps,
+               stage_ms=meas["stage_ms"], visible_per_view=int(ws["V"]), tile_instances_per_view=int(ws["R"]),
+               walked_instances_per_view=int(ws["R_walk"]), mean_contributors_per_pixel=round(ws["mean_contrib"], 2),
+               final_loss=round(float(tr.last["loss"]), 6),
+               roofline=roofline_object(meas, P, ws, HW, True, ips, "densified"))
+    return rep, m
+
+
+# ------------------------------------------------------------------------------------------------ modules-only loop
+class RefStyleModel:
+    """INTEGRATION.md section 1 AS WRITTEN: the user only puts the three rasterizer packages on PYTHONPATH and keeps the
+    reference's own GaussianModel.  This is that model's training-time surface restated for the measurement (six
+    nn.Parameters with torch activations — scene/gaussian_model.py:33-41,101-121 —, torch.optim.Adam over six groups with
+    eps 1e-15 — :172-186 —, add_densification_stats :461-463); it is NOT this package's flat model."""
+
+    def __init__(self, sc, opt, dev):
+        import torch.nn as nn
+        self.max_sh_degree, self.active_sh_degree = 3, 3
+        self._xyz = nn.Parameter(sc.xyz.to(dev).contiguous().requires_grad_(True))
+        self._features_dc = nn.Parameter(sc.features_dc.to(dev).contiguous().requires_grad_(True))
+        self._features_rest = nn.Parameter(sc.features_rest.to(dev).contiguous().requires_grad_(True))
+        self._scaling = nn.Parameter(sc.scaling.to(dev).contiguous().requires_grad_(True))
+        self._rotation = nn.Parameter(sc.rotation.to(dev).contiguous().requires_grad_(True))
+        self._opacity = nn.Parameter(sc.opacity.to(dev).contiguous().requires_grad_(True))
+        P = sc.xyz.shape[0]
+        self.max_radii2D = torch.zeros(P, device=dev)
+        self.xyz_gradient_accum = torch.zeros(P, 1, device=dev)
+        self.denom = torch.zeros(P, 1, device=dev)
+        groups = [{"params": [self._xyz], "lr": opt.position_lr_init, "name": "xyz"},
+                  {"params": [self._features_dc], "lr": opt.feature_lr, "name": "f_dc"},
+                  {"params": [self._features_rest], "lr": opt.feature_lr / 20.0, "name": "f_rest"},
+                  {"params": [self._opacity], "lr": opt.opacity_lr, "name": "opacity"},
+                  {"params": [self._scaling], "lr": opt.scaling_lr, "name": "scaling"},
+                  {"params": [self._rotation], "lr": opt.rotation_lr, "name": "rotation"}]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        from w3d_amd.gaussian_model import get_expon_lr_func
+        self._xyz_lr = get_expon_lr_func(opt.position_lr_init, opt.position_lr_final, lr_delay_mult=opt.position_lr_delay_mult,
+                                         max_steps=opt.position_lr_max_steps)
+
+    get_xyz = property(lambda self: self._xyz)
+    get_scaling = property(lambda self: torch.exp(self._scaling))
+    get_rotation = property(lambda self: torch.nn.functional.normalize(self._rotation))
+    get_opacity = property(lambda self: torch.sigmoid(self._opacity))
+    get_features = property(lambda self: torch.cat((self._features_dc, self._features_rest), dim=1))
+
+    def update_learning_rate(self, iteration):
+        for g in self.optimizer.param_groups:
+            if g["name"] == "xyz":
+                g["lr"] = self._xyz_lr(iteration)
+
+    def oneupSHdegree(self):
+        self.active_sh_degree = min(self.active_sh_degree + 1, self.max_sh_degree)
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
+        self.denom[update_filter] += 1
+
+
+def time_modules_only(args, sc, cams, bg, dev, perm):
+    """The reference loop body (reference_loop) with ONLY the rasterizer module swapped: the reference's own render()
+    marshalling through diff_gaussian_rasterization.GaussianRasterizer on ACTIVATED tensors (this package's render() takes
+    exactly that branch for a model that is not its flat GaussianModel), RefStyleModel's torch activations / six-group
+    torch.optim.Adam, and the reference's loss formulas with torch ops (l1 = mean |a - b|, conv2d SSIM)."""
+    from w3d_amd.gaussian_model import OptimizationParams
+    from w3d_amd.train import PipelineParams
+    from w3d_amd import loss as L
+    n = min(args.steps, 60) if args.modules_only_steps < 0 else args.modules_only_steps
+    if n <= 0:
+        return None
+    opt = OptimizationParams()
+    model = RefStyleModel(sc, opt, dev)
+    pipe = PipelineParams()
+    torch_l1 = lambda a, b: torch.abs(a - b).mean()          # noqa: E731  (utils/loss_utils.py:17-18)
+    fns = (torch_l1, L.ssim_torch)
+    w = max(3, min(args.warmup, 6))
+    reference_loop(model, opt, cams, bg, pipe, 1, w, perm, loss_fns=fns)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reference_loop(model, opt, cams, bg, pipe, 1 + w, n, perm, loss_fns=fns)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ev = []
+    reference_loop(model, opt, cams, bg, pipe, 1 + w + n, min(n, 20), perm, iter_events=ev, loss_fns=fns)
+    torch.cuda.synchronize()
+    iter_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    del model
+    torch.cuda.empty_cache()
+    return {"iters_per_s": round(n / dt, 2), "ms_per_step": round(1e3 * dt / n, 4), "steps": n,
+            "iter_time_ms_median": round(iter_ms[len(iter_ms) // 2], 4),
+            "what": "INTEGRATION.md section 1 as written: only diff_gaussian_rasterization is this repo's; six nn.Parameters with "
+                    "torch exp / sigmoid / normalize / cat, torch.optim.Adam (6 groups), torch conv2d SSIM, the reference loop's "
+                    "host syncs"}
+
+
 # ------------------------------------------------------------------------------------------------ exchange
 def exchange_bandwidth(model, world, dev, rows=0):
     """The step's gradient collectives alone (N > 1): achieved bus bandwidth per GPU.
@@ -492,7 +921,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    from w3d_amd import _lib
     from w3d_amd.train import Trainer, render_views
     from w3d_amd.loss import photometric_loss, photometric_loss_torch
 
@@ -507,36 +935,16 @@ def main():
     loss_fn = photometric_loss_torch if args.torch_loss else photometric_loss
     trainer = Trainer(model, cams, opt, bg, densify=False, loss_fn=loss_fn, fused=False if args.autograd_path else None,
                       force_exchange=force_dist, exchange="rows" if args.exchange == "auto" else args.exchange)
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    _lib.lib.w3d_profile_enable.argtypes = [ctypes.c_char_p]
-    _lib.lib.w3d_profile_collect.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
-
-    def timed(n_steps, it, prof_sel):
-        """n_steps trainer steps between barrier + synchronize brackets; max over ranks.  Returns (seconds, it, stages)."""
-        sync()
-        _lib.lib.w3d_profile_enable(prof_sel)
-        t0 = time.perf_counter()
-        for _ in range(n_steps):
-            it += 1
-            trainer.step(it)
-        sync()
-        t1 = time.perf_counter()
-        _lib.lib.w3d_profile_enable(None)
-        buf = ctypes.create_string_buffer(1 << 16)
-        _lib.lib.w3d_profile_collect(buf, len(buf))
-        stages = {}
-        for line in buf.value.decode().splitlines():
-            name, cnt, ms = line.split()
-            stages[name] = (int(cnt), float(ms))
-        el = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        return float(el), it, stages
+    meter = StepMeter(trainer, world, dev)
+    sync = meter.sync
+    # camera 0 with the INITIAL parameters, for "PSNR vs ref" (compared with the oracle's render in the cpu_baseline leg)
+    own_view0 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from w3d_amd.fused_step import render_raw
+        with torch.no_grad():
+            r0 = render_raw(cams[0], model, bg)
+        own_view0 = tuple(t.detach().cpu().numpy() for t in (r0["render"], r0["depth"], r0["alpha"], cams[0].original_image))
+        del r0
 
     _progress("warm-up")
     it = 0
@@ -551,7 +959,7 @@ def main():
     multi = world > 1 or force_dist        # (--force-dist: the N > 1 code below runs on a 1-rank group, so that one GPU can test it)
     if multi and trainer.fused and args.exchange == "auto":
         autotune = {}
-        for mode in ("rows", "lowrank"):
+        for mode in (("rows", "lowrank") if world <= 32 else ("lowrank",)):   # (rows: one 32-bit view mask per Gaussian)
             trainer.exchange_mode = mode
             for _ in range(2):
                 it += 1
@@ -581,18 +989,13 @@ def main():
                 it += 1
                 trainer.step(it)
             selfcheck["replicas_identical_after_fallback"] = replicas_identical(model, world, dev)
-    prof_sel = b"*" if args.all_stages else args.profile.encode()
     _progress("timed steps")
-    elapsed, it, stages = timed(args.steps, it, prof_sel)
+    meas = meter.measure(args.steps, it, args.profile, args.all_stages)
+    elapsed, it, stages, stage_ms = meas["elapsed"], meas["it"], meas["stages"], meas["stage_ms"]
     final_loss = float(trainer.last["loss"])
 
-    # per-stage times, OUTSIDE the timed region (an event pair around every stage costs ~4 % of the step): 20 more steps
-    if not args.all_stages:
-        _, it, st2 = timed(20, it, b"*")
-        stage_ms = {k: round(ms / c, 4) for k, (c, ms) in st2.items() if c > 0}
-    else:
-        stage_ms = {k: round(ms / c, 4) for k, (c, ms) in stages.items() if c > 0}
-
+    extras_on = not args.no_extras and not args.trained_only and not args.densified_only
+    is_fused = bool(trainer.fused)
     extras = {}
     exchange = None
     if multi:
@@ -610,7 +1013,7 @@ def main():
         exchange["selfcheck_ok"] = bool((selfcheck["replicas_identical_after_warmup"] or
                                          selfcheck.get("replicas_identical_after_fallback", False)) and
                                         exchange["replicas_identical_after_timed_steps"])
-    if not args.no_extras and not args.trained_only:
+    if extras_on:
         _progress("extras: render / FlashSplat")
         # forward-only render throughput (reference render.py's use), same scene, views cycled
         n_r = max(4, min(args.steps, 72))
@@ -727,141 +1130,86 @@ def main():
         del uc, masks, stripes, labels
         torch.cuda.empty_cache()
 
-    ws = None
-    if rank == 0:
-        ws = [workload_stats(model, cams[i], bg, dev) for i in (0, len(cams) // 2)]
+    P, HW = args.points, args.width * args.height
+    single = world == 1 and not force_dist
+    fused_adam = trainer.fused and trainer.fused_adam and single
+    ws = mean_workload(model, cams, bg, dev) if rank == 0 else None
 
-    # the UNMODIFIED reference loop body on the drop-in modules (single GPU: the reference is single-GPU)
-    dropin = None
-    if not args.no_extras and not args.trained_only and world == 1 and not force_dist:
+    # the UNMODIFIED reference loop body on the drop-in modules (single GPU: the reference is single-GPU), and the same
+    # loop with ONLY the rasterizer module swapped (INTEGRATION.md section 1 as written)
+    dropin = modules_only = None
+    if extras_on and single:
         _progress("drop-in loop")
         dropin = time_dropin(args, sc, cams, bg, dev, trainer.perm)
+        _progress("modules-only loop")
+        try:
+            modules_only = time_modules_only(args, sc, cams, bg, dev, trainer.perm)
+        except Exception as e:                     # an extra must never take the bench line down
+            modules_only = {"error": repr(e)}
 
     # the same measurement on a TRAINED scene: the fit lowers opacities and lengthens the per-tile walks
     trained = None
-    if not args.no_extras and args.trained_steps > 0 and trainer.fused:
+    if not args.no_extras and not args.densified_only and args.trained_steps > 0 and trainer.fused:
         _progress("trained scene")
         for _ in range(args.trained_steps):
             it += 1
             trainer.step(it)
-        t_el, it, _ = timed(args.steps, it, None)
-        trained = {"value": round(world * args.steps / t_el, 3), "ms_per_step": round(1e3 * t_el / args.steps, 4),
-                   "after_steps": it - args.steps, "final_loss": round(float(trainer.last["loss"]), 6)}
-        _, it, st3 = timed(20, it, b"*")                 # per-stage times of the trained scene (outside its timed region)
-        trained["stage_ms"] = {k: round(ms / c, 4) for k, (c, ms) in st3.items() if c > 0}
+        tm = meter.measure(args.steps, it, args.profile, args.all_stages)
+        it = tm["it"]
+        trained = {"value": round(world * args.steps / tm["elapsed"], 3), "ms_per_step": round(1e3 * tm["elapsed"] / args.steps, 4),
+                   "after_steps": it - args.steps, "final_loss": round(float(trainer.last["loss"]), 6), "stage_ms": tm["stage_ms"]}
         if rank == 0:
-            w2 = [workload_stats(model, cams[i], bg, dev) for i in (0, len(cams) // 2)]
-            trained["walked_instances_per_view"] = int(sum(w["R_walk"] for w in w2) / len(w2))
-            trained["tile_instances_per_view"] = int(sum(w["R"] for w in w2) / len(w2))
-            trained["_V"] = sum(w["V"] for w in w2) / len(w2)
+            w2 = mean_workload(model, cams, bg, dev)
+            trained.update(visible_per_view=int(w2["V"]), tile_instances_per_view=int(w2["R"]),
+                           walked_instances_per_view=int(w2["R_walk"]),
+                           mean_contributors_per_pixel=round(w2["mean_contrib"], 2),
+                           roofline=roofline_object(tm, P, w2, HW, fused_adam, args.steps / tm["elapsed"], "trained"))
+
+    # ... and on a DENSIFIED one: a model grown to ~2 M Gaussians by the reference's schedule (config C3's regime)
+    densified = None
+    if not args.no_extras and not args.trained_only and args.densify_iterations > 0 and single and is_fused and rank == 0:
+        _progress("densified scene")
+        del trainer, meter
+        model = None
+        torch.cuda.empty_cache()
+        try:
+            densified, _m = densified_scene(args, dev, bg, _progress)
+            del _m
+        except Exception as e:
+            densified = {"error": repr(e)}
+        torch.cuda.empty_cache()
 
     if rank == 0:
-        V = sum(w["V"] for w in ws) / len(ws)
-        R = sum(w["R"] for w in ws) / len(ws)
-        Rw = sum(w["R_walk"] for w in ws) / len(ws)
-        HW = args.width * args.height
-        P = args.points
-        fused_adam = trainer.fused and trainer.fused_adam and world == 1 and not force_dist
-
-        def kernel_bytes(V, R, Rw):
-            """Algorithmic HBM bytes per launch of every stage (what the stage must read and write once)."""
-            return {
-                "preprocess_fwd": 236.0 * P + 64.0 * V,              # parameters read; packed per-visible records written
-                # first pass reads P (key, id) pairs, the others V; the last writes 24-B records from a 16-B rect/mask gather
-                "depth_sort": 8.0 * P + 8.0 * V + 2 * 16.0 * V + (8.0 + 16.0 + 24.0) * V,
-                "tile_count_scan": 24.0 * V,                           # the records, once
-                "fill_lists": 24.0 * V + 4.0 * R,                      # the records once + the lists
-                "render_fwd": 48.0 * Rw + 36.0 * HW,                   # 4-B id + 44-B gather per walked instance; image + aux
-                "loss": 2 * 12.0 * HW + 12.0 * HW,                     # image + gt read, gradient written
-                "render_bwd": 84.0 * Rw + 20.0 * HW,                   # gather + one 40-B record update; dL/dpixel + aux
-                # fused Adam: parameters + both moments read and written, 2-D records read / otherwise gradients written
-                "preprocess_bwd": (6 * 236.0 * P + 104.0 * V) if fused_adam else (236.0 * P + 64.0 * V + 252.0 * P),
-            }
-
-        def kernel_table(stage_ms, V, R, Rw):
-            """Per stage: event-timed ms, algorithmic bytes, achieved GB/s and fraction of the HBM peak, PMC-counter traffic of
-            the newest committed summary and its ratio to the algorithmic bytes (wasted re-reads show up there)."""
-            kb = kernel_bytes(V, R, Rw)
-            pmc_name = {"preprocess_fwd": "preprocess_fwd_kernel", "preprocess_bwd": "preprocess_bwd_kernel",
-                        "render_fwd": "render_fwd_kernel", "render_bwd": "render_bwd_kernel", "fill_lists": "chunk_walk_kernel<1",
-                        "loss": "l1_ssim", "depth_sort": "radix_", "tile_count_scan": "chunk_walk_kernel<0"}
-            rows = []
-            for k, ms in sorted(stage_ms.items(), key=lambda kv: -kv[1]):
-                if k not in kb:
-                    continue
-                gbs = kb[k] / (ms * 1e-3) / 1e9
-                tr = pmc_traffic(pmc_name.get(k, k))
-                rows.append({"stage": k, "ms": ms, "algorithmic_bytes": int(kb[k]), "achieved_GBps": round(gbs, 1),
-                             "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "pmc_traffic_bytes": tr,
-                             "traffic_ratio": None if not tr else round(tr / kb[k], 2)})
-            return rows
-
-        def step_roofline(V, R, Rw, it_per_s, stage_ms):
-            """SURVEY.md section 8(d) / BASELINE.md section 5 as written: (B_f + B_b + B_adam) * iters/s / peak with the MEASURED
-            V and R, and the same with this design's own byte count (sum of the stages' algorithmic bytes — fusion removed the
-            gradient round trip and the 64-bit key sort, so it is smaller)."""
-            B_f = 236.0 * P + 56.0 * V + 80.0 * R + 28.0 * HW
-            B_b = 484.0 * P + 80.0 * V + 84.0 * R + 20.0 * HW
-            B_adam = 1652.0 * P
-            tot = B_f + B_b + B_adam
-            kb = kernel_bytes(V, R, Rw)
-            own = sum(kb[k] for k in kb if k in stage_ms)
-            return {"formula": "B_f + B_b + B_adam, B_f = 236P + 56V + 80R + 28HW, B_b = 484P + 80V + 84R + 20HW, B_adam = 1652P",
-                    "P": P, "V": int(V), "R": int(R), "HW": HW, "B_f": int(B_f), "B_b": int(B_b), "B_adam": int(B_adam),
-                    "algorithmic_bytes": int(tot), "achieved_GBps": round(tot * it_per_s / 1e9, 1),
-                    "frac": round(tot * it_per_s / 1e9 / HBM_PEAK_GBS, 4),
-                    "design_bytes": int(own), "design_achieved_GBps": round(own * it_per_s / 1e9, 1),
-                    "design_frac": round(own * it_per_s / 1e9 / HBM_PEAK_GBS, 4)}
-
         it_per_s = args.steps / elapsed          # per GPU (weak scaling: every rank runs this step)
-        algo = kernel_bytes(V, R, Rw)
-        roof = None
-        if args.profile in stages and stages[args.profile][0] > 0:
-            # the dominant kernel, timed with HIP events on its launch stream INSIDE the timed region
-            cnt, ms = stages[args.profile]
-            avg_ms = ms / cnt
-            hbm_ach = algo.get(args.profile, 0.0) / (avg_ms * 1e-3) / 1e9
-            label = "preprocess_bwd+adam" if (args.profile == "preprocess_bwd" and fused_adam) else args.profile
-            tr = pmc_traffic(args.profile + "_kernel")
-            roof = {"bound": "hbm", "kernel": label, "achieved": round(hbm_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(hbm_ach / HBM_PEAK_GBS, 4), "traffic": tr,
-                    "traffic_ratio": None if not tr else round(tr / algo[args.profile], 2),
-                    "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
-                    "algorithmic_bytes_per_launch": int(algo.get(args.profile, 0.0)),
-                    "step": step_roofline(V, R, Rw, it_per_s, stage_ms),
-                    "kernels": kernel_table(stage_ms, V, R, Rw)}
-        # the blend backward's own roof is VALU issue, not HBM (DESIGN.md section 2.1): kept beside the HBM objects
-        valu = None
-        n_valu, src = valu_instructions("render_bwd_kernel")
-        if n_valu and "render_bwd" in stage_ms:
-            peak, peak_src = valu_peak()
-            ach = n_valu * FLOP_PER_VALU_INSTR / (stage_ms["render_bwd"] * 1e-3) / 1e12
-            valu = {"bound": "valu", "kernel": "render_bwd", "achieved": round(ach, 2), "peak": VALU_SPEC_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / VALU_SPEC_TFLOPS, 4), "peak_measured": round(peak, 1),
-                    "frac_of_measured": round(ach / peak, 4), "avg_launch_ms": stage_ms["render_bwd"],
-                    "valu_wave_instr_per_launch": int(n_valu), "valu_instr_source": src, "peak_source": peak_src,
-                    "flop_equiv_per_wave_instr": FLOP_PER_VALU_INSTR,
-                    "note": "instruction count from the committed SQ counter summary (collected on the untrained scene)"}
+        roof = roofline_object(meas, P, ws, HW, fused_adam, it_per_s, "untrained")
+        # the blend backward's own roof is VALU issue, not HBM: kept beside the dominant kernel's object
+        valu = valu_object("render_bwd", stage_ms["render_bwd"], "untrained") if "render_bwd" in stage_ms else None
         if args.all_stages:
             for k, (c, ms) in sorted(stages.items(), key=lambda kv: -kv[1][1]):
                 print(f"[stage] {k:18s} {c:5d} launches  avg {ms / c:8.4f} ms", file=sys.stderr)
+        step_desc = "fused raw-parameter kernels (no autograd)" if is_fused else "render() + autograd (Trainer.step)"
         out = {
-            "metric": "train iters/sec @ 2M Gaussians, 1600x1200 (render+loss+backward+Adam); render Mpix/sec alongside",
+            "metric": "train iters/sec @ 2M Gaussians, 1600x1200 (render+loss+backward+Adam); render Mpix/sec and PSNR vs the oracle alongside",
             "value": round(world * args.steps / elapsed, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            # the same step on the scene after `trained_steps` more training steps (opacities dropped, walks 2-3x longer): the
-            # regime a real run spends its time in
+            # the same step on the scene after `trained_steps` more training steps (opacities dropped, walks 2-3x longer) and on a
+            # model GROWN to ~2 M Gaussians by the reference's densification schedule: the regimes a real run spends its time in
             "trained_value": None if trained is None else trained["value"],
             "trained_ms_per_step": None if trained is None else trained["ms_per_step"],
+            "densified_value": None if not densified or "value" not in densified else densified["value"],
+            "densified_ms_per_step": None if not densified or "value" not in densified else densified["ms_per_step"],
             "dropin_iters_per_s": None if dropin is None else dropin["iters_per_s"],
+            "modules_only_iters_per_s": None if not modules_only or "iters_per_s" not in modules_only else modules_only["iters_per_s"],
             "config": {"workload": f"C3: plot-shaped synthetic scene, {P} Gaussians, SH degree 3, "
                                    f"{args.width}x{args.height}, {args.views} overhead cameras, depth+alpha channels",
                        "points": P, "image": [args.width, args.height], "views_per_step": world,
                        "parallelism": f"view-parallel dp{world}" if world > 1 else "single GPU",
-                       "visible_per_view": int(V), "tile_instances_per_view": int(R), "walked_instances_per_view": int(Rw),
+                       "visible_per_view": int(ws["V"]), "tile_instances_per_view": int(ws["R"]),
+                       "walked_instances_per_view": int(ws["R_walk"]),
+                       "mean_contributors_per_pixel": round(ws["mean_contrib"], 2),
                        "loss": "torch conv2d" if args.torch_loss else "fused HIP L1+SSIM",
-                       "step": "fused raw-parameter kernels (no autograd)" if trainer.fused else "render() + autograd (Trainer.step)",
+                       "step": step_desc,
                        "final_loss": round(final_loss, 6)},
             "roofline": roof,
             "roofline_valu_kernel": valu,
@@ -872,17 +1220,23 @@ def main():
             out["dropin"] = dict(dropin, loop="reference train_vanilla_3dgs.py:55-115 body on the drop-in render / "
                                               "GaussianModel / l1_loss / ssim; loss.item() and the boolean-mask statistics "
                                               "lines (host syncs of the reference loop) included")
+        if modules_only is not None:
+            out["modules_only"] = modules_only
         if trained is not None:
-            tV, tR, tRw = trained.pop("_V"), trained["tile_instances_per_view"], trained["walked_instances_per_view"]
-            trained["roofline"] = {"step": step_roofline(tV, tR, tRw, trained["value"] / world, trained["stage_ms"]),
-                                   "kernels": kernel_table(trained["stage_ms"], tV, tR, tRw)}
             out["trained_scene"] = trained
+        if densified is not None:
+            out["densified_scene"] = densified
         if exchange is not None:
             out["exchange"] = exchange
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, own_view0)
+            out["psnr"] = out["cpu_baseline"].pop("psnr", None)
         else:
             out["cpu_baseline"] = None
+            out["psnr"] = None
+        if densified and "psnr_train_db_before_after" in densified:
+            out["psnr"] = dict(out["psnr"] or {}, densified_run_train_db_before_after=densified["psnr_train_db_before_after"],
+                               densified_run_heldout_db_before_after=densified["psnr_heldout_db_before_after"])
         _emit(json.dumps(out))
     if world > 1 or force_dist:
         dist.barrier()

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""K fused training steps of ONE of bench.py's scenes between two marker kernels, for rocprofv3 counter passes.
+
+    python3 profiles/scene_step.py --scene untrained|trained|densified --steps 6 [--model-file /tmp/x.pt]
+
+The scene is built exactly as bench.py builds it (same generator, cameras, ground truth; `trained` = 3000 more steps at
+fixed P, `densified` = bench.grow_densified_model).  With --model-file the prepared model (GaussianModel.capture()) is
+saved there on the first run and restored on later ones, so the counter passes do not repeat the preparation under the
+profiler.  The K measured steps sit between two launches of a marker kernel (torch.lgamma on 1 element — nothing else in
+the process launches it): profiles/summarize_pmc.py --window / summarize_sq.py --window sum every kernel's counters over
+the dispatches between the markers and divide by K -> per-step, per-kernel figures that bench.py adds up per stage."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "wheat-3dgs_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="untrained", choices=("untrained", "trained", "densified"))
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=40, help="steps before the window (>= 36 so that every camera's walk hint exists)")
+    ap.add_argument("--model-file", default=None)
+    ap.add_argument("--trained-steps", type=int, default=3000)
+    a = ap.parse_args()
+    args = bench.parse_defaults()
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    bg = torch.zeros(3, device=dev)
+    have = a.model_file and os.path.exists(a.model_file)
+    if a.scene == "densified":
+        if have:
+            pack = torch.load(a.model_file, weights_only=False)
+            cams = bench.densified_views(args, dev, bg)[0]
+            opt = pack["opt"]
+            model = GaussianModel(3, device=dev)
+            model.restore(pack["model"], opt)
+            it = pack["it"]
+        else:
+            model, opt, cams, _, _ = bench.grow_densified_model(args, dev, bg, log=bench._progress)
+            it = opt.iterations
+            if a.model_file:
+                torch.save({"model": model.capture(), "opt": opt, "it": it}, a.model_file)
+        opt.iterations, opt.densify_until_iter = 10 ** 9, 10 ** 9
+    else:
+        sc, model, opt, cams = bench.build_scene(args, dev)
+        bench.make_ground_truth(args, cams, dev, bg)
+        it = 0
+        if a.scene == "trained":
+            if have:
+                pack = torch.load(a.model_file, weights_only=False)
+                model = GaussianModel(3, device=dev)
+                model.restore(pack["model"], OptimizationParams())
+                it = pack["it"]
+            else:
+                tr0 = Trainer(model, cams, opt, bg, densify=False)
+                for _ in range(a.trained_steps):
+                    it += 1
+                    tr0.step(it)
+                if a.model_file:
+                    torch.save({"model": model.capture(), "it": it}, a.model_file)
+    trainer = Trainer(model, cams, opt, bg, densify=False)
+    for _ in range(a.warmup):
+        it += 1
+        trainer.step(it)
+    mark = torch.ones(1, device=dev)
+    torch.cuda.synchronize()
+    torch.lgamma(mark)                      # ---- window opens
+    for _ in range(a.steps):
+        it += 1
+        trainer.step(it)
+    torch.lgamma(mark)                      # ---- window closes
+    torch.cuda.synchronize()
+    print(f"scene_step: {a.scene}, {model.num_points} Gaussians, {a.steps} steps in the window", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

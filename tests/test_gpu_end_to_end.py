@@ -1,0 +1,238 @@
+"""Configs C3 and C4 END TO END as -m gpu tests (round 3 ran them as evidence scripts without assertions:
+profiles/c3_densify_run.py, profiles/c4_seg_run.py).
+
+C3: reference train_vanilla_3dgs.py:55-115 with scene/gaussian_model.py:399-459 (densify_and_prune) on a compressed schedule,
+from a point cloud through create_from_pcd (distCUDA2), at 1600x1200 — the Gaussian count must grow, the held-out PSNR rise,
+the statistics the fused kernels accumulate equal the reference's statements, and the fused step after the last compaction
+equal the autograd step.
+C4: reference run_3d_seg.py:74-172 (label step: per-mask contribution renders summed over the views + multi_instance_opt;
+find_match: subset render, alpha > 0.5, bounding box, IoU against the candidate masks) on a scene with PLANTED objects and the
+masks a perfect 2-D segmenter would deliver — recall of the planted membership and the best-candidate rate are asserted.
+Numbers of every run go to gpurun_out/end_to_end.jsonl."""
+import json
+import math
+import os
+from collections import namedtuple
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _record(obj):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "end_to_end.jsonl"), "a") as f:
+        f.write(json.dumps(obj) + "\n")
+
+
+def _psnr(a, b):
+    mse = float(((a - b) ** 2).mean())
+    return 99.0 if mse == 0 else 20.0 * math.log10(1.0 / math.sqrt(mse))       # reference utils/image_utils.py:17-19
+
+
+def _clone_model(m, opt):
+    from w3d_amd.gaussian_model import GaussianModel
+    twin = GaussianModel(3, device=m.flat.device)
+    twin.restore(m.capture(), opt)
+    twin.max_radii2D, twin.xyz_gradient_accum, twin.denom = m.max_radii2D.clone(), m.xyz_gradient_accum.clone(), m.denom.clone()
+    return twin
+
+
+def test_c3_compressed_densify_schedule_from_a_point_cloud():
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.gaussian_renderer import render
+    from w3d_amd.loss import l1_loss, ssim
+    from w3d_amd.train import PipelineParams, Trainer, render_views
+    import w3d_amd.gaussian_renderer as gr
+    dev = torch.device("cuda:0")
+    W, H = 1600, 1200
+    bg = torch.zeros(3, device=dev)
+    cams = [c.to(dev) for c in make_cameras(36, W, H)]
+    gt_points, init_points, iterations = 300_000, 100_000, 1500
+    gt_sc = make_scene(gt_points, seed=1, scale_mean=0.011)
+    gt = GaussianModel(3, device=dev)
+    gt.create_from_tensors(gt_sc.xyz, gt_sc.features_dc, gt_sc.features_rest, gt_sc.scaling, gt_sc.rotation, gt_sc.opacity)
+    gt.active_sh_degree = 3
+    for cam, img in zip(cams, render_views(gt, cams, bg)):
+        cam.original_image = img.clamp(0.0, 1.0).contiguous()
+    del gt
+    train = [c for i, c in enumerate(cams) if i % 12 < 10]         # the reference's split (scene/dataset_readers.py:181-193)
+    held = [c for i, c in enumerate(cams) if i % 12 >= 10]
+    g = torch.Generator().manual_seed(2)
+    sel = torch.randperm(gt_points, generator=g)[:init_points]
+    pts = gt_sc.xyz[sel] + 0.004 * torch.randn(init_points, 3, generator=g)
+    col = (0.28209479177387814 * gt_sc.features_dc[sel, 0] + 0.5).clamp(0, 1)
+    PCD = namedtuple("BasicPointCloud", ["points", "colors", "normals"])
+    opt = OptimizationParams()
+    opt.iterations = iterations
+    opt.densify_from_iter, opt.densify_until_iter, opt.densification_interval = 200, 1101, 100
+    opt.opacity_reset_interval = 600
+    opt.position_lr_max_steps = iterations
+    opt.densify_grad_threshold = 1.5e-5        # (reference 2e-4 is tuned for photographs)
+    last_densify = 1100
+    m = GaussianModel(3, device=dev)
+    m.create_from_pcd(PCD(pts.numpy(), col.numpy(), None), 1.0)
+    m.training_setup(opt)
+    assert m.num_points == init_points
+    tr = Trainer(m, train, opt, bg, densify=True, cameras_extent=2.0)
+
+    def quality(views):
+        return sum(_psnr(i, v.original_image) for i, v in zip(render_views(m, views, bg), views)) / len(views)
+    q0 = (quality(train), quality(held))
+    counts = {}
+    interval_start = last_densify - opt.densification_interval          # the densification at this iteration resets the statistics
+    for it in range(1, interval_start + 1):
+        tr.step(it)
+        if it % 100 == 0:
+            counts[it] = m.num_points
+    # ---- the statistics of the LAST densification interval against the reference's statements.  A twin of the model follows
+    # the trainer through the interval: before every step it takes the trainer's current parameters and runs that iteration's
+    # view through render() + loss.backward() and the three statistics lines of train_vanilla_3dgs.py:102-103 /
+    # scene/gaussian_model.py:461-463 (activated tensors through the drop-in module, torch statements — no optimizer step of
+    # its own).  The trainer's kernels (statistics fused into the backward + Adam kernel; host statements in the densifying
+    # iteration) must have accumulated the same — their values are caught right before densify_and_prune consumes them.
+    twin = _clone_model(m, opt)
+    assert float(twin.denom.max()) == 0.0
+    gr_flag, gr.RAW_AUTOGRAD = gr.RAW_AUTOGRAD, False
+    pipe = PipelineParams()
+
+    def reference_statements(it):
+        twin.flat.detach().copy_(m.flat.detach())
+        cam = tr.camera_for(it)
+        twin.optimizer.zero_grad(set_to_none=True)
+        pkg = render(cam, twin, pipe, bg)
+        loss = (1.0 - opt.lambda_dssim) * l1_loss(pkg["render"], cam.original_image) + \
+            opt.lambda_dssim * (1.0 - ssim(pkg["render"], cam.original_image))
+        loss.backward()
+        with torch.no_grad():
+            vf, radii = pkg["visibility_filter"], pkg["radii"]
+            twin.max_radii2D[vf] = torch.max(twin.max_radii2D[vf], radii[vf])
+            twin.add_densification_stats(pkg["viewspace_points"], vf)
+    try:
+        for it in range(interval_start + 1, last_densify):
+            reference_statements(it)
+            tr.step(it)
+        reference_statements(last_densify)
+    finally:
+        gr.RAW_AUTOGRAD = gr_flag
+    caught = {}
+    real = m.densify_and_prune
+
+    def spy(*a, **k):
+        caught.update(accum=m.xyz_gradient_accum.clone(), denom=m.denom.clone(), radii=m.max_radii2D.clone(), P=m.num_points)
+        return real(*a, **k)
+    m.densify_and_prune = spy
+    tr.step(last_densify)
+    m.densify_and_prune = real
+    assert caught["P"] == twin.num_points
+    n = float(caught["P"])
+    # visibility counts and radii: integer work — identical except where the raw-parameter kernels' own exp / normalize move
+    # 3 sigma across an integer (test_gpu_fullsize: <= 4 of 2 M per view, by exactly 1)
+    denom_diff = float((caught["denom"] != twin.denom).sum()) / n
+    radii_diff = (caught["radii"] - twin.max_radii2D).abs()
+    assert denom_diff <= 1e-5, denom_diff
+    assert float(radii_diff.max()) <= 1.0 and float((radii_diff > 0).sum()) / n <= 2e-4
+    ref = twin.xyz_gradient_accum
+    both = (ref > 0) & (caught["accum"] > 0)
+    assert float(((ref > 0) != (caught["accum"] > 0)).sum()) / n <= 1e-4
+    err = ((caught["accum"] - ref).abs() / ref.abs().clamp_min(1e-30))[both].float()
+    stat_p99, stat_p999 = float(err.quantile(0.99)), float(err.quantile(0.999))
+    # north_star: densification-grad norms within 1e-4 (p99 unconditionally; the tail is threshold flips of single views,
+    # DESIGN.md section 4, diluted here by the ~30 views a Gaussian's sum holds)
+    assert stat_p99 <= 1e-4 and stat_p999 <= 1e-3, (stat_p99, stat_p999)
+    counts[last_densify] = m.num_points
+    # ---- the fused step right after the last compaction == the autograd step (images, statistics, first moments)
+    twin = _clone_model(m, opt)
+    tr2 = Trainer(twin, train, opt, bg, densify=True, cameras_extent=2.0, fused=False)
+    assert tr.fused and not tr2.fused
+    la, lb = float(tr.step(last_densify + 1)), float(tr2.step(last_densify + 1))
+    assert abs(la - lb) <= 1e-6
+    assert float((tr.last["image"] - tr2.last["image"]).abs().max()) <= 2e-5
+    moment_err = {}
+    for name, (a, b) in m.block_slices().items():
+        x, y = m.optimizer.exp_avg[a:b], twin.optimizer.exp_avg[a:b]
+        moment_err[name] = float((x - y).abs().max() / (y.abs().max() + 1e-30))
+        assert moment_err[name] <= 2e-4, (name, moment_err[name])
+    del twin, tr2
+    for it in range(last_densify + 2, iterations + 1):
+        tr.step(it)
+    q1 = (quality(train), quality(held))
+    finite = bool(torch.isfinite(m.flat).all())
+    _record({"test": "c3_compressed_densify", "gaussians_by_iteration": counts, "final_gaussians": m.num_points,
+             "psnr_train": [round(q0[0], 2), round(q1[0], 2)], "psnr_heldout": [round(q0[1], 2), round(q1[1], 2)],
+             "stat_accum_rel_err_p99_p999": [stat_p99, stat_p999], "stat_denom_diff_frac": denom_diff, "first_moment_rel_err_fused_vs_autograd": moment_err, "finite": finite})
+    assert finite
+    assert m.num_points >= 2 * init_points, counts                  # densification grew the model (measured: ~4x)
+    assert q1[1] - q0[1] >= 6.0 and q1[0] - q0[0] >= 8.0, (q0, q1)  # held-out / training PSNR rise (measured: +10 / +15 dB)
+    assert m.active_sh_degree == 1                                   # raised once, at iteration 1000
+
+
+def test_c4_label_and_find_match_loop_recovers_planted_objects():
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel
+    from w3d_amd.gaussian_renderer import flashsplat_render
+    from w3d_amd.segmentation import accumulate_counts_raw, mask_iou_device, multi_instance_opt
+    from w3d_amd.train import PipelineParams
+    dev = torch.device("cuda:0")
+    W, H, P, K = 1600, 1200, 300_000, 6
+    bg = torch.zeros(3, device=dev)
+    pipe = PipelineParams()
+    cams = [c.to(dev) for c in make_cameras(36, W, H)][::3]          # 12 of the 36 views
+    V = len(cams)
+    sc = make_scene(P, seed=2, scale_mean=0.008)
+    g = torch.Generator().manual_seed(5)
+    centres = torch.stack([torch.rand(K, generator=g) * 2.4 - 1.2, torch.rand(K, generator=g) * 1.0 - 0.5,
+                           0.35 + 0.2 * torch.rand(K, generator=g)], 1)
+    member = torch.stack([(sc.xyz - c).norm(dim=1) < 0.09 for c in centres])
+    member &= member.cumsum(0) == 1
+    sc.opacity[member.any(0)] = 2.5
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    m.active_sh_degree = 3
+    member = member.to(dev)
+    with torch.no_grad():
+        masks = torch.zeros(V, K, H, W, dtype=torch.bool, device=dev)
+        for v, cam in enumerate(cams):
+            for k in range(K):
+                masks[v, k] = flashsplat_render(cam, m, pipe, bg, used_mask=member[k])["alpha"][0] > 0.5
+        # label step (run_3d_seg.py:75-104): contributions summed over the views, one object at a time, then multi_instance_opt;
+        # the kernel-side accumulation must equal the reference's formulation (sum of per-view used_count tensors)
+        pred = torch.zeros(K, P, dtype=torch.bool, device=dev)
+        for k in range(K):
+            counts = accumulate_counts_raw(m, cams, [masks[v, k].float() for v in range(V)], bg, obj_num=1)
+            if k == 0:
+                ref = sum(flashsplat_render(cam, m, pipe, bg, gt_mask=masks[v, 0].float(), obj_num=1)["used_count"]
+                          for v, cam in enumerate(cams))
+                assert float((counts - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+            pred[k] = multi_instance_opt(counts)[1]
+        inter = (pred & member).sum(1).float()
+        recall = (inter / member.sum(1).float().clamp_min(1)).cpu()
+        precision = (inter / pred.sum(1).float().clamp_min(1)).cpu()
+        # find_match (:113-175): the labelled object against the candidate masks of every view
+        hits, scored, ious = 0, 0, []
+        for k in range(K):
+            for v, cam in enumerate(cams):
+                alpha = flashsplat_render(cam, m, pipe, bg, used_mask=pred[k])["alpha"]
+                iou, bbox, n_pred = mask_iou_device(alpha, masks[v].to(torch.uint8), 0.5)
+                if int(masks[v, k].sum()) > 50:
+                    scored += 1
+                    hits += int(int(iou.argmax()) == k)
+                    ious.append(float(iou[k]))
+                    # ... and the device scoring equals the reference's host formulation on this view
+                    if k == 0 and v == 0:
+                        p = alpha[0] > 0.5
+                        want = [float((mk & p).sum()) / max(float((mk | p).sum()), 1.0) for mk in masks[v]]
+                        assert max(abs(a - b) for a, b in zip(want, iou.tolist())) <= 1e-12
+                        ys, xs = torch.nonzero(p, as_tuple=True)
+                        assert bbox == (int(xs.min()), int(ys.min()), int(xs.max()), int(ys.max())) and n_pred == int(p.sum())
+    rate = hits / max(scored, 1)
+    _record({"test": "c4_label_and_find_match", "objects": K, "views": V, "gaussians": P,
+             "gaussians_per_object": [int(x) for x in member.sum(1).cpu()], "recall": [round(float(x), 3) for x in recall],
+             "precision": [round(float(x), 3) for x in precision], "scored_views": scored, "best_candidate_rate": round(rate, 4),
+             "mask_iou_mean": round(sum(ious) / max(len(ious), 1), 4)})
+    assert scored >= K * V // 2
+    assert float(recall.mean()) >= 0.75 and float(recall.min()) >= 0.5, recall       # (r03 script, 12 objects / 36 views: 0.86)
+    assert rate >= 0.9, rate                                                          # (r03 script: 0.988)
