@@ -73,7 +73,7 @@ def parse(argv=None):
                     help="run only the reference-loop measurement (for rocprofv3 --kernel-trace of that loop) and print its JSON")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip render / FlashSplat / drop-in / modules-only / trained-scene / densified-scene measurements")
-    ap.add_argument("--densify-iterations", type=int, default=6000,
+    ap.add_argument("--densify-iterations", type=int, default=8000,
                     help="iterations of the compressed C3 schedule that grows the densified scene (densified_scene leg); 0: skip")
     ap.add_argument("--densify-grad-threshold", type=float, default=1.5e-5,
                     help="densify_grad_threshold of that schedule (reference default 2e-4, arguments/__init__.py:88, tuned for "
@@ -462,10 +462,11 @@ def reference_loop(model, opt, cams, bg, pipe, first_iter, n_steps, perm, iter_e
     return ema_loss_for_log
 
 
-def time_dropin(args, sc, cams, bg, dev, perm):
+def time_dropin(args, sc, cams, bg, dev, perm, loss_fns=None, n=None):
     from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
     from w3d_amd.train import PipelineParams
-    n = args.steps if args.dropin_steps < 0 else args.dropin_steps
+    if n is None:
+        n = args.steps if args.dropin_steps < 0 else args.dropin_steps
     if n <= 0:
         return None
     model = GaussianModel(3, device=dev)
@@ -475,16 +476,16 @@ def time_dropin(args, sc, cams, bg, dev, perm):
     model.training_setup(opt)
     pipe = PipelineParams()
     w = max(3, min(args.warmup, 10))
-    reference_loop(model, opt, cams, bg, pipe, 1, w, perm)
+    reference_loop(model, opt, cams, bg, pipe, 1, w, perm, loss_fns=loss_fns)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    reference_loop(model, opt, cams, bg, pipe, 1 + w, n, perm)
+    reference_loop(model, opt, cams, bg, pipe, 1 + w, n, perm, loss_fns=loss_fns)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     # the reference's own timer (TensorBoard `iter_time`, train_vanilla_3dgs.py:56,82,149): CUDA/HIP events around
     # render + loss + backward — a separate short run, so the event pairs do not sit in the timed loop above
     ev = []
-    reference_loop(model, opt, cams, bg, pipe, 1 + w + n, min(n, 36), perm, iter_events=ev)
+    reference_loop(model, opt, cams, bg, pipe, 1 + w + n, min(n, 36), perm, iter_events=ev, loss_fns=loss_fns)
     torch.cuda.synchronize()
     iter_ms = sorted(a.elapsed_time(b) for a, b in ev)
     del model
@@ -840,28 +841,41 @@ def time_modules_only(args, sc, cams, bg, dev, perm):
     if n <= 0:
         return None
     opt = OptimizationParams()
-    model = RefStyleModel(sc, opt, dev)
     pipe = PipelineParams()
     torch_l1 = lambda a, b: torch.abs(a - b).mean()          # noqa: E731  (utils/loss_utils.py:17-18)
-    fns = (torch_l1, L.ssim_torch)
+    torch_fns = (torch_l1, L.ssim_torch)
     w = max(3, min(args.warmup, 6))
-    reference_loop(model, opt, cams, bg, pipe, 1, w, perm, loss_fns=fns)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    reference_loop(model, opt, cams, bg, pipe, 1 + w, n, perm, loss_fns=fns)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ev = []
-    reference_loop(model, opt, cams, bg, pipe, 1 + w + n, min(n, 20), perm, iter_events=ev, loss_fns=fns)
-    torch.cuda.synchronize()
-    iter_ms = sorted(a.elapsed_time(b) for a, b in ev)
-    del model
-    torch.cuda.empty_cache()
-    return {"iters_per_s": round(n / dt, 2), "ms_per_step": round(1e3 * dt / n, 4), "steps": n,
-            "iter_time_ms_median": round(iter_ms[len(iter_ms) // 2], 4),
-            "what": "INTEGRATION.md section 1 as written: only diff_gaussian_rasterization is this repo's; six nn.Parameters with "
-                    "torch exp / sigmoid / normalize / cat, torch.optim.Adam (6 groups), torch conv2d SSIM, the reference loop's "
-                    "host syncs"}
+
+    def run(fns):
+        model = RefStyleModel(sc, opt, dev)
+        reference_loop(model, opt, cams, bg, pipe, 1, w, perm, loss_fns=fns)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reference_loop(model, opt, cams, bg, pipe, 1 + w, n, perm, loss_fns=fns)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ev = []
+        reference_loop(model, opt, cams, bg, pipe, 1 + w + n, min(n, 20), perm, iter_events=ev, loss_fns=fns)
+        torch.cuda.synchronize()
+        iter_ms = sorted(a.elapsed_time(b) for a, b in ev)
+        del model
+        torch.cuda.empty_cache()
+        return n / dt, iter_ms[len(iter_ms) // 2]
+    base, base_iter = run(torch_fns)
+    out = {"iters_per_s": round(base, 2), "ms_per_step": round(1e3 / base, 4), "steps": n,
+           "iter_time_ms_median": round(base_iter, 4),
+           "what": "INTEGRATION.md section 1 as written: only diff_gaussian_rasterization is this repo's; six nn.Parameters with "
+                   "torch exp / sigmoid / normalize / cat, torch.optim.Adam (6 groups), torch conv2d SSIM, the reference loop's "
+                   "host syncs"}
+    # which of the other swaps buys what (same loop, one more module of this repo at a time)
+    try:
+        plus_loss, _ = run(None)                                  # + utils.loss_utils -> w3d_amd.loss (fused L1 + SSIM pair)
+        out["plus_loss_module_iters_per_s"] = round(plus_loss, 2)
+        d = time_dropin(args, sc, cams, bg, dev, perm, loss_fns=torch_fns, n=n)     # + scene.GaussianModel / render, torch loss
+        out["plus_model_and_render_modules_iters_per_s"] = d["iters_per_s"]
+    except Exception as e:
+        out["breakdown_error"] = repr(e)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ exchange

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=40, help="steps before the window (>= 36 so that every camera's walk hint exists)")
     ap.add_argument("--model-file", default=None)
     ap.add_argument("--trained-steps", type=int, default=3000)
+    ap.add_argument("--report", action="store_true",
+                    help="instead of the marker window: time --steps steps (bench.StepMeter: probe, timed, per-stage events) and print "
+                         "one JSON line {scene, iters_per_s, ms_per_step, stage_ms} — the A/B harness of profiles/ab_scenes.sh")
     a = ap.parse_args()
     args = bench.parse_defaults()
     from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
@@ -71,6 +74,14 @@ def main():
     for _ in range(a.warmup):
         it += 1
         trainer.step(it)
+    if a.report:
+        import json
+        meter = bench.StepMeter(trainer, 1, dev)
+        meas = meter.measure(a.steps, it, "auto", False, probe_steps=6, stage_steps=20)
+        print(json.dumps({"scene": a.scene, "lib": os.environ.get("W3D_HIP_LIB", "product"), "gaussians": model.num_points,
+                          "iters_per_s": round(a.steps / meas["elapsed"], 2), "ms_per_step": round(1e3 * meas["elapsed"] / a.steps, 4),
+                          "stage_ms": meas["stage_ms"]}))
+        return
     mark = torch.ones(1, device=dev)
     torch.cuda.synchronize()
     torch.lgamma(mark)                      # ---- window opens

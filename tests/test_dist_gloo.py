@@ -164,7 +164,7 @@ def _lowrank_worker(rank, world, port, out, mode):
     from w3d_amd.train import Trainer
     P = m.num_points
     tr = Trainer(m, _cams(), opt, torch.zeros(3), densify=True, exchange=mode.split("_")[0],
-                 rows_max_fraction=0.2 if mode == "rows_fallback" else None)
+                 rows_max_fraction=0.2 if mode in ("rows_fallback", "rows_abandon") else None)
     stats = []
     for step in range(1, 4):
         dcol, geo = _lowrank_inputs(rank, step, P, m.flat.numel())
@@ -175,6 +175,8 @@ def _lowrank_worker(rank, world, port, out, mode):
         radii = (torch.rand(P, generator=torch.Generator().manual_seed(9 * rank + step)) * 30).to(torch.int32) * vis
         if mode == "rows_overflow" and step > 1:
             tr._rows_cap = 8                                     # far below the ~45 rows of a view: remainder all-gather
+        if mode == "rows_abandon" and step > 1:
+            tr._rows_skip, tr._rows_cap = 0, 8                   # a speculative collective on a step that turns out too dense
         ex = tr.exchange_rows if mode.startswith("rows") else tr.exchange_lowrank
         nsum, vcount, rmax = ex(dcol / world, gnorm, vis, radii)
         tr.wait_stats()
@@ -203,12 +205,14 @@ def _run_lowrank(mode, world=2):
 def test_rows_exchange_two_ranks_equals_lowrank_bit_for_bit():
     """The sparse form ships only the non-zero gradient rows and adds them in view order: for two ranks that is the same
     sum as the low-rank form's all-reduce (0 + a + b), so parameters, moments and statistics must agree BIT FOR BIT — also
-    when a step is too dense for the sparse form and falls back (rows_max_fraction 0.2 with 70 % non-zero rows), and when
-    the speculative size of the row collective was too small and a second all-gather carries the remainder."""
+    when a step is too dense for the sparse form and falls back (rows_max_fraction 0.2 with 70 % non-zero rows), when
+    the speculative size of the row collective was too small and a second all-gather carries the remainder, and when a
+    speculatively sized collective is abandoned because the step turned out too dense (its size is capped at rows_limit)."""
     import numpy as np
     ref = _run_lowrank("lowrank")
     for mode, used in (("rows", {"rows": 3, "lowrank": 0}), ("rows_fallback", {"rows": 0, "lowrank": 3}),
-                       ("rows_overflow", {"rows": 3, "lowrank": 0, "rows_overflow": 2})):
+                       ("rows_overflow", {"rows": 3, "lowrank": 0, "rows_overflow": 2}),
+                       ("rows_abandon", {"rows": 0, "lowrank": 3, "rows_abandoned": 2})):
         res = _run_lowrank(mode)
         for rank in (0, 1):
             assert res[rank][6] == used

@@ -31,6 +31,34 @@ namespace {
 #define LOG2E 1.4426950408889634f
 #define W3D_FLASH_LABELS 4     // FlashSplat: labels per tile that take the LDS row-sum path (more: one wave reduction per label and entry)
 #define W3D_ACC_SLOTS 128      // backward: (entry of a 32-entry half batch) x (16-lane row) slots per accumulated value
+#ifndef W3D_VCC_SELECT
+#define W3D_VCC_SELECT 1       // per-lane selects of the blend loops through VCC: v_cndmask_b32_e32 issues at full rate, the e64 form
+                               // (mask in an SGPR pair — what the compiler picks when several lane masks are alive) at half rate
+                               // (profiles/r02/valu_microbench.json); one s_mov_b64 vcc on the scalar pipe feeds 2-3 selects
+#endif
+
+// Selects with ONE lane mask in their VCC form (see W3D_VCC_SELECT).  fwd_apply: w = m ? aT : 0, T = m ? T_new : T,
+// last = m ? idx : last;  kill_where: x = m ? v : x;  bwd_mask2: a = m ? a : 0, g = m ? g : 0.
+__device__ __forceinline__ float fwd_apply(uint64_t m, float aT, float &T, float T_new, uint32_t &last, uint32_t idx) {
+    float w;
+    asm volatile("s_mov_b64 vcc, %3\n\t"
+                 "v_cndmask_b32_e32 %0, 0, %4, vcc\n\t"
+                 "v_cndmask_b32_e32 %1, %1, %5, vcc\n\t"
+                 "v_cndmask_b32_e32 %2, %2, %6, vcc"
+                 : "=v"(w), "+v"(T), "+v"(last) : "s"(m), "v"(aT), "v"(T_new), "v"(idx) : "vcc");
+    return w;
+}
+__device__ __forceinline__ void kill_where(uint64_t m, float &x, float v) {
+    asm volatile("s_mov_b64 vcc, %1\n\t"
+                 "v_cndmask_b32_e32 %0, %0, %2, vcc"
+                 : "+v"(x) : "s"(m), "v"(v) : "vcc");
+}
+__device__ __forceinline__ void bwd_mask2(uint64_t m, float &a, float &g) {
+    asm volatile("s_mov_b64 vcc, %2\n\t"
+                 "v_cndmask_b32_e32 %0, 0, %0, vcc\n\t"
+                 "v_cndmask_b32_e32 %1, 0, %1, vcc"
+                 : "+v"(a), "+v"(g) : "s"(m) : "vcc");
+}
 
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_mov(float src) {
@@ -139,8 +167,11 @@ __device__ __forceinline__ uint32_t stage_entries(StagedLDS &s, uint32_t lane, u
 }
 
 // ------------------------------------------------------------------------------ forward
+#ifndef W3D_FWD_OCC
+#define W3D_FWD_OCC 6     // waves per SIMD the forward is compiled for (80 VGPRs as it falls out; 8 would need <= 64)
+#endif
 template <bool FLASH>
-__global__ void __launch_bounds__(64 * W3D_RW)
+__global__ void __launch_bounds__(64 * W3D_RW, FLASH ? 4 : W3D_FWD_OCC)
 render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restrict__ tile_start,
                   const uint32_t *__restrict__ point_list, const float2 *__restrict__ xy,
                   const float4 *__restrict__ conic_op, const float4 *__restrict__ rgbd, const float *__restrict__ bg,
@@ -244,21 +275,32 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 if (!(qm & (1u << k))) continue;
                 const float dx = ea.x - pxf[k], dy = ea.y - pyf[k];
                 const float power = fmaf(ed.z * dy, dy, fmaf(ed.y, dy, ed.x * dx) * dx);      // log2 domain
-                // (two ballots of plain compares ANDed as scalars: the ballot of a compound predicate is materialised in a VGPR)
-                if ((w3d_ballot(power <= hi[k]) & w3d_ballot(power >= ea.z)) == 0ull) continue;   // whole quadrant untouched
-                const bool cand = power <= hi[k] && power >= ea.z;
+                // (ballots of plain compares ANDed as scalars: the ballot of a compound predicate is materialised in a VGPR)
+                const uint64_t m_cand = w3d_ballot(power <= hi[k]) & w3d_ballot(power >= ea.z);
+                if (m_cand == 0ull) continue;                                                      // whole quadrant untouched
                 float alpha = ed.w * __builtin_amdgcn_exp2f(power);
                 alpha = fminf(0.99f, alpha);
                 const float test_T = Tr[k] * (1.f - alpha);
+#if W3D_VCC_SELECT
+                // ok = cand && alpha >= 1/255; stop = ok && T' < 1e-4 (the entry is NOT applied and the pixel is done);
+                // apply = ok && !stop — as lane masks on the scalar pipe, the selects in their full-rate VCC form
+                const uint64_t m_ok = m_cand & w3d_ballot(alpha >= (1.0f / 255.0f));
+                const uint64_t m_small = w3d_ballot(test_T < 0.0001f);
+                const float w = fwd_apply(m_ok & ~m_small, alpha * Tr[k], Tr[k], test_T, last[k], contributor);
+                kill_where(m_ok & m_small, hi[k], -INFINITY);
+                const bool apply = FLASH && w != 0.f;           // (alpha >= 1/255 and T >= 1e-4: an applied weight is never 0)
+#else
+                const bool cand = power <= hi[k] && power >= ea.z;
                 const bool ok = cand && alpha >= (1.0f / 255.0f);
                 const bool stop = ok && test_T < 0.0001f;
                 const bool apply = ok && !stop;
                 const float w = apply ? alpha * Tr[k] : 0.f;
-                C0[k] += ec.x * w; C1[k] += ec.y * w; C2[k] += ec.z * w;
-                D[k] += ec.w * w; A[k] += w;
                 Tr[k] = apply ? test_T : Tr[k];
                 last[k] = apply ? contributor : last[k];
                 hi[k] = stop ? -INFINITY : hi[k];
+#endif
+                C0[k] += ec.x * w; C1[k] += ec.y * w; C2[k] += ec.z * w;
+                D[k] += ec.w * w; A[k] += w;
                 if (FLASH) { wk[k] = w; napplied[k] += apply ? 1 : 0; any_applied = any_applied || apply; }
             }
             if (FLASH && gt_mask && used_count) {
@@ -536,8 +578,14 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                     // Branch-free per lane: a lane that does not blend this Gaussian runs the same recurrences
                     // with alpha = G = 0, which leaves T and the suffix accumulators untouched and adds zeros.
                     const bool ok = cand && araw >= (1.0f / 255.0f);    // (its lane mask is mk, already in an SGPR pair)
+#if W3D_VCC_SELECT
+                    float alpha = araw, G = Graw;
+                    (void)ok;
+                    bwd_mask2(mk, alpha, G);
+#else
                     const float alpha = ok ? araw : 0.f;
                     const float G = ok ? Graw : 0.f;
+#endif
                     const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                     const float Tn = Tr[k] * inv;
                     const float dch = alpha * Tn;

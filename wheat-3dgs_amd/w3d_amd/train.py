@@ -101,6 +101,7 @@ class Trainer:
         self._rows_cap = None
         self._rows_skip = 0
         self._rows = None                     # fused_step.GatheredRows of the current iteration (GPU path of exchange_rows)
+        self._rows_bufs = None                # persistent per-step buffers of exchange_rows (index arrays, pinned counts)
         self.exchange_used = {"rows": 0, "lowrank": 0}        # steps per form actually taken (rows mode decides per step)
         self.fused_adam = bool(fused_adam)
         if exchange == "rows" and self.world > 32:
@@ -232,8 +233,15 @@ class Trainer:
         counts = torch.empty(self.world, dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(counts, count)
         pinned = ev = None
+        bufs = self._rows_bufs
+        if counts.is_cuda and (bufs is None or bufs["P"] != P or bufs["dev"] != dev):
+            # index arrays and the pinned landing place of the counts live as long as P does (resized after a densification)
+            bufs = self._rows_bufs = {"P": P, "dev": dev, "pinned": torch.empty(self.world, dtype=torch.int32, pin_memory=True),
+                                      "viewmask": torch.empty(max(P, 1), dtype=torch.int32, device=dev),
+                                      "slots": torch.empty(self.world * max(P, 1), dtype=torch.int32, device=dev)}
+        index_bufs = None if bufs is None or not counts.is_cuda else (bufs["viewmask"], bufs["slots"])
         if counts.is_cuda:                       # the counts start their way to the host now; whoever needs them waits on ev
-            pinned = torch.empty(self.world, dtype=torch.int32, pin_memory=True)
+            pinned = bufs["pinned"]
             pinned.copy_(counts, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
@@ -262,41 +270,52 @@ class Trainer:
             dist.all_gather_into_tensor(part.view(-1), rows[first:first + n].reshape(-1))
             return part
 
+        def too_dense(hc):
+            # too dense for the sparse form: this step's gradients travel as in exchange_lowrank; the norms, which
+            # would have travelled in the rows, as one more all-reduce.  Decided from the gathered counts: identically on every rank
+            self.last_row_counts = hc
+            self.exchange_used["lowrank"] += 1
+            self._rows_skip = self.ROWS_RETRY
+            self._rows_cap = None
+            ns = None
+            if tracking:
+                ns = grad2d_norm * visible
+                self._stat_work = self._stat_work + (dist.all_reduce(ns, op=dist.ReduceOp.SUM, async_op=True),)
+            self.exchange_lowrank(dcolor, None, None, None, tracking=False)
+            return ns, vcount, rmax
+
         cap = self._rows_cap
+        limit = self.rows_limit(P)
         gathered = None
         if cap is not None:
-            cap = min(cap, max(P, 1))
+            # (never speculate beyond the size at which the sparse form stops paying: a step that turned dense — after a
+            #  densification or an SH degree bump — then costs one wasted collective of at most `limit` rows, not of P)
+            cap = max(1, min(cap, max(P, 1), max(limit, 1)))
             parts = [gather(0, cap)]
             if gpu:
-                gathered = GatheredRows(m, parts[0], counts)      # (indexing kernel enqueued behind the collective)
+                gathered = GatheredRows(m, parts[0], counts, index_bufs)      # (indexing kernel enqueued behind the collective)
             hc = host_counts()                                    # the GPU is busy with the collective meanwhile
             nmax = max(hc)
+            if nmax > limit:
+                self.exchange_used["rows_abandoned"] = self.exchange_used.get("rows_abandoned", 0) + 1
+                return too_dense(hc)
             if nmax > cap:                                        # a view outgrew the guess: the remainder follows
                 parts.append(gather(cap, nmax - cap))
                 self.exchange_used["rows_overflow"] = self.exchange_used.get("rows_overflow", 0) + 1
                 if gpu:
-                    gathered = GatheredRows(m, torch.cat(parts, 1).contiguous(), counts)
+                    gathered = GatheredRows(m, torch.cat(parts, 1).contiguous(), counts, index_bufs)
         else:
             hc = host_counts()                                    # host wait: backward + a world-int collective
             nmax = max(hc)
-            if nmax > self.rows_limit(P):
-                # too dense for the sparse form: this step's gradients travel as in exchange_lowrank; the norms, which
-                # would have travelled in the rows, as one more all-reduce
-                self.last_row_counts = hc
-                self.exchange_used["lowrank"] += 1
-                self._rows_skip = self.ROWS_RETRY
-                if tracking:
-                    nsum = grad2d_norm * visible
-                    self._stat_work = self._stat_work + (dist.all_reduce(nsum, op=dist.ReduceOp.SUM, async_op=True),)
-                self.exchange_lowrank(dcolor, None, None, None, tracking=False)
-                return nsum, vcount, rmax
+            if nmax > limit:
+                return too_dense(hc)
             parts = [gather(0, max(nmax, 1))]
             if gpu:
-                gathered = GatheredRows(m, parts[0], counts)
+                gathered = GatheredRows(m, parts[0], counts, index_bufs)
         self.last_row_counts = hc
         self.exchange_used["rows"] += 1
         # next step's guess — or back to the exact, host-sized form when the views have become too dense for this one
-        self._rows_cap = None if nmax > self.rows_limit(P) or not self.rows_speculate else \
+        self._rows_cap = None if nmax > limit or not self.rows_speculate else \
             min(max(P, 1), (int(1.25 * nmax) + 1024) // 1024 * 1024)
         if gpu:
             # the optimizer kernel reads the rows through the per-Gaussian index (optimizer_step_lowrank -> w3d_rows_adam):
