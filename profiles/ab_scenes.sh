@@ -4,7 +4,7 @@
 # product library and every profiles/_bin/variants/<name>/libw3d_hip.so (profiles/build_variant.sh) time the same models.
 #   usage: profiles/ab_scenes.sh [steps] ["scenes"] [rounds]      -> gpurun_out/ab_scenes.log (one JSON line per lib, scene, round)
 cd "$(dirname "$0")/.."
-STEPS=${1:-60}; SCENES=${2:-"untrained trained densified"}; ROUNDS=${3:-2}
+STEPS=${1:-60}; SCENES=${2:-"untrained trained densified"}; ROUNDS=${3:-2}; EXTRA=${4:-}     # EXTRA: e.g. --freeze
 mkdir -p gpurun_out
 : > gpurun_out/ab_scenes.log
 for S in $SCENES; do
@@ -15,7 +15,7 @@ for r in $(seq 1 $ROUNDS); do
   for lib in wheat-3dgs_amd/lib/libw3d_hip.so profiles/_bin/variants/*/libw3d_hip.so; do
     [ -f "$lib" ] || continue
     for S in $SCENES; do
-      W3D_HIP_LIB=$lib timeout 300 python3 profiles/scene_step.py --scene $S --steps $STEPS --model-file /tmp/w3d_ab_$S.pt --report 2>/dev/null \
+      W3D_HIP_LIB=$lib timeout 300 python3 profiles/scene_step.py --scene $S --steps $STEPS --model-file /tmp/w3d_ab_$S.pt --report $EXTRA 2>/dev/null \
         | grep '^{' | sed "s#\"lib\": \"[^\"]*\"#\"lib\": \"$(basename $(dirname $lib))\"#" >> gpurun_out/ab_scenes.log
     done
   done

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=40, help="steps before the window (>= 36 so that every camera's walk hint exists)")
     ap.add_argument("--model-file", default=None)
     ap.add_argument("--trained-steps", type=int, default=3000)
+    ap.add_argument("--freeze", action="store_true",
+                    help="with --report: the parameters do NOT change — every iteration is forward + loss + gradient-writing backward "
+                         "(no optimizer step), so variants that alter results are still timed on identical work")
     ap.add_argument("--report", action="store_true",
                     help="instead of the marker window: time --steps steps (bench.StepMeter: probe, timed, per-stage events) and print "
                          "one JSON line {scene, iters_per_s, ms_per_step, stage_ms} — the A/B harness of profiles/ab_scenes.sh")
@@ -74,6 +77,43 @@ def main():
     for _ in range(a.warmup):
         it += 1
         trainer.step(it)
+    if a.report and a.freeze:
+        import ctypes
+        import json
+        import time
+        from w3d_amd import _lib
+        from w3d_amd.fused import l1_ssim_fwd_bwd
+        from w3d_amd.fused_step import backward_raw, finish, render_raw
+        lib = _lib.lib
+        lib.w3d_profile_enable.argtypes = [ctypes.c_char_p]
+        lib.w3d_profile_collect.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
+
+        def one(i):
+            cam = cams[i % len(cams)]
+            with torch.no_grad():
+                pkg = render_raw(cam, model, bg, sync=False)
+                loss, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, 0.2)
+                backward_raw(model, pkg["handle"], dimg)
+                finish(pkg["handle"])
+        for i in range(40):
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            one(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        lib.w3d_profile_enable(b"*")
+        for i in range(36):
+            one(i)
+        torch.cuda.synchronize()
+        lib.w3d_profile_enable(None)
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.w3d_profile_collect(buf, len(buf))
+        st = {ln.split()[0]: round(float(ln.split()[2]) / int(ln.split()[1]), 4) for ln in buf.value.decode().splitlines()}
+        print(json.dumps({"scene": a.scene, "lib": os.environ.get("W3D_HIP_LIB", "product"), "gaussians": model.num_points,
+                          "iters_per_s": round(a.steps / dt, 2), "ms_per_step": round(1e3 * dt / a.steps, 4), "stage_ms": st}))
+        return
     if a.report:
         import json
         meter = bench.StepMeter(trainer, 1, dev)

@@ -265,6 +265,33 @@ def test_duplicate_gaussians_tie_order():
     check_images(out, ref, "[dups, culled] ")
 
 
+@pytest.mark.parametrize("depth_span,P", [("narrow", 150_000), ("wide", 150_000), ("wide", 9_000)])
+def test_depth_sort_paths_and_tie_order_at_size(depth_span, P):
+    """The depth sort (w3d_binning.hip: 8-bit digits; three passes when the upper halves of the view's depth keys take at
+    most 256 consecutive values, else four) on enough Gaussians that every wave of the sort holds keys, for both digit rules:
+    `narrow` — the benchmark's overhead cameras, depths within one octave; `wide` — the slab stretched 30 units away from the
+    cameras, depths 2 ... 33 (four octaves: the fourth pass runs).  A quarter of the Gaussians are exact duplicates of earlier
+    ones (densify_and_clone's output), so equal keys must keep ascending index order.  Per-tile ranges and lists: bit-identical
+    to the oracle's (stable order by (depth bits, index))."""
+    from w3d_amd.synth import make_scene, make_cameras
+    W, H = 320, 240
+    sc = make_scene(P, seed=23, scale_mean=0.004)
+    if depth_span == "wide":
+        sc.xyz[:, 2] = 0.6 - 30.0 * torch.rand(P, generator=torch.Generator().manual_seed(5))
+    cam, bg = make_cameras(6, W, H)[2], (0.0, 0.0, 0.0)
+    d = view_inputs(sc, cam)
+    d = {k: (None if v is None else torch.cat([v, v[: P // 3]], 0).contiguous()) for k, v in d.items()}
+    o = make_oracle(cam, bg, nthreads=8)
+    ref = o.forward(**np_inputs(d))
+    depth = o.geom()["depth"][ref["radii"] > 0]
+    octaves = float(np.log2(depth.max() / depth.min()))
+    assert (octaves > 2.5) if depth_span == "wide" else (octaves < 1.0), octaves
+    out, _ = run_hip(d, cam, bg, tile_cull=False)
+    check_integers(out, o, ref)
+    check_images(out, ref, f"[sort {depth_span}] ")
+    o.free()
+
+
 @pytest.mark.parametrize("num_obj", [1, 5])
 def test_flashsplat_parity(num_obj):
     from flashsplat_rasterization import GaussianRasterizer

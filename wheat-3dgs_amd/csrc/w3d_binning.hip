@@ -209,8 +209,10 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
     };
     // software pipeline: the (key, id) pairs of the next two batches and the rect line of the next batch are in flight while
     // the current batch is ranked
-    uint32_t k1 = (beg + lane < end) ? keys_in[beg + lane] : 0u, v1 = (beg + lane < end) ? vals_in[beg + lane] : 0u;
-    uint32_t k2 = (beg + 64 + lane < end) ? keys_in[beg + 64 + lane] : 0u, v2 = (beg + 64 + lane < end) ? vals_in[beg + 64 + lane] : 0u;
+    // (first pass: the value of key i is i — the preprocess writes the Gaussians in index order — so no value array is read)
+    auto val_at = [&](uint32_t i) -> uint32_t { return drop_invalid ? i : vals_in[i]; };
+    uint32_t k1 = (beg + lane < end) ? keys_in[beg + lane] : 0u, v1 = (beg + lane < end) ? val_at(beg + lane) : 0u;
+    uint32_t k2 = (beg + 64 + lane < end) ? keys_in[beg + 64 + lane] : 0u, v2 = (beg + 64 + lane < end) ? val_at(beg + 64 + lane) : 0u;
     uint4 g1 = make_uint4(0u, 0u, 0u, 0u);
     if (CAN_FINAL && fin && beg + lane < end) g1 = gather(v1);
     for (uint32_t base = beg; base < end; base += 64) {
@@ -220,7 +222,7 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
         const bool valid = i < end && !(drop_invalid && key == W3D_INVALID_KEY);
         k1 = k2; v1 = v2;
         k2 = 0u; v2 = 0u;
-        if (i + 128 < end) { k2 = keys_in[i + 128]; v2 = vals_in[i + 128]; }
+        if (i + 128 < end) { k2 = keys_in[i + 128]; v2 = val_at(i + 128); }
         if (CAN_FINAL && fin && i + 64 < end) g1 = gather(v1);
         const uint32_t d = (three ? (key >> 16) - kmin_hi : (key >> shift)) & (W3D_RADIX_BINS - 1u);
         // lanes holding the same digit (stable rank = number of such lanes below me)

@@ -31,6 +31,13 @@ namespace {
 #define LOG2E 1.4426950408889634f
 #define W3D_FLASH_LABELS 4     // FlashSplat: labels per tile that take the LDS row-sum path (more: one wave reduction per label and entry)
 #define W3D_ACC_SLOTS 128      // backward: (entry of a 32-entry half batch) x (16-lane row) slots per accumulated value
+#ifndef W3D_ACC_PITCH
+#define W3D_ACC_PITCH 132      // ... and the distance (floats) between two values' slot arrays.  With 128 every value's array starts
+                               // on the same LDS bank: the 16 storing lanes of an entry (4 values x 4 rows) hit 4 banks 4-way, and
+                               // the flush's 16 value-lanes read one bank group 16-way — SQ_LDS_BANK_CONFLICT = 12 % of the
+                               // kernel's cycles on the densified scene (profiles/r04/lds_counters.txt).  132 (16-B aligned for
+                               // the flush's b128 reads) spreads the values over banks 4k mod 32.
+#endif
 #ifndef W3D_VCC_SELECT
 #define W3D_VCC_SELECT 1       // per-lane selects of the blend loops through VCC: v_cndmask_b32_e32 issues at full rate, the e64 form
                                // (mask in an SGPR pair — what the compiler picks when several lane masks are alive) at half rate
@@ -45,7 +52,7 @@ __device__ __forceinline__ float fwd_apply(uint64_t m, float aT, float &T, float
                  "v_cndmask_b32_e32 %0, 0, %4, vcc\n\t"
                  "v_cndmask_b32_e32 %1, %1, %5, vcc\n\t"
                  "v_cndmask_b32_e32 %2, %2, %6, vcc"
-                 : "=v"(w), "+v"(T), "+v"(last) : "s"(m), "v"(aT), "v"(T_new), "v"(idx) : "vcc");
+                 : "=&v"(w), "+v"(T), "+v"(last) : "s"(m), "v"(aT), "v"(T_new), "v"(idx) : "vcc");   // (w is written before T_new / idx are read)
     return w;
 }
 __device__ __forceinline__ void kill_where(uint64_t m, float &x, float v) {
@@ -435,7 +442,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     // row sums of the current half batch: acc[value][entry * 4 + row].  Every (entry, row) slot is written exactly once
     // per half batch by that row's leader lane — plain stores, no LDS atomics (measured on gfx950: a ds_add_f32 of four lanes
     // on one address occupies the CU's LDS for ~15 cycles, nine of them per entry cost more than the entry's arithmetic)
-    __shared__ __align__(16) float acc_all[W3D_RW][NV * W3D_ACC_SLOTS];
+    __shared__ __align__(16) float acc_all[W3D_RW][NV * W3D_ACC_PITCH];
     uint32_t tile;
     if (!wave_to_tile(T, tile, tile_order)) return;
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -487,9 +494,9 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     // three values its bank ended up with
     const uint32_t l4 = (lane >> 2) & 3u, row = lane >> 4;
     const bool storer = (lane & 3u) == 0u;
-    const uint32_t offA = ((l4 >> 1) + 5u * (l4 & 1u)) * W3D_ACC_SLOTS + row;      // values 0, 5, 1, 6
-    const uint32_t offB = offA + 2u * W3D_ACC_SLOTS;                               // values 2, 7, 3, 8
-    const uint32_t offC = (4u + 5u * (l4 & 1u)) * W3D_ACC_SLOTS + row;             // values 4, 9
+    const uint32_t offA = ((l4 >> 1) + 5u * (l4 & 1u)) * W3D_ACC_PITCH + row;      // values 0, 5, 1, 6
+    const uint32_t offB = offA + 2u * W3D_ACC_PITCH;                               // values 2, 7, 3, 8
+    const uint32_t offC = (4u + 5u * (l4 & 1u)) * W3D_ACC_PITCH + row;             // values 4, 9
     const bool storeC = storer && (l4 == 0u || (HAS_DA && l4 == 1u));
     // software pipeline over the 64-entry batches (walked back to front): while batch b is consumed from
     // LDS, the records of batch b-1 are already in flight to registers and the ids of batch b-2 to `ids`.
@@ -661,7 +668,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 for (uint32_t pass = 0; pass < 8; pass++) {
                     const uint32_t e = pass * 4u + sub;
                     if (((touched >> e) & 1u) && k < (uint32_t)NV) {
-                        const float4 r4v = *reinterpret_cast<const float4 *>(&acc[k * W3D_ACC_SLOTS + e * 4u]);
+                        const float4 r4v = *reinterpret_cast<const float4 *>(&acc[k * W3D_ACC_PITCH + e * 4u]);
                         const float sk = (r4v.x + r4v.y) + (r4v.z + r4v.w);
                         const float so = dpp_mov<0xB1>(sk);            // k = 0 <-> k = 1 exchange their sums (S1, S2)
                         const float4 co = s.b[jlo + e];
@@ -712,12 +719,16 @@ det_gather_kernel(int P, int gx, const uint2 *__restrict__ rect, const uint4 *__
                   uint32_t inst_cap, float *__restrict__ grad2d) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= P) return;
-    const uint2 rc = rect[g];
+    uint2 rc = rect[g];
     if (!(rc.x | rc.y)) return;
+    // (tile_cull: the lists were built from the rect of the 16-B rect / mask record, which the preprocess may have shrunk to
+    //  the footprint's own extent; the mask bits count the tiles of THAT rect)
+    uint4 rm = make_uint4(0u, 0u, 0u, 0u);
+    if (cull) { rm = rect_mask[g]; rc = make_uint2(rm.x, rm.y); }
     const uint32_t minx = rc.x & 0xFFFFu, miny = rc.x >> 16, maxx = rc.y & 0xFFFFu, maxy = rc.y >> 16;
     const uint32_t w = maxx - minx, nt = w * (maxy - miny);
     uint64_t mask = ~0ull;
-    if (cull && nt <= 64u) { const uint4 rm = rect_mask[g]; mask = (uint64_t)rm.z | ((uint64_t)rm.w << 32); }
+    if (cull && nt <= 64u) mask = (uint64_t)rm.z | ((uint64_t)rm.w << 32);
     const uint32_t cap = min(counters[3], inst_cap);
     const uint32_t mykey = __float_as_uint(rgbd[g].w);
     float sum[10];
