@@ -108,7 +108,7 @@ typedef struct w3d_view {
 
 /* Version of this ABI: major * 100 + minor.  The major number changes whenever a struct of this header changes its layout or
  * an entry point its signature; a binding must refuse a library whose major number differs from the header it mirrors. */
-#define W3D_ABI_VERSION 200
+#define W3D_ABI_VERSION 201
 int w3d_version(void);
 const char *w3d_last_error(void);
 
@@ -328,7 +328,9 @@ int w3d_adam_step(uint64_t n, float *param, float *grad, float *exp_avg, float *
 /* Next-row N3: one-pass row compaction of the flat parameter buffer and both Adam moments for densify / prune
  * <- scene/gaussian_model.py:332-397 (_prune_optimizer, cat_tensors_to_optimizer, densification_postfix,
  *    prune_points), called three to four times per densify_and_prune :441-455.
- * The flat buffers are block-wise: block b holds P rows of block_dims_host[b] floats, blocks back to back.
+ * The flat buffers are block-wise: block b holds P rows of block_dims_host[b] floats; the blocks lie back to back except that
+ * every block STARTS on a multiple of 4 floats (16 B; at most 3 floats of padding in front of a block, never read or written
+ * here) — so that the streaming kernels find every block 16-B aligned whatever P is (ABI 201; ABI 200 packed them tightly).
  * Output row r takes source row src_rows[r] (< P_old).  Rows [0, n_keep) keep their Adam moments; rows
  * [n_keep, P_new) are new (clones, then split children from n_child0 on) and get zero moments; split children
  * take their xyz_block / scaling_block rows from child_xyz / child_scaling ((P_new - n_child0, 3) each).

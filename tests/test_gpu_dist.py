@@ -130,7 +130,7 @@ def test_densifying_training_under_exchange(one_rank_group, mode):
             sizes.append(m.num_points)
         tr.gather_moments()
         assert torch.isfinite(m.flat).all() and all(np.isfinite(losses))
-        assert m.flat.numel() == 59 * m.num_points and m.optimizer.exp_avg.numel() == m.flat.numel()
+        assert 59 * m.num_points <= m.flat.numel() <= 59 * m.num_points + 15 and m.optimizer.exp_avg.numel() == m.flat.numel()
         results[name] = (sizes, losses)
     (s0, l0), (s1, l1) = results["single"], results[mode]
     assert len(set(s0)) > 3
@@ -181,7 +181,7 @@ def test_sh_adam_lowrank_kernel_three_views_against_torch(P, deg):
 def test_gradient_row_kernels_against_torch(P, frac):
     """w3d_pack_gradient_rows / w3d_apply_gradient_rows (the sparse exchange's two kernels): the packed rows are exactly the
     non-zero rows (each once, any order, -0.0 counts as zero), and applying three "views" in order reproduces the dense
-    sums bit for bit — against the CPU branch of the same functions and plain torch.  P = 10007: no block is 16-B aligned."""
+    sums bit for bit — against the CPU branch of the same functions and plain torch.  P = 10007: odd row counts, padded blocks."""
     from w3d_amd.fused_step import GEO_BLOCKS, ROW_FLOATS, apply_gradient_rows, pack_gradient_rows
     from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
     from w3d_amd.synth import make_scene
@@ -253,7 +253,9 @@ def test_gradient_row_kernels_against_torch(P, frac):
         want_n += ref["gnorm"]
         assert torch.equal(d_all[dev][v].cpu(), ref["dcol"] + 0.0)
     for got in (mg.flat_grad.cpu(), mc.flat_grad):
-        assert torch.equal(got[a:b], want_geo[a:b] + 0.0)
+        for n in GEO_BLOCKS:                             # (block by block: the <= 3 padding floats in front of a block are nobody's)
+            lo, hi = sl[n]
+            assert torch.equal(got[lo:hi], want_geo[lo:hi] + 0.0), n
         assert float(got[:a].abs().max() if a else 0) == 0 and float(got[b:].abs().max()) == 0      # SH blocks untouched
     assert torch.equal(nsum[dev].cpu(), want_n) and torch.equal(nsum["cpu"], want_n)
 

@@ -549,8 +549,8 @@ def attributed_gradient_check(name, m, cam_dev, gc, ref, gref, want, final_T_ref
             # measured: 0.2-0.9 x the spread on xyz / SH / scaling / rotation, 1.6 x on opacity (profiles/r04/fullsize_parity.jsonl)
             # (`worst32_explained` is recorded, not asserted: where HIP's tail is far below the spread — SH, xyz — its 32 worst
             #  are 1e-3-sized and need no explanation; the maximum is held to the spread's maximum instead)
-            assert st["max"] <= max(1e-2, probe_factor * pr["max"]), f"{tag}grad {k}: worst Gaussian {st['max']:.3g} vs spread {pr['max']:.3g}"
             pr = rec["probe_blocks_unmarked"][k]
+            assert st["max"] <= max(1e-2, probe_factor * pr["max"]), f"{tag}grad {k}: worst Gaussian {st['max']:.3g} vs spread {pr['max']:.3g}"
             assert st["p99"] <= max(1e-4, probe_factor * pr["p99"]) and st["p999"] <= max(1e-4, probe_factor * pr["p999"]), \
                 f"{tag}grad {k} over the Gaussians without a flipped pixel: {st}; oracle's own rounding spread: {pr}"
             assert st["beyond_1e4"] <= probe_factor * pr["beyond_1e4"] + 16, f"{tag}grad {k}: {st} vs spread {pr}"

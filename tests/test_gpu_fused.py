@@ -235,7 +235,7 @@ def test_training_with_densification_prune_and_opacity_reset():
         losses.append(float(tr.step(it)))
         sizes.append(m.num_points)
     assert len(set(sizes)) > 3                       # P changed several times (clone/split/prune)
-    assert m.flat.numel() == 59 * m.num_points and m.optimizer.exp_avg.numel() == m.flat.numel()
+    assert 59 * m.num_points <= m.flat.numel() <= 59 * m.num_points + 15 and m.optimizer.exp_avg.numel() == m.flat.numel()
     assert m.xyz_gradient_accum.shape[0] == m.num_points and m.max_radii2D.shape[0] == m.num_points
     assert torch.isfinite(m.flat).all() and all(np.isfinite(losses))
     assert min(losses[30:44]) < np.mean(losses[:5])        # learning happens between the opacity resets (45, 90)

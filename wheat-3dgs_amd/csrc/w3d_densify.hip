@@ -30,7 +30,13 @@ densify_compact_kernel(DensifyBlocks B, uint64_t P_old, uint64_t P_new, uint64_t
     const int b = blockIdx.y;
     const uint32_t dim = (uint32_t)B.dim[b];
     uint64_t off_old = 0, off_new = 0;
-    for (int i = 0; i < b; i++) { off_old += P_old * (uint64_t)B.dim[i]; off_new += P_new * (uint64_t)B.dim[i]; }
+    // (every block starts on a multiple of 4 floats: include/w3d.h, w3d_densify_compact)
+    for (int i = 0; i < b; i++) {
+        off_old = ((off_old + 3ull) & ~3ull) + P_old * (uint64_t)B.dim[i];
+        off_new = ((off_new + 3ull) & ~3ull) + P_new * (uint64_t)B.dim[i];
+    }
+    off_old = (off_old + 3ull) & ~3ull;
+    off_new = (off_new + 3ull) & ~3ull;
     const uint64_t n = P_new * dim;
     for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t row = e / dim;

@@ -21,6 +21,23 @@ from torch import nn
 # view-parallel exchange all-reduces exactly that span of the gradient bucket in one collective), then the SH blocks.
 BLOCKS = (("xyz", (3,)), ("opacity", (1,)), ("scaling", (3,)), ("rotation", (4,)), ("f_dc", (1, 3)), ("f_rest", (15, 3)))
 FLOATS_PER_GAUSSIAN = sum(int(np.prod(s)) for _, s in BLOCKS)  # 59
+BLOCK_ALIGN = 4        # every block of the flat buffers starts on a multiple of 4 floats (16 B)
+
+
+def flat_layout(P):
+    """name -> (start, stop) element offsets of each parameter block inside the flat buffers, and the total length.
+    Blocks lie back to back, except that every block STARTS on a 16-byte boundary (round 4): the kernels stream the blocks
+    with 16-B vector accesses and fall back to dword paths when a block's base is misaligned — with back-to-back blocks that
+    was the case whenever P was not a multiple of 4, i.e. after three densifications out of four (the fused backward + Adam
+    kernel took 0.72 instead of 0.55 ms at 1.9 M Gaussians).  At most 3 floats of padding per block; they stay zero.
+    The same rule is applied by w3d_densify_compact (include/w3d.h)."""
+    off, out = 0, {}
+    for name, shape in BLOCKS:
+        off = (off + BLOCK_ALIGN - 1) // BLOCK_ALIGN * BLOCK_ALIGN
+        n = P * int(np.prod(shape))
+        out[name] = (off, off + n)
+        off += n
+    return out, off
 
 
 def inverse_sigmoid(x):
@@ -99,7 +116,7 @@ class GaussianModel:
     def _bind(self, blocks: dict):
         """(Re)build the flat buffers from a dict name -> tensor (P, *shape)."""
         P = blocks["xyz"].shape[0]
-        n = P * FLOATS_PER_GAUSSIAN
+        layout, n = flat_layout(P)
         # storage padded to a multiple of 256 elements: every world size that divides 256 (1, 2, 4, 8, ...) shards it
         # evenly for the reduce-scatter / all-gather exchange (train.py checks) without repacking
         n_pad = (n + 255) // 256 * 256
@@ -109,15 +126,13 @@ class GaussianModel:
         self.flat = self.flat_store[:n]
         self.flat_grad = self.flat_grad_store[:n]
         self._p = {}
-        off = 0
         for name, shape in BLOCKS:
-            n = P * int(np.prod(shape))
-            view = self.flat[off:off + n].view(P, *shape)
+            a, b = layout[name]
+            view = self.flat[a:b].view(P, *shape)
             view.copy_(blocks[name].reshape(P, *shape))
             p = nn.Parameter(view, requires_grad=True)
-            p.grad = self.flat_grad[off:off + n].view(P, *shape)
+            p.grad = self.flat_grad[a:b].view(P, *shape)
             self._p[name] = p
-            off += n
 
     def grad_view(self, name):
         """The block of the flat gradient bucket that belongs to parameter `name`, shaped like it (whether or not the
@@ -131,13 +146,8 @@ class GaussianModel:
             p.grad = self.grad_view(name)
 
     def block_slices(self):
-        """name -> (start, stop) element offsets of each block inside the flat buffers."""
-        P, off, out = self.num_points, 0, {}
-        for name, shape in BLOCKS:
-            n = P * int(np.prod(shape))
-            out[name] = (off, off + n)
-            off += n
-        return out
+        """name -> (start, stop) element offsets of each block inside the flat buffers (flat_layout)."""
+        return flat_layout(self.num_points)[0]
 
     @property
     def num_points(self):
@@ -278,16 +288,14 @@ class GaussianModel:
         .grad None, as the reference's replaced parameters do (scene/gaussian_model.py:340-397 builds new nn.Parameters
         in _prune_optimizer / cat_tensors_to_optimizer): the `optimizer.step()` that follows a densification in the
         reference's loop (train_vanilla_3dgs.py:105-115) therefore skips them, and so does FlatAdam.step()."""
-        n = P * FLOATS_PER_GAUSSIAN
+        layout, n = flat_layout(P)
         self.flat_store, self.flat_grad_store = flat_store, flat_grad_store
         self.flat, self.flat_grad = flat_store[:n], flat_grad_store[:n]
         self._p = {}
         self._bucket_claimed = False
-        off = 0
         for name, shape in BLOCKS:
-            k = P * int(np.prod(shape))
-            self._p[name] = nn.Parameter(self.flat[off:off + k].view(P, *shape), requires_grad=True)
-            off += k
+            a, b = layout[name]
+            self._p[name] = nn.Parameter(self.flat[a:b].view(P, *shape), requires_grad=True)
 
     def _compact(self, src, n_keep, n_child0=None, child_xyz=None, child_scaling=None, reset_stats=True):
         """The single resize path.  New row r = old row src[r]; rows >= n_keep are new points
@@ -296,7 +304,8 @@ class GaussianModel:
         csrc/w3d_densify.hip on the GPU (torch index_select on the CPU, for the host-logic tests)."""
         P_old, P_new = self.num_points, int(src.numel())
         n_child0 = P_new if n_child0 is None else int(n_child0)
-        n = P_new * FLOATS_PER_GAUSSIAN
+        layout_old, layout_new = flat_layout(P_old)[0], flat_layout(P_new)[0]
+        n = flat_layout(P_new)[1]
         n_pad = (n + 255) // 256 * 256
         opt = self.optimizer
         # Buffers come from a two-generation pool with 25 % head room: a fresh multi-GB hipMalloc costs 100+ ms,
@@ -312,6 +321,15 @@ class GaussianModel:
         full = {"store": take("store")}
         new_store = full["store"][:n_pad]
         new_store[n:].zero_()
+
+        def zero_padding(buf):                           # (the <= 3 padding floats in front of a block stay zero)
+            prev_end = 0
+            for name, _ in BLOCKS:
+                a, b = layout_new[name]
+                if a > prev_end:
+                    buf[prev_end:a].zero_()
+                prev_end = b
+        zero_padding(new_store)
         g_full = cur.get("grad")
         full["grad"] = g_full if g_full is not None and g_full.numel() >= n_pad else take("grad")
         new_grad = full["grad"][:n_pad]
@@ -320,6 +338,8 @@ class GaussianModel:
         if opt is not None:
             full["m"], full["v"] = take("m"), take("v")
             m_new, v_new = full["m"][:n], full["v"][:n]
+            zero_padding(m_new)
+            zero_padding(v_new)
         dims = [int(np.prod(shape)) for _, shape in BLOCKS]
         names = [name for name, _ in BLOCKS]
         if self.flat.is_cuda:
@@ -329,8 +349,9 @@ class GaussianModel:
                             new_store, m_new, v_new, child_xyz, child_scaling)
         else:
             src64 = src.to(torch.int64)
-            off_o = off_n = 0
             for name, d in zip(names, dims):
+                off_o, off_n = layout_old[name][0], layout_new[name][0]
+
                 def rows(buf):
                     return buf[off_o:off_o + P_old * d].view(P_old, d).index_select(0, src64)
                 blk = rows(self.flat.detach())
@@ -344,8 +365,6 @@ class GaussianModel:
                         mb = rows(old)
                         mb[n_keep:] = 0
                         new_[off_n:off_n + P_new * d] = mb.reshape(-1)
-                off_o += P_old * d
-                off_n += P_new * d
         src64 = src.to(torch.int64)
         self._which_object = self._which_object.index_select(0, src64)
         stats = None if reset_stats else (self.xyz_gradient_accum.index_select(0, src64), self.denom.index_select(0, src64),
