@@ -360,6 +360,9 @@ int w3d_profile_collect(char *out, uint64_t cap);
 
 /* Debug/inspection: copies of internal per-tile ranges (T,2) uint32 laid out as [start,end). */
 int w3d_debug_tile_ranges(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *ranges_out, w3d_stream_t stream);
+/* Debug/inspection: the per-Gaussian 16-B rect / tile-mask records of the forward (P,4) uint32 {rect lo, rect hi, mask lo, mask hi}
+ * (tile units: lo = minx | miny << 16, hi = maxx | maxy << 16; written only when view->tile_cull was set). */
+int w3d_debug_tile_rects(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *rects_out, w3d_stream_t stream);
 /* Debug/inspection of the per-pixel state kept for backward: final_T (H,W) f32, n_contrib (H,W) u32. */
 int w3d_debug_pixel_state(int32_t H, int32_t W, int32_t P, const void *state, float *final_T_out,
                           uint32_t *n_contrib_out, w3d_stream_t stream);

@@ -54,7 +54,24 @@ def main():
         op = torch.sigmoid(model._opacity.detach().reshape(-1))
         hist = {str(k): int(((nt > lo) & (nt <= hi)).sum()) for k, (lo, hi) in
                 {"1-4": (0, 4), "5-16": (4, 16), "17-64": (16, 64), "65-256": (64, 256), "257-1024": (256, 1024), ">1024": (1024, 1e9)}.items()}
-        out.append({"camera": ci, "gaussians": model.num_points, "visible": int(vis.sum()),
+        # what the forward actually binned: the (possibly shrunk) rect + 64-bit mask of every Gaussian
+        from w3d_amd.rasterizer import debug_tile_rects
+        tr = debug_tile_rects(pkg["handle"]).to(torch.int64) & 0xFFFFFFFF
+        w = (tr[:, 1] & 0xFFFF) - (tr[:, 0] & 0xFFFF)
+        h = (tr[:, 1] >> 16) - (tr[:, 0] >> 16)
+        nt2 = (w * h) * vis
+        bits = torch.zeros_like(nt2)
+        for word in (tr[:, 2], tr[:, 3]):
+            x = word.clone()
+            for _ in range(32):
+                bits += x & 1
+                x >>= 1
+        small = nt2 <= 64
+        binned = {"entries_from_masked_rects_le_64": int((bits * small * vis).sum()), "entries_from_whole_rects_over_64": int(nt2[~small].sum()),
+                  "gaussians_with_binned_rect_over_64": int((~small & vis).sum()),
+                  "over_64_histogram": {"65-128": int(((nt2 > 64) & (nt2 <= 128)).sum()), "129-256": int(((nt2 > 128) & (nt2 <= 256)).sum()),
+                                        "257-1024": int(((nt2 > 256) & (nt2 <= 1024)).sum()), ">1024": int((nt2 > 1024).sum())}}
+        out.append({"camera": ci, "binned": binned, "gaussians": model.num_points, "visible": int(vis.sum()),
                     "square_instances": int(nt.sum()), "square_instances_from_rects_over_64": int(nt[big].sum()),
                     "gaussians_with_rect_over_64": int(big.sum()), "list_entries_after_culling": pkg["handle"]["num_rendered"],
                     "rect_size_histogram": hist, "mean_opacity_of_big": float(op[big].mean()) if big.any() else None,

@@ -74,7 +74,7 @@ def main():
                 if a.model_file:
                     torch.save({"model": model.capture(), "it": it}, a.model_file)
     trainer = Trainer(model, cams, opt, bg, densify=False)
-    for _ in range(a.warmup):
+    for _ in range(0 if (a.report and a.freeze) else a.warmup):      # (--freeze: the variant under test never trains the model)
         it += 1
         trainer.step(it)
     if a.report and a.freeze:

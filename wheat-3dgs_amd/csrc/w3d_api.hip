@@ -469,6 +469,16 @@ int w3d_debug_tile_ranges(int32_t H, int32_t W, int32_t P, const void *state, ui
     return w3d_debug_tile_ranges_impl(L, static_cast<const char *>(state), ranges_out, reinterpret_cast<hipStream_t>(stream_));
 }
 
+int w3d_debug_tile_rects(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *rects_out, w3d_stream_t stream_) {
+    W3DLayout L;
+    int rc = w3d_make_layout(P, H, W, &L);
+    if (rc || !state || (P > 0 && !rects_out)) { w3d_set_error("bad arguments"); return W3D_ERR_INVALID; }
+    if (P > 0)
+        W3D_HIP_CHECK(hipMemcpyAsync(rects_out, static_cast<const char *>(state) + L.o_tile_mask, (size_t)P * 16, hipMemcpyDeviceToDevice,
+                                     reinterpret_cast<hipStream_t>(stream_)));
+    return W3D_OK;
+}
+
 int w3d_debug_pixel_state(int32_t H, int32_t W, int32_t P, const void *state, float *final_T_out,
                           uint32_t *n_contrib_out, w3d_stream_t stream_) {
     W3DLayout L;

@@ -442,6 +442,17 @@ def debug_tile_ranges(saved):
     return out
 
 
+def debug_tile_rects(saved):
+    """(P,4) int32 {rect lo, rect hi, mask lo, mask hi} of a forward with tile_cull (include/w3d.h w3d_debug_tile_rects)."""
+    v = saved["view"].c
+    dev = saved["state"].device
+    out = torch.empty(saved["P"], 4, dtype=torch.int32, device=dev)
+    lib.w3d_debug_tile_rects.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_void_p] * 3
+    lib.w3d_debug_tile_rects.restype = ctypes.c_int
+    check(lib.w3d_debug_tile_rects(v.image_height, v.image_width, saved["P"], ptr(saved["state"]), ptr(out), stream_ptr(dev)))
+    return out
+
+
 def debug_pixel_state(saved):
     v = saved["view"].c
     dev = saved["state"].device
