@@ -53,6 +53,7 @@ def nccl_inplace_shard(full, lo, hi, rank, world):
 
 class Trainer:
     ROWS_RETRY = 16          # exchange="rows": steps in the low-rank form after one that was too dense, before rows are counted again
+    ROWS_WINDOW = 48         # ... and the speculative size of the row collective follows the largest count of this many steps
 
     def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
                  densify=True, loss_fn=photometric_loss, fused=None, force_exchange=False, fused_adam=True,
@@ -102,6 +103,7 @@ class Trainer:
         self._rows_skip = 0
         self._rows = None                     # fused_step.GatheredRows of the current iteration (GPU path of exchange_rows)
         self._rows_bufs = None                # persistent per-step buffers of exchange_rows (index arrays, pinned counts)
+        self._rows_recent = []                # largest per-view row counts of the last ROWS_WINDOW steps (sizes the speculation)
         self.exchange_used = {"rows": 0, "lowrank": 0}        # steps per form actually taken (rows mode decides per step)
         self.fused_adam = bool(fused_adam)
         if exchange == "rows" and self.world > 32:
@@ -277,6 +279,7 @@ class Trainer:
             self.exchange_used["lowrank"] += 1
             self._rows_skip = self.ROWS_RETRY
             self._rows_cap = None
+            self._rows_recent = []
             ns = None
             if tracking:
                 ns = grad2d_norm * visible
@@ -315,8 +318,11 @@ class Trainer:
         self.last_row_counts = hc
         self.exchange_used["rows"] += 1
         # next step's guess — or back to the exact, host-sized form when the views have become too dense for this one
+        # (the views differ: one camera's row count says little about the next one's — sized from the previous STEP alone, 27 of
+        #  100 benchmark steps outgrew the guess and paid a second collective; the largest count of a window of steps, + 15 %)
+        self._rows_recent = (self._rows_recent + [nmax])[-self.ROWS_WINDOW:]
         self._rows_cap = None if nmax > limit or not self.rows_speculate else \
-            min(max(P, 1), (int(1.25 * nmax) + 1024) // 1024 * 1024)
+            min(max(P, 1), (int(1.15 * max(self._rows_recent)) + 1024) // 1024 * 1024)
         if gpu:
             # the optimizer kernel reads the rows through the per-Gaussian index (optimizer_step_lowrank -> w3d_rows_adam):
             # no dense per-view array is zero-filled, scattered into or read
