@@ -446,6 +446,9 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                 if (pos < capacity) point_list[pos] = id;
             });
             __builtin_amdgcn_wave_barrier();
+            // (round 4 tried advancing the cursors through the touched tiles' LEADER records — lowest bit of the bitmap — instead of
+            //  this sweep over the band: 0.152 -> 0.175 ms; sixteen exec-masked LDS read-modify-writes per lane cost more than
+            //  five coalesced sweeps of 64 tiles)
             for (uint32_t t0 = 0; t0 < Tb; t0 += 512) {          // cursors advance by the batch's hits; 8 reads in flight
                 unsigned long long b8[8];
 #pragma unroll

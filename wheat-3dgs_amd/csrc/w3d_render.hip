@@ -19,6 +19,8 @@
 // neighbouring tiles (which share Gaussians) hit the same L2.
 #include "w3d_common.h"
 
+#include <type_traits>
+
 namespace {
 
 #ifndef W3D_RW
@@ -508,6 +510,12 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
 #ifdef W3D_BWD_STATS
     uint32_t st_entries = 0, st_quads = 0, st_exp = 0, st_full = 0, st_staged = 0;
 #endif
+    // The walk exists twice — black background (the reference's default, arguments/__init__.py: white_background False; the
+    // background term and its per-quadrant scalar branch are compiled out) and any other — chosen once per wave: the time of
+    // this kernel is the number of instructions it issues, and `if (has_bg)` cost two of them per
+    // quadrant evaluation even when the background is black.
+    auto walk = [&](auto bg_tag) {
+    constexpr bool BG = decltype(bg_tag)::value;
     Staged nxt;
     {
         const uint32_t g = batch_id(nb - 1);
@@ -607,11 +615,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                     }
                     Tr[k] = Tn;
                     dL_dalpha *= Tn;
-                    if (has_bg) {
-                        // (the empty asm keeps this a scalar branch: if-converted it costs 3 VALU per quadrant on black backgrounds)
-                        asm volatile("" : "+v"(dL_dalpha));
-                        dL_dalpha -= (Tfin[k] * inv) * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);
-                    }
+                    if (BG) dL_dalpha -= (Tfin[k] * inv) * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);
                     const float m = ed.w * dL_dalpha * G;      // dL/dG * G
                     const float mx = m * dx, my = m * dy;
                     v[0] += mx; v[1] += my;
@@ -692,6 +696,8 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             __builtin_amdgcn_wave_barrier();
         }
     }
+    };
+    if (has_bg) walk(std::true_type{}); else walk(std::false_type{});
 #ifdef W3D_BWD_STATS
     if (lane == 0) {
         uint32_t *cw = const_cast<uint32_t *>(counters);
