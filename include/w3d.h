@@ -130,7 +130,8 @@ int w3d_forward_stage1(const w3d_view *view, int32_t P, const float *means3D, co
  * that sized the buffer speculatively to avoid stage 1's host sync) nothing is written or read beyond
  * it, the outputs of that view are incomplete, and the caller must repeat the stage with a larger list
  * once it has seen num_rendered (the counters are the first two uint32 of `state`).  out_color (3,H,W), out_depth (1,H,W), out_alpha
- * (1,H,W).  FlashSplat extras are all nullable: gt_mask (H,W) fp32 labels in [0,num_obj],
+ * (1,H,W); out_depth and out_alpha may BOTH be NULL when no FlashSplat output is asked for (a training step whose loss only reads the
+ * colour image: the blend then skips the two channels).  FlashSplat extras are all nullable: gt_mask (H,W) fp32 labels in [0,num_obj],
  * used_count (num_obj+1,P) is ACCUMULATED into (caller zero-fills), contrib_num (H,W) int32,
  * proj_xy (P,2), gs_depth (P,). */
 int w3d_forward_stage2(const w3d_view *view, int32_t P, void *state, void *scratch, uint32_t *point_list,

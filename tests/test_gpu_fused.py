@@ -726,3 +726,47 @@ def test_kept_backward_scratch_is_handed_back_clean_and_changes_no_gradient(monk
         with pytest.raises(RuntimeError, match="between backward_blend_dcolor"):
             FS.backward_raw_lowrank(m, pkg_a["handle"], None)
         assert clean(m)
+
+
+def test_color_only_forward_equals_the_full_forward():
+    """w3d_forward_stage2 with out_depth = out_alpha = NULL (render_raw(color_only=True), what Trainer.step_fused asks for): the
+    colour image, the per-pixel state kept for the backward and the gradients are bit-identical to the full forward's; asking
+    for FlashSplat outputs without the two images is refused."""
+    import ctypes
+    import w3d_amd.fused_step as FS
+    from w3d_amd._lib import lib, ptr, stream_ptr
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.rasterizer import debug_pixel_state
+    dev = torch.device("cuda:0")
+    W, H = 203, 149
+    cam = make_cameras(2, W, H)[1].to(dev)
+    sc = make_scene(9000, seed=12, scale_mean=0.03)
+    bg = torch.tensor([0.2, 0.0, 0.1], device=dev)
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    m.active_sh_degree = 3
+    m.deterministic = True
+    m.training_setup(OptimizationParams())
+    dimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    with torch.no_grad():
+        full = FS.render_raw(cam, m, bg)
+        FS.backward_raw(m, full["handle"], dimg)
+        g_full = m.flat_grad.clone()
+        co = FS.render_raw(cam, m, bg, color_only=True)
+        assert co["depth"] is None and co["alpha"] is None and torch.equal(co["render"], full["render"])
+        sa = debug_pixel_state(dict(view=full["handle"]["view"], state=full["handle"]["state"], P=full["handle"]["P"]))
+        sb = debug_pixel_state(dict(view=co["handle"]["view"], state=co["handle"]["state"], P=co["handle"]["P"]))
+        assert torch.equal(sa[0], sb[0]) and torch.equal(sa[1], sb[1])
+        FS.backward_raw(m, co["handle"], dimg)
+        assert torch.equal(m.flat_grad, g_full)
+        # FlashSplat outputs need the two images: refused on the host side of the ABI
+        h = co["handle"]
+        cn = torch.empty(H, W, dtype=torch.int32, device=dev)
+        sb_, tb_ = ctypes.c_uint64(), ctypes.c_uint64()
+        lib.w3d_forward_sizes(h["P"], H, W, ctypes.byref(sb_), ctypes.byref(tb_))
+        scratch = torch.empty(tb_.value, dtype=torch.uint8, device=dev)
+        rc = lib.w3d_forward_stage2(ctypes.byref(h["view"].c), h["P"], ptr(h["state"]), ptr(scratch), ptr(h["point_list"]),
+                                    ctypes.c_uint64(h["capacity"]), ptr(co["render"]), None, None, None, 1, None, ptr(cn), None, None,
+                                    stream_ptr(dev))
+        assert rc != 0 and b"both or neither" in lib.w3d_last_error()

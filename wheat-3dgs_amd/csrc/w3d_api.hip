@@ -180,7 +180,12 @@ int w3d_forward_stage2(const w3d_view *view, int32_t P, void *state, void *scrat
     W3DLayout L;
     rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
     if (rc) { w3d_set_error("bad sizes"); return rc; }
-    if (!state || !scratch || !out_color || !out_depth || !out_alpha) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
+    if (!state || !scratch || !out_color) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
+    const bool flash_out = gt_mask || used_count || contrib_num;
+    if ((out_depth == nullptr) != (out_alpha == nullptr) || (flash_out && !out_depth)) {
+        w3d_set_error("out_depth / out_alpha: both or neither (neither only without the FlashSplat outputs)");
+        return W3D_ERR_INVALID;
+    }
     if (list_capacity > 0 && !point_list) { w3d_set_error("point_list is NULL"); return W3D_ERR_INVALID; }
     if (gt_mask && used_count && num_obj < 0) { w3d_set_error("num_obj must be >= 0"); return W3D_ERR_INVALID; }
     char *st = static_cast<char *>(state), *sc = static_cast<char *>(scratch);

@@ -179,7 +179,9 @@ __device__ __forceinline__ uint32_t stage_entries(StagedLDS &s, uint32_t lane, u
 #ifndef W3D_FWD_OCC
 #define W3D_FWD_OCC 6     // waves per SIMD the forward is compiled for (80 VGPRs as it falls out; 8 would need <= 64)
 #endif
-template <bool FLASH>
+// DA: the depth and alpha images are wanted (every API path but the fused training step, which only feeds the colour image to its
+// loss: w3d_forward_stage2 with out_depth = out_alpha = NULL drops their two accumulations per pixel and entry and their stores)
+template <bool FLASH, bool DA = true>
 __global__ void __launch_bounds__(64 * W3D_RW, FLASH ? 4 : W3D_FWD_OCC)
 render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restrict__ tile_start,
                   const uint32_t *__restrict__ point_list, const float2 *__restrict__ xy,
@@ -309,7 +311,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                 hi[k] = stop ? -INFINITY : hi[k];
 #endif
                 C0[k] += ec.x * w; C1[k] += ec.y * w; C2[k] += ec.z * w;
-                D[k] += ec.w * w; A[k] += w;
+                if (DA) { D[k] += ec.w * w; A[k] += w; }
                 if (FLASH) { wk[k] = w; napplied[k] += apply ? 1 : 0; any_applied = any_applied || apply; }
             }
             if (FLASH && gt_mask && used_count) {
@@ -371,8 +373,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             out_color[pix] = C0[k] + Tr[k] * bg0;
             out_color[HW + pix] = C1[k] + Tr[k] * bg1;
             out_color[2 * HW + pix] = C2[k] + Tr[k] * bg2;
-            out_depth[pix] = D[k];
-            out_alpha[pix] = A[k];
+            if (DA) { out_depth[pix] = D[k]; out_alpha[pix] = A[k]; }
             final_T[pix] = Tr[k];
             n_contrib[pix] = last[k];
             if (FLASH && contrib_num) contrib_num[pix] = napplied[k];
@@ -861,7 +862,8 @@ int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const 
     {
         W3D_PROF("render_fwd", stream);
         if (flash) hipLaunchKernelGGL((render_fwd_kernel<true>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
-        else hipLaunchKernelGGL((render_fwd_kernel<false>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
+        else if (out_depth && out_alpha) hipLaunchKernelGGL((render_fwd_kernel<false>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
+        else hipLaunchKernelGGL((render_fwd_kernel<false, false>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
     }
 #undef ARGS
     W3D_LAUNCH_CHECK(v.debug, stream);

@@ -95,14 +95,16 @@ def finish(handle):
     return handle["num_rendered"] <= handle["capacity"]
 
 
-def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, flash=None, used_mask=None):
+def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, flash=None, used_mask=None, color_only=False):
     """Forward on the raw parameters.  Returns the dict of render() (minus viewspace_points) plus a
     `handle` for backward_raw().  sync=False: no host synchronisation (rasterizer.ListCapacity); the caller
     must call finish(handle) before trusting the outputs, and repeat the view when it returns False.
     used_mask: (P,) bool — only these Gaussians are rendered (flashsplat_render(used_mask=...), reference
     gaussian_renderer/__init__.py:151-156,168-170,186-187); the others are culled inside the preprocess kernel, so no
     subset of the parameter blocks is gathered.  Per-Gaussian outputs keep P rows (zeros on the rows left out).
-    The model's `tile_cull` / `deterministic` attributes select the two optional behaviours (rasterizer.py header)."""
+    The model's `tile_cull` / `deterministic` attributes select the two optional behaviours (rasterizer.py header).
+    color_only: the depth and alpha images are not wanted (Trainer.step_fused: reference train_vanilla_3dgs.py:74-80 feeds only
+    `render` to the loss) — `depth` / `alpha` of the result are None and the blend skips the two channels."""
     dev = model.flat.device
     if not model.flat.is_cuda:
         raise RuntimeError("the fused step needs the model on the GPU; there is no CPU path")
@@ -149,8 +151,10 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, flash=None
             pending = (pinned, ev)
         plist = torch.empty(max(R, 1), dtype=torch.int32, device=dev)
         color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-        depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
-        alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        depth = alpha = None
+        if not (color_only and flash is None):
+            depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+            alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
         gt_mask = used_count = contrib_num = proj_xy = gs_depth = None
         num_obj = 0
         if flash is not None:

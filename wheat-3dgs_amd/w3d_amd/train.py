@@ -512,7 +512,7 @@ class Trainer:
                 attempts += 1
                 if attempts > 4:      # one repeat sizes the list buffer exactly; more means the counters are corrupt
                     raise RuntimeError("fused step: the forward keeps reporting an overflowing list buffer")
-                pkg = render_raw(cam, m, bg, sync=False)
+                pkg = render_raw(cam, m, bg, sync=False, color_only=True)      # (the loss reads `render` only)
                 loss, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
                 if not single and self.world > 1:
                     dimg.mul_(1.0 / self.world)      # the bucket then holds grad/world: reduce-scatter(SUM) = mean
