@@ -40,6 +40,9 @@ namespace {
                                // kernel's cycles on the densified scene (profiles/r04/lds_counters.txt).  132 (16-B aligned for
                                // the flush's b128 reads) spreads the values over banks 4k mod 32.
 #endif
+#ifndef W3D_BWD_SFORM
+#define W3D_BWD_SFORM 1        // blend backward: the suffix colour carried as its product with dL/dpixel (one scalar per pixel)
+#endif
 #ifndef W3D_VCC_SELECT
 #define W3D_VCC_SELECT 1       // per-lane selects of the blend loops through VCC: v_cndmask_b32_e32 issues at full rate, the e64 form
                                // (mask in an SGPR pair — what the compiler picks when several lane masks are alive) at half rate
@@ -462,7 +465,15 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     const float pxb = (float)(tx0 + lx), pyb = (float)(ty0 + ly);
     float Tr[4], Tfin[4];
     float dp0[4], dp1[4], dp2[4], dpd[4], dpa[4];
+#if W3D_BWD_SFORM
+    // The colour (depth, alpha) composited BEHIND the entry being visited enters dL/dalpha only through its product with
+    // dL/dpixel, so ONE scalar per pixel is carried, S = A . dL/dpixel, advanced by the same recurrence (A <- a c + (1-a) A
+    // gives S <- S + a (c . dL/dpixel - S)): 5 instructions per pixel and entry instead of 9 (15 -> 7 with depth / alpha
+    // gradients), 8 (16) registers fewer.  The other legal form of the suffix recurrence (the oracle's exp-mode bit 3).
+    float S[4];
+#else
     float ar0[4], ar1[4], ar2[4], ard[4], ara[4];
+#endif
     uint32_t last[4];
     uint32_t maxc = 0;
 #pragma unroll
@@ -478,7 +489,11 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         dp2[k] = in ? dL_dcolor[2 * HW + pix] : 0.f;
         dpd[k] = (HAS_DA && in && dL_ddepth) ? dL_ddepth[pix] : 0.f;
         dpa[k] = (HAS_DA && in && dL_dalpha_px) ? dL_dalpha_px[pix] : 0.f;
+#if W3D_BWD_SFORM
+        S[k] = 0.f;
+#else
         ar0[k] = ar1[k] = ar2[k] = ard[k] = ara[k] = 0.f;
+#endif
         maxc = max(maxc, last[k]);
     }
     maxc = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(maxc));   // (an SGPR: everything derived from it stays scalar)
@@ -605,6 +620,12 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                     const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                     const float Tn = Tr[k] * inv;
                     const float dch = alpha * Tn;
+#if W3D_BWD_SFORM
+                    float cdp = ec.x * dp0[k] + ec.y * dp1[k] + ec.z * dp2[k];
+                    if (HAS_DA) { cdp += ec.w * dpd[k] + dpa[k]; v[9] += dch * dpd[k]; }
+                    float dL_dalpha = cdp - S[k];
+                    S[k] = fmaf(alpha, dL_dalpha, S[k]);
+#else
                     const float d0 = ec.x - ar0[k], d1 = ec.y - ar1[k], d2 = ec.z - ar2[k];
                     float dL_dalpha = d0 * dp0[k] + d1 * dp1[k] + d2 * dp2[k];
                     ar0[k] += alpha * d0; ar1[k] += alpha * d1; ar2[k] += alpha * d2;   // A <- a c + (1-a) A
@@ -614,6 +635,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                         ard[k] += alpha * dd; ara[k] += alpha * da;
                         v[9] += dch * dpd[k];
                     }
+#endif
                     Tr[k] = Tn;
                     dL_dalpha *= Tn;
                     if (BG) dL_dalpha -= (Tfin[k] * inv) * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);

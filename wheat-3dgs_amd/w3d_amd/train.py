@@ -640,10 +640,10 @@ def render_views(model, cameras, background, pipe=None):
         def settle(i, pkg):
             if not finish(pkg["handle"]):
                 with torch.cuda.stream(streams[i % len(streams)]):
-                    out[i] = render_raw(cameras[i], model, background)["render"]      # synchronous: exact buffer size
+                    out[i] = render_raw(cameras[i], model, background, color_only=True)["render"]      # synchronous: exact buffer size
         for i, cam in enumerate(cameras):
             with torch.cuda.stream(streams[i % len(streams)]):
-                pkg = render_raw(cam, model, background, sync=False)
+                pkg = render_raw(cam, model, background, sync=False, color_only=True)      # (only `render` is returned)
             out.append(pkg["render"])
             pending.append((i, pkg))
             if len(pending) > len(streams):
