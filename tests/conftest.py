@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "wheat-3dgs_amd"), os.path.join(ROOT, "tests"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import _poison                      # W3D_TEST_FILL=zeros|ff|nan|small|rand|unit: patterned torch.empty (tests/_poison.py)
+    _poison.install_from_env()
 
 
 def pytest_collection_modifyitems(config, items):

@@ -140,8 +140,13 @@ def test_fused_raw_step_equals_autograd_step(deg, W, H):
     ga, gb = grads[0], grads[5]          # first step of each flavour (5 steps each)
     for name, (a, b) in ma.block_slices().items():
         ref = ga[a:b]
-        err = float((gb[a:b] - ref).abs().max() / (ref.abs().max() + 1e-20))
-        assert err <= 2e-4, f"{name}: rel err {err:.2e}"
+        d = (gb[a:b] - ref).abs()
+        err = float(d.max() / (ref.abs().max() + 1e-20))
+        if err > 2e-4:                   # say which elements, should this ever trip: a single Gaussian or a whole block?
+            bad = (d > 2e-4 * ref.abs().max()).nonzero().flatten()[:8].tolist()
+            detail = [(i, float(ref[i]), float(gb[a:b][i])) for i in bad]
+            raise AssertionError(f"{name}: rel err {err:.2e}, {int((d > 2e-4 * ref.abs().max()).sum())} of {b - a} "
+                                 f"elements beyond the bound, first (index, autograd, fused): {detail}")
     # (a near-zero gradient whose sign differs in the last bit moves that parameter by 2*lr under Adam:
     #  bound the bulk tightly and the maximum by the largest learning rate)
     diff = (ma.flat - mb.flat).abs()
@@ -770,3 +775,53 @@ def test_color_only_forward_equals_the_full_forward():
                                     ctypes.c_uint64(h["capacity"]), ptr(co["render"]), None, None, None, 1, None, ptr(cn), None, None,
                                     stream_ptr(dev))
         assert rc != 0 and b"both or neither" in lib.w3d_last_error()
+
+
+def test_last_gaussian_of_a_ragged_workgroup():
+    """P is not a multiple of the per-Gaussian backward's 256-lane workgroups: the idle lanes of the last workgroup stay in
+    the kernel for its barriers (they alias Gaussian P - 1) and must not act on it.  Round 4: under records_kept_clean such a
+    lane could zero the record of P - 1 before its owner had read it — Gaussian P - 1 then lost its whole gradient for that
+    view, about once in 40 launches, which surfaced as three unrelated-looking one-off failures of the full suite.  The same
+    view's backward is repeated and the last Gaussian's gradient must come out the same every time."""
+    from w3d_amd.synth import make_scene, make_cameras
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.fused_step import backward_raw, backward_raw_adam, render_raw
+    from w3d_amd.fused import l1_ssim_fwd_bwd
+    dev = torch.device("cuda:0")
+    W, H, P = 176, 144, 19 * 256 + 65        # the last workgroup: one whole wave + 1 lane are Gaussians, two whole waves are idle
+    cam = make_cameras(3, W, H)[1].to(dev)
+    cam.original_image = torch.rand(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    sc = make_scene(P, seed=21, scale_mean=0.03)
+    sc.xyz[-1] = sc.xyz.mean(0)              # the last Gaussian sits in the middle of the scene: visible, with a gradient
+    sc.opacity[-1] = 2.0
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    m.active_sh_degree = 3
+    opt = OptimizationParams()
+    m.training_setup(opt)
+    bg = torch.zeros(3, device=dev)
+    rows = []
+    with torch.no_grad():
+        for it in range(400):
+            pkg = render_raw(cam, m, bg, sync=True, color_only=True)
+            _, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
+            backward_raw(m, pkg["handle"], dimg)
+            rows.append(torch.cat([m.flat_grad[a:b].view(P, -1)[-1] for a, b in m.block_slices().values()]).clone())
+    rows = torch.stack(rows)
+    assert float(rows[0].abs().max()) > 0, "the last Gaussian has no gradient in this view: the test tests nothing"
+    spread = float((rows - rows[0]).abs().max() / rows[0].abs().max())
+    assert spread <= 1e-4, f"the last Gaussian's gradient varies from launch to launch: {spread:.2e} of its largest component"
+    # ... and the fused backward + Adam kernel: the first moment the first step leaves behind is 0.1 x that gradient
+    for it in range(50):
+        m2 = GaussianModel(3, device=dev)
+        m2.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+        m2.active_sh_degree = 3
+        m2.training_setup(opt)
+        m2.update_learning_rate(1)
+        with torch.no_grad():
+            pkg = render_raw(cam, m2, bg, sync=True, color_only=True)
+            _, dimg = l1_ssim_fwd_bwd(pkg["render"], cam.original_image, opt.lambda_dssim)
+            backward_raw_adam(m2, pkg["handle"], dimg, want_norm=False, update_stats=False)
+        mom = torch.cat([m2.optimizer.exp_avg[a:b].view(P, -1)[-1] for a, b in m2.block_slices().values()])
+        err = float((mom - 0.1 * rows[0]).abs().max() / (0.1 * rows[0].abs().max()))
+        assert err <= 1e-4, f"fused backward + Adam, launch {it}: first moment of the last Gaussian off by {err:.2e}"

@@ -86,6 +86,9 @@ def worker(rank, world, port, mode, outdir, backend="gloo_staged"):
             sys.path.insert(0, p)
     import torch
     import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _poison                      # (W3D_TEST_FILL: patterned torch.empty, see tests/_poison.py; a no-op otherwise)
+    _poison.install_from_env()
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     if backend == "nccl":               # one GPU per rank, RCCL over xGMI, the product's collectives as they are
         dev = torch.device("cuda", rank)

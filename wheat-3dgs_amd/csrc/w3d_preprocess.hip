@@ -414,10 +414,12 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
                 const float xext = __builtin_amdgcn_sqrtf(T2 * conz * idet) * 1.0001f + 0.01f;
                 const float yext = __builtin_amdgcn_sqrtf(T2 * conx * idet) * 1.0001f + 0.01f;
                 // tile t holds the pixel columns (rows) [16 t, 16 t + 15]
-                cminx = max(minx, (int)ceilf((px - xext - (float)(W3D_TILE - 1)) * (1.0f / W3D_TILE)));
-                cmaxx = min(maxx, (int)floorf((px + xext) * (1.0f / W3D_TILE)) + 1);
-                cminy = max(miny, (int)ceilf((py - yext - (float)(W3D_TILE - 1)) * (1.0f / W3D_TILE)));
-                cmaxy = min(maxy, (int)floorf((py + yext) * (1.0f / W3D_TILE)) + 1);
+                // (clamped as floats before the conversion: an extent beyond the int range — a degenerate conic — or a NaN
+                //  leaves the published rect's bound in place instead of wrapping around)
+                cminx = max(minx, (int)fmaxf(ceilf((px - xext - (float)(W3D_TILE - 1)) * (1.0f / W3D_TILE)), -1.f));
+                cmaxx = min(maxx, (int)fminf(floorf((px + xext) * (1.0f / W3D_TILE)), 65535.f) + 1);
+                cminy = max(miny, (int)fmaxf(ceilf((py - yext - (float)(W3D_TILE - 1)) * (1.0f / W3D_TILE)), -1.f));
+                cmaxy = min(maxy, (int)fminf(floorf((py + yext) * (1.0f / W3D_TILE)), 65535.f) + 1);
                 if (cminx >= cmaxx || cminy >= cmaxy) cminx = cminy = cmaxx = cmaxy = 0;
             }
             // (b) within it, tile by tile — for rects of up to 64 tiles (larger ones are left whole)
@@ -572,7 +574,10 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *means3D, const float *shs,
     float inv_qnorm = 1.f;
     float q_act[4] = {1.f, 0.f, 0.f, 0.f}, s_act[3] = {0.f, 0.f, 0.f};
     const ushort4 rc = rect[g];
-    const bool vis = ((int)rc.z - (int)rc.x) * ((int)rc.w - (int)rc.y) > 0;
+    // (`active`: the idle lanes of the last workgroup alias Gaussian P - 1 only to stay in the barriers — they must not act
+    //  on it: under records_kept_clean a lane that zeroed P - 1's record before its owner had read it cost that Gaussian its
+    //  gradient, once in ~40 launches of a 5 000-Gaussian scene — tests/test_gpu_fused.py::test_last_gaussian_of_a_ragged_workgroup)
+    const bool vis = active && ((int)rc.z - (int)rc.x) * ((int)rc.w - (int)rc.y) > 0;
     float dmean[3] = {0.f, 0.f, 0.f};
     float dm2[2] = {0.f, 0.f};
     float dop = 0.f;
