@@ -433,7 +433,11 @@ void *w3do_forward(const W3DOView *v, int P, const float *means3D, const float *
  * behind every earlier one — so every Gaussian blended at that pixel moves.
  *
  * w3do_fragile_pixels: out[pix] = 1 where the oracle's own walk of the pixel meets a pair with
- *     |alpha * 255 - 1| <= eps,  or  |test_T / 1e-4 - 1| <= eps,  or  |power| <= eps (power within eps of the power > 0 skip).
+ *     |ln(alpha * 255)| <= tol,  or  |test_T / 1e-4 - 1| <= eps + tol_T,  or  |power| <= tol (the power > 0 skip),
+ * where tol = eps + 2e-6 * (0.5 (|A| dx^2 + |C| dy^2) + |B dx dy|): "on the threshold" is measured in units of what TWO fp32
+ * evaluations of the exponent can differ by — a few ulps of the sum of its terms' magnitudes, which for a needle-shaped Gaussian
+ * (conic condition 1e4 ... 1e7) hundreds of pixels from its centre is 0.01 ... 1, not 1e-7 — and tol_T accumulates what that
+ * does to the transmittance (sum of alpha / (1 - alpha) times the pair's exponent noise).  For ordinary Gaussians tol = eps.
  * w3do_mark_contributors: flags[g] = 1 for every Gaussian that is BLENDED (applied) at a pixel with pixel_flags != 0. */
 void w3do_fragile_pixels(void *h, float eps, unsigned char *out) {
     W3DOState *s = (W3DOState *)h;
@@ -444,20 +448,23 @@ void w3do_fragile_pixels(void *h, float eps, unsigned char *out) {
         uint32_t b = s->ranges[2 * t], e = s->ranges[2 * t + 1];
         for (int py = ty0; py < ty0 + TILE && py < H; py++)
             for (int px = tx0; px < tx0 + TILE && px < W; px++) {
-                float Tr = 1.0f, pxf = (float)px, pyf = (float)py;
+                float Tr = 1.0f, pxf = (float)px, pyf = (float)py, tol_T = 0.0f;
                 unsigned char frag = 0;
                 for (uint32_t i = b; i < e; i++) {
                     uint32_t g = s->point_list[i];
                     float dx = s->xy[2 * (size_t)g] - pxf, dy = s->xy[2 * (size_t)g + 1] - pyf;
                     const float *co = s->conic_op + 4 * (size_t)g;
                     float power = w3do_power(co, dx, dy);
-                    if (fabsf(power) <= eps && co[3] >= 1.0f / 255.0f) frag = 1;
+                    const float noise = 2e-6f * (0.5f * (fabsf(co[0]) * dx * dx + fabsf(co[2]) * dy * dy) + fabsf(co[1] * dx * dy));
+                    const float tol = eps + noise;
+                    if (fabsf(power) <= tol && co[3] >= 1.0f / 255.0f) frag = 1;
                     if (power > 0.0f) continue;
                     float alpha = fminf(0.99f, co[3] * w3do_exp(power));
-                    if (fabsf(alpha * 255.0f - 1.0f) <= eps) frag = 1;
+                    if (alpha > 0.0f && fabsf(logf(alpha * 255.0f)) <= tol) frag = 1;
                     if (alpha < 1.0f / 255.0f) continue;
                     float test_T = Tr * (1.f - alpha);
-                    if (fabsf(test_T * 10000.0f - 1.0f) <= eps) frag = 1;
+                    tol_T += noise * alpha / (1.f - alpha);
+                    if (fabsf(test_T * 10000.0f - 1.0f) <= eps + tol_T) frag = 1;
                     if (test_T < 0.0001f) break;
                     Tr = test_T;
                 }
@@ -486,9 +493,11 @@ void w3do_mark_contributors(void *h, const unsigned char *pixel_flags, unsigned 
                     float dx = s->xy[2 * (size_t)g] - pxf, dy = s->xy[2 * (size_t)g + 1] - pyf;
                     const float *co = s->conic_op + 4 * (size_t)g;
                     float power = w3do_power(co, dx, dy);
-                    if (power > 1e-3f) continue;
-                    float alpha = fminf(0.99f, co[3] * w3do_exp(power));
-                    if (alpha < 0.99f / 255.0f) continue;
+                    /* (same exponent-noise window as w3do_fragile_pixels) */
+                    const float noise = 2e-6f * (0.5f * (fabsf(co[0]) * dx * dx + fabsf(co[2]) * dy * dy) + fabsf(co[1] * dx * dy));
+                    if (power > 1e-3f + noise) continue;
+                    float alpha = fminf(0.99f, co[3] * w3do_exp(fminf(power, 0.0f)));
+                    if (alpha * w3do_exp(fminf(noise, 80.0f)) < 0.99f / 255.0f) continue;
                     flags[g] = 1;           /* (benign race: every writer stores 1) */
                     if (i - b >= s->n_contrib[pix] + 64u) break;   /* far behind the stop: cannot be reached by a flip */
                 }

@@ -265,6 +265,35 @@ def test_duplicate_gaussians_tie_order():
     check_images(out, ref, "[dups, culled] ")
 
 
+@pytest.mark.parametrize("seed", [0, 3])
+def test_culls_are_exact_on_needles(seed):
+    """The footprint culls (rect shrunk to the ellipse's extent, per-tile mask, per-quadrant masks of the blend) may only drop
+    instances that contribute nothing UNDER THE BLEND'S OWN fp32 EXPONENT.  On needle-shaped Gaussians (conic condition up to
+    1e7, centres outside the frame) that exponent is off by up to ~1 in absolute terms, and round 4's first version of the
+    culls — fixed margins of 1e-3 / 0.01 px, the conic's determinant as A*C - B*B — dropped 30-100 pixels' worth of
+    contributions with alpha just above 1/255 per view of this scene (and once tripped the trained-scene test: 35 pixels with
+    dT/T up to 1.3 %).  Now: the images with the culls are bit-identical to the images without, and against the oracle every
+    dropped (Gaussian, tile) instance stays below 1/255 on all its pixels."""
+    from util import needle_scene
+    W, H = 400, 304
+    sc = needle_scene(seed, P=6000)
+    bg = (0.0, 0.0, 0.0)
+    for ci, cam in enumerate(make_cameras(3, W, H)):
+        d = view_inputs(sc, cam)
+        a, _ = run_hip(d, cam, bg, tile_cull=False)
+        b, _ = run_hip(d, cam, bg, tile_cull=True)
+        assert b["num_rendered"] < 0.8 * a["num_rendered"]          # the culls do remove a lot here
+        for k in ("color", "depth", "alpha", "radii"):
+            assert np.array_equal(a[k], b[k]), f"view {ci}: {k} changes under the culls " \
+                f"({int((a[k] != b[k]).sum())} elements, max {np.abs(a[k].astype(np.float64) - b[k]).max():.2e})"
+        if ci == 0:
+            o = make_oracle(cam, bg, nthreads=8)
+            ref = o.forward(**np_inputs(d))
+            check_integers(a, o, ref)
+            assert check_culled_lists(b, o, ref, W, H) > 0
+            o.free()
+
+
 @pytest.mark.parametrize("depth_span,P", [("narrow", 150_000), ("wide", 150_000), ("wide", 9_000)])
 def test_depth_sort_paths_and_tie_order_at_size(depth_span, P):
     """The depth sort (w3d_binning.hip: 8-bit digits; three passes when the upper halves of the view's depth keys take at

@@ -56,3 +56,20 @@ def psnr(a, b):
 def rel_err(x, ref):
     x, ref = np.asarray(x, np.float64), np.asarray(ref, np.float64)
     return float(np.abs(x - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+def needle_scene(seed, P=20000):
+    """A stress scene for the footprint culls: needles — one axis 0.05 ... 8 scene units, the two others 1e-5 ... 2e-3, so the
+    projected conics have condition numbers up to 1e7 — many of them centred outside the frame.  For such a Gaussian the blend's
+    fp32 exponent carries an absolute rounding error of 0.01 ... 1 hundreds of pixels from the centre."""
+    import math
+    import torch
+    from w3d_amd.synth import make_scene
+    sc = make_scene(P, seed=100 + seed, scale_mean=0.03)
+    g = torch.Generator().manual_seed(seed)
+    sc.scaling[:, 0] = torch.empty(P).uniform_(math.log(0.05), math.log(8.0), generator=g)
+    sc.scaling[:, 1:] = torch.empty(P, 2).uniform_(math.log(1e-5), math.log(2e-3), generator=g)
+    sc.xyz[:, 0] *= 3.0
+    sc.xyz[:, 1] *= 3.0
+    sc.opacity[:] = torch.empty(P, 1).normal_(0.0, 2.0, generator=g)
+    return sc

@@ -158,6 +158,27 @@ struct W3DRawBwdArgs {
 // again (v_cndmask + v_cmp per call); the builtin consumes the lane mask the comparison already produced.
 __device__ __forceinline__ uint64_t w3d_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// Footprint culling against an exponent that is itself evaluated in fp32.  The blend computes q(d) = 0.5 (A dx^2 + C dy^2) +
+// B dx dy per pixel in fp32; its rounding error is bounded by a few ulps of the SUM OF THE TERMS' MAGNITUDES, which for the
+// needle-shaped Gaussians of a trained scene (conic condition 1e4 ... 1e7, centres hundreds of pixels away) reaches 0.01 ... 1
+// in absolute terms — a pair whose exact q lies outside the ellipse q <= ln(255 o) can evaluate inside it, and the reference
+// (which tests every pixel of the bounding square) blends it.  Every geometric cull therefore widens its threshold by
+// w3d_q_noise() over the region it decides on: 16 x 2^-24 (dx, dy and the pre-scaled coefficients carry a rounding each, the
+// three products and two sums another five) times the largest possible term magnitude there.  For an ordinary Gaussian this is
+// 1e-6 ... 1e-4, below the fixed 1e-3 margin.
+#define W3D_Q_NOISE 1.0e-6f
+__device__ __forceinline__ float w3d_q_noise(float A, float B, float C, float Dx, float Dy) {
+    return W3D_Q_NOISE * (0.5f * (fabsf(A) * Dx * Dx + fabsf(C) * Dy * Dy) + fabsf(B) * Dx * Dy);
+}
+// A C - B^2 of a conic to ~1.5 ulp (Kahan's difference of products): the plain expression loses log2(cond / 4) bits, i.e.
+// everything for a needle with axis ratio 1e3.5, and the ellipse's extents sqrt(2 tau C / det) with it.
+__device__ __forceinline__ float w3d_conic_det(float A, float B, float C) {
+    const float w = B * B;
+    const float e = fmaf(-B, B, w);       // w - B*B, exactly
+    const float f = fmaf(A, C, -w);       // A*C - w, rounded once
+    return f + e;
+}
+
 // torch.optim.Adam's element update (no weight decay / amsgrad), shared by the sweep kernel and the fused backward;
 // contraction off so that both compile to the same roundings
 __device__ __forceinline__ void w3d_adam1(float &p, float g, float &m, float &v, float step_size, float b1, float b2,

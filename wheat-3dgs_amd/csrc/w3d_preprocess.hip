@@ -201,13 +201,14 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float *c, const float *
 // w* = -+ B sqrt(2 tau / (C det)) where r, l reach the ellipse's own extent +- sqrt(2 tau C / det).  The ellipse cut by a
 // strip is convex, hence the tiles it meets in a row are exactly the ones whose pixel columns meet [l, r]: one
 // contiguous run of mask bits per row, no per-tile test (the per-lane loop over up to 64 tiles used to dominate
-// the kernel: a wave runs as long as its largest rect).  tau carries a +1e-3 margin and the intervals a +0.01 px
-// margin, far above fp32 rounding, so a tile is only dropped when the Gaussian provably contributes nothing there:
+// the kernel: a wave runs as long as its largest rect).  tau carries a +1e-3 margin plus the fp32 evaluation noise of the blend's own
+// exponent over the rect (w3d_q_noise, w3d_common.h) and the intervals a +0.01 px margin, the determinant is taken to ~1 ulp
+// (w3d_conic_det), so a tile is only dropped when the Gaussian provably contributes nothing there:
 // every output is unchanged, R and R_walk shrink.  Bit k of the result = k-th tile of the rect, row-major.
 __device__ __forceinline__ uint64_t footprint_tile_mask(float mx, float my, float A, float B, float C, float tau,
                                                         int minx, int miny, int maxx, int maxy) {
     if (tau < 0.f) return 0ull;                       // o <= 1/255: alpha >= 1/255 is unreachable anywhere
-    const float det = A * C - B * B;
+    const float det = w3d_conic_det(A, B, C);
     if (!(A > 0.f && C > 0.f && det > 0.f)) return ~0ull;
     // (hardware rcp / sqrt, ~1 ulp: this mask only has to be conservative, and the 0.01-px / 1e-3 margins dwarf that)
     const float T2 = 2.f * tau, idet = __builtin_amdgcn_rcpf(det), iA = __builtin_amdgcn_rcpf(A);
@@ -399,14 +400,21 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
         if (v.tile_cull) {
             // which tiles of the rect can this Gaussian reach at all?
             // o <= 1/255 can never reach alpha >= 1/255: tau < 0 drops every tile
-            const float tau = (opac > 0.f) ? (__logf(255.0f * opac) + 1e-3f) : -1.0f;
+            float tau = (opac > 0.f) ? (__logf(255.0f * opac) + 1e-3f) : -1.0f;
+            if (tau >= 0.f) {
+                // ... widened by what the blend's fp32 exponent can be off by anywhere in the published rect (its pixel columns
+                // [16 minx, 16 maxx - 1], rows likewise): needles only — w3d_q_noise, w3d_common.h
+                const float Dx = fmaxf(fabsf(px - (float)(W3D_TILE * minx)), fabsf((float)(W3D_TILE * maxx - 1) - px));
+                const float Dy = fmaxf(fabsf(py - (float)(W3D_TILE * miny)), fabsf((float)(W3D_TILE * maxy - 1) - py));
+                tau += w3d_q_noise(conx, cony, conz, Dx, Dy);
+            }
             // (a) the rect itself: the published rule takes the bounding SQUARE of the 3-sigma circle of the major axis; the
             // pixels that can reach alpha >= 1/255 lie inside the ellipse q <= tau, whose own axis-aligned extent is
             // +- sqrt(2 tau C / det) x +- sqrt(2 tau A / det) — for the stretched, faint Gaussians a trained scene is full of a
             // fraction of the square (round 4: 45 % of the densified scene's list entries came from rects of more than 64 tiles,
             // which carry no mask).  Same margins as the mask: +1e-3 on tau, +0.01 px on the extents.
             int cminx = minx, cminy = miny, cmaxx = maxx, cmaxy = maxy;
-            const float det = conx * conz - cony * cony;
+            const float det = w3d_conic_det(conx, cony, conz);
             if (tau < 0.f) {
                 cminx = cminy = cmaxx = cmaxy = 0;
             } else if (conx > 0.f && conz > 0.f && det > 0.f) {

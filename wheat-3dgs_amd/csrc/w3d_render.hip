@@ -129,11 +129,17 @@ struct StagedLDS {
 // binning stage, w3d_preprocess.hip footprint_hits_tile, on a quarter tile): the minimum sits at the centre if
 // that is inside, otherwise on one of the four edges, where it is a clamped 1-D parabola minimum.  Evaluated
 // once per list entry by the staging lane; the blend loops then skip a quadrant on a scalar bit test instead
-// of evaluating the exponent for 64 pixels.  Conservative by the 1e-3 margin, so no result changes.
+// of evaluating the exponent for 64 pixels.  Conservative by the 1e-3 margin plus the exponent's own fp32 evaluation noise
+// over the tile, so no result changes.
 __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, float B, float C, float pmin,
                                                   float tx0, float ty0) {
     if (!(A > 0.f && C > 0.f)) return pmin <= 0.f ? 0xFu : 0u;
-    const float tau = -pmin + 9e-4f;                 // pmin = -log(255 o) - 1e-4
+#ifdef W3D_NO_QUADMASK          // (test aid: profiles/cull_exactness_probe.py compares the product against a build without the masks)
+    return 0xFu;
+#endif
+    // pmin = -log(255 o) - 1e-4; + the fp32 evaluation noise of the exponent over this tile (w3d_q_noise: needles only)
+    const float Dx = fmaxf(fabsf(mx - tx0), fabsf(mx - (tx0 + 15.f))), Dy = fmaxf(fabsf(my - ty0), fabsf(my - (ty0 + 15.f)));
+    const float tau = -pmin + 9e-4f + w3d_q_noise(A, B, C, Dx, Dy);
     const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
     uint32_t m = 0;
 #pragma unroll
