@@ -83,8 +83,10 @@ typedef struct w3d_view {
     int32_t tile_cull;       /* 0: per-tile lists = every tile of the 3-sigma bounding square (the published
                               * rule; lists comparable entry by entry with a reference implementation);
                               * 1: additionally drop (Gaussian, tile) instances whose footprint provably
-                              * cannot reach alpha >= 1/255 on any pixel of the tile — identical images and
-                              * gradients, 40-60 % of the list entries */
+                              * cannot reach alpha >= 1/255 on any pixel of the tile under the blend's own fp32
+                              * evaluation of the exponent (the threshold carries that evaluation's rounding
+                              * bound over the tile) — bit-identical images, identical gradients, 40-60 % of
+                              * the list entries */
     int32_t deterministic;   /* backward only.  0: the blend backward adds every (tile, Gaussian) contribution to the
                               * Gaussian's record with float atomics — fastest, but the order of the additions (hence the
                               * last bits of every gradient) differs from run to run, as in the reference's CUDA kernels.
