@@ -265,6 +265,33 @@ def test_duplicate_gaussians_tie_order():
     check_images(out, ref, "[dups, culled] ")
 
 
+@pytest.mark.parametrize("W,H,P,scale", [(3840, 2160, 1500, 0.05), (5001, 37, 2000, 0.05), (33, 4099, 2000, 0.05)])
+def test_large_and_odd_frames(W, H, P, scale):
+    """A 4K frame (32 400 tiles: more than the tile scan's one workgroup holds at once, four times the benchmark's) and two
+    degenerate aspect ratios (313 x 3 and 3 x 257 tiles: one ragged tile row / column): lists bit-identical to the oracle's,
+    images within the PSNR bar, the culled images bit-identical to the unculled ones, gradients within fp32 accumulation noise
+    (a Gaussian of the 4K frame sums 1e5 pixel terms with float atomics; the oracle sums in double)."""
+    import os
+    sc = make_scene(P, seed=7, scale_mean=scale)
+    cam, bg = make_cameras(3, W, H)[1], (0.1, 0.0, 0.2)
+    d = view_inputs(sc, cam)
+    o = make_oracle(cam, bg, nthreads=os.cpu_count() or 8)
+    ref = o.forward(**np_inputs(d))
+    gc = np.random.RandomState(0).randn(3, H, W).astype(np.float32)
+    gref = o.backward(gc)
+    out, g = run_hip(d, cam, bg, tile_cull=False, grads=(torch.from_numpy(gc), None, None))
+    check_integers(out, o, ref)
+    check_images(out, ref, f"[{W}x{H}] ")
+    out2, g2 = run_hip(d, cam, bg, tile_cull=True, grads=(torch.from_numpy(gc), None, None))
+    assert check_culled_lists(out2, o, ref, W, H) > 0
+    for k in ("color", "depth", "alpha"):
+        assert np.array_equal(out[k], out2[k]), f"{k} changes under the culls"
+    vis = ref["radii"] > 0
+    check_grads(g, gref, vis, f"[{W}x{H}] ", tol=3e-3)
+    check_grads(g2, gref, vis, f"[{W}x{H}, culled] ", tol=3e-3)
+    o.free()
+
+
 @pytest.mark.parametrize("seed", [0, 3])
 def test_culls_are_exact_on_needles(seed):
     """The footprint culls (rect shrunk to the ellipse's extent, per-tile mask, per-quadrant masks of the blend) may only drop
