@@ -10,7 +10,7 @@ for p in (ROOT, os.path.join(ROOT, "wheat-3dgs_amd"), os.path.join(ROOT, "tests"
 import torch
 from w3d_amd.synth import make_scene, make_cameras
 from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
-from w3d_amd.fused_step import render_raw, backward_raw
+from w3d_amd.fused_step import render_raw, backward_raw, backward_raw_adam
 
 pad = int(float(sys.argv[1]) * 1e6) if len(sys.argv) > 1 else 24_000_000
 dev = torch.device("cuda:0")
@@ -30,13 +30,21 @@ def run(sc_tensors):
     with torch.no_grad():
         pkg = render_raw(cam, m, bg, sync=True)
         gn, _ = backward_raw(m, pkg["handle"], dimg, want_norm=True)
-    return m, pkg, gn
+        # ... and one step of the fused backward + Adam kernel (parameters and both moments updated in place)
+        grads = {k: m.flat_grad[lo:hi].clone() for k, (lo, hi) in m.block_slices().items()}
+        m.update_learning_rate(1)
+        pkg2 = render_raw(cam, m, bg, sync=True, color_only=True)
+        backward_raw_adam(m, pkg2["handle"], dimg, want_norm=False, update_stats=True)
+        m.optimizer.note_fused_step()
+    return m, pkg, gn, grads
 
 
 tA = (a.xyz, a.features_dc, a.features_rest, a.scaling, a.rotation, a.opacity)
-mA, pA, gnA = run(tA)
+mA, pA, gnA, grA = run(tA)
 refs = dict(img=pA["render"].clone(), depth=pA["depth"].clone(), alpha=pA["alpha"].clone(), radii=pA["radii"].clone(), gn=gnA.clone(),
-            grads={k: mA.flat_grad[lo:hi].clone() for k, (lo, hi) in mA.block_slices().items()})
+            grads=grA, after={k: (mA.flat[lo:hi].clone(), mA.optimizer.exp_avg[lo:hi].clone(), mA.optimizer.exp_avg_sq[lo:hi].clone())
+                              for k, (lo, hi) in mA.block_slices().items()},
+            stats=(mA.xyz_gradient_accum.clone(), mA.denom.clone(), mA.max_radii2D.clone()))
 R_A = pA["handle"]["num_rendered"]
 del mA, pA
 torch.cuda.empty_cache()
@@ -44,7 +52,7 @@ far = torch.zeros(pad, 3); far[:, 2] = 50.0 + torch.rand(pad)            # behin
 def cat(x, y): return torch.cat([x, y], 0)
 big = (cat(far, a.xyz), cat(torch.zeros(pad, 1, 3), a.features_dc), cat(torch.zeros(pad, 15, 3), a.features_rest),
        cat(torch.full((pad, 3), -5.0), a.scaling), cat(torch.tensor([[1.0, 0, 0, 0]]).repeat(pad, 1), a.rotation), cat(torch.zeros(pad, 1), a.opacity))
-mB, pB, gnB = run(big)
+mB, pB, gnB, grB = run(big)
 P = pad + PA
 print(f"P = {P}: flat buffer {mB.flat.numel() * 4 / 2**30:.2f} GiB; visible {int((pB['radii'] > 0).sum())} (alone: {int((refs['radii'] > 0).sum())}); list entries {pB['handle']['num_rendered']} (alone: {R_A})")
 ok = True
@@ -59,7 +67,12 @@ for k in ("img", "depth", "alpha"):
 check("densification norm of A bit-identical", torch.equal(gnB[pad:], refs["gn"]))
 check("densification norm of the prefix zero", float(gnB[:pad].abs().max()) == 0.0)
 for k, (lo, hi) in mB.block_slices().items():
-    gB = mB.flat_grad[lo:hi].view(P, -1)
+    gB = grB[k].view(P, -1)
     check(f"grad {k}: A's rows bit-identical (byte offset of the first {(lo + pad * gB.shape[1]) * 4 / 2**30:.2f} GiB)", torch.equal(gB[pad:].reshape(-1), refs["grads"][k]))
     check(f"grad {k}: prefix zero", float(gB[:pad].abs().max()) == 0.0)
+for k, (lo, hi) in mB.block_slices().items():
+    for what, buf, ref in zip(("parameters", "first moment", "second moment"), (mB.flat, mB.optimizer.exp_avg, mB.optimizer.exp_avg_sq), refs["after"][k]):
+        check(f"after one fused backward + Adam step, {k} {what}: A's rows bit-identical", torch.equal(buf[lo:hi].view(P, -1)[pad:].reshape(-1), ref))
+for name, bufB, bufA in zip(("xyz_gradient_accum", "denom", "max_radii2D"), (mB.xyz_gradient_accum, mB.denom, mB.max_radii2D), refs["stats"]):
+    check(f"statistics {name}: A's rows bit-identical, prefix zero", torch.equal(bufB[pad:], bufA) and float(bufB[:pad].abs().max()) == 0.0)
 print("RESULT", "ok" if ok else "FAILED")
