@@ -59,3 +59,11 @@ def test_backward_matches_the_oracle_on_random_scenes():
     assert n_bad <= 9, out[-3000:]
     worst = max(float(tok) for tok in line.split("worst per block:")[1].replace(",", " ").split() if tok[0].isdigit())
     assert worst <= 1e-2, out[-3000:]
+
+
+def test_densify_and_prune_cpu_and_gpu_agree_on_random_models():
+    """The CPU path (pinned to the reference's own densify_and_prune by tests/golden/densify.npz) against the HIP compaction on 250
+    random models, thresholds from 'nothing selected' to 'everything pruned'."""
+    out = _run("fuzz_densify_probe.py", 250, 99)
+    assert "cases 250 from seed 99: 0 with differences" in out, out[-3000:]
+
