@@ -67,3 +67,32 @@ def test_densify_and_prune_cpu_and_gpu_agree_on_random_models():
     out = _run("fuzz_densify_probe.py", 250, 99)
     assert "cases 250 from seed 99: 0 with differences" in out, out[-3000:]
 
+
+def test_fused_loss_on_random_shapes():
+    """w3d_l1_ssim_fwd_bwd against the torch restatement of utils/loss_utils.py on 60 random shapes — widths and heights from 1 to
+    ~400 (smaller than the 11-tap window, ragged against the 32 x 32 tiles), 1 or 3 channels, random lambda: value 2e-6, gradient
+    2e-5 of its maximum."""
+    import numpy as np
+    import torch
+    from w3d_amd.loss import photometric_loss, photometric_loss_torch
+    rs = np.random.RandomState(5)
+    for case in range(60):
+        C = int(rs.choice([1, 3]))
+        H = int(rs.choice([1, 2, 5, 11, 12, 31, 32, 33, 64, 97, int(rs.randint(1, 400))]))
+        W = int(rs.choice([1, 3, 10, 11, 21, 32, 33, 63, 65, 130, int(rs.randint(1, 400))]))
+        lam = float(rs.choice([0.0, 0.2, 1.0]))
+        g = torch.Generator().manual_seed(case)
+        gt = torch.rand(C, H, W, generator=g)
+        img = (gt + 0.2 * torch.randn(C, H, W, generator=g)).clamp(0, 1)
+        if case % 3 == 0:
+            img.view(-1)[:: 7] = gt.view(-1)[:: 7]          # exact zeros of |x - y|: sign(0) = 0
+        a = img.clone().requires_grad_(True)
+        ref = photometric_loss_torch(a, gt, lam)
+        ref.backward()
+        b = img.cuda().requires_grad_(True)
+        out = photometric_loss(b, gt.cuda(), lam)
+        out.backward()
+        assert abs(float(out.detach()) - float(ref.detach())) <= 2e-6 * max(1.0, abs(float(ref.detach()))), (case, C, H, W, lam)
+        gerr = float((b.grad.cpu() - a.grad).abs().max() / (a.grad.abs().max() + 1e-30))
+        assert gerr <= 2e-5, (case, C, H, W, lam, gerr)
+
