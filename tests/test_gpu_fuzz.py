@@ -96,3 +96,33 @@ def test_fused_loss_on_random_shapes():
         gerr = float((b.grad.cpu() - a.grad).abs().max() / (a.grad.abs().max() + 1e-30))
         assert gerr <= 2e-5, (case, C, H, W, lam, gerr)
 
+
+def test_knn_on_random_point_clouds():
+    """distCUDA2 (the device grid kNN) against the oracle's brute force on 40 random clouds: uniform, clustered, a lattice with
+    exact duplicates, points on a line, a cloud with one far outlier (one huge grid cell range) — bit-identical."""
+    import numpy as np
+    import torch
+    from simple_knn._C import distCUDA2
+    from oracle.oracle import knn_dist2
+    rs = np.random.RandomState(11)
+    for case in range(40):
+        N = int(rs.choice([1, 2, 3, 4, 5, 64, 257, 1000, 3001]))
+        g = torch.Generator().manual_seed(case)
+        kind = rs.choice(["uniform", "clusters", "lattice", "line", "outlier"])
+        if kind == "uniform":
+            pts = torch.rand(N, 3, generator=g) * float(rs.choice([1e-3, 1.0, 1e3]))
+        elif kind == "clusters":
+            c = torch.randn(5, 3, generator=g) * 10
+            pts = c[torch.randint(0, 5, (N,), generator=g)] + 0.01 * torch.randn(N, 3, generator=g)
+        elif kind == "lattice":
+            pts = torch.randint(0, 4, (N, 3), generator=g).float()               # many exact duplicates
+        elif kind == "line":
+            pts = torch.zeros(N, 3)
+            pts[:, 0] = torch.rand(N, generator=g)
+        else:
+            pts = torch.randn(N, 3, generator=g)
+            pts[0] = torch.tensor([1e4, -1e4, 1e4])
+        ref = knn_dist2(pts.numpy())
+        got = distCUDA2(pts.cuda()).cpu().numpy()
+        assert np.array_equal(got, ref), (case, kind, N, float(np.abs(got - ref).max()))
+
