@@ -43,6 +43,9 @@ namespace {
 #ifndef W3D_BWD_SFORM
 #define W3D_BWD_SFORM 1        // blend backward: the suffix colour carried as its product with dL/dpixel (one scalar per pixel)
 #endif
+#ifndef W3D_FWD_HOIST_IDX
+#define W3D_FWD_HOIST_IDX 1
+#endif
 #ifndef W3D_VCC_SELECT
 #define W3D_VCC_SELECT 1       // per-lane selects of the blend loops through VCC: v_cndmask_b32_e32 issues at full rate, the e64 form
                                // (mask in an SGPR pair — what the compiler picks when several lane masks are alive) at half rate
@@ -287,7 +290,14 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
             todo &= todo - 1ull;
             const uint32_t qm = (uint32_t)__builtin_amdgcn_readlane((int)myq, (int)j);
             const float4 ea = s.a[j], ed = s.d[j], ec = s.c[j];
+#if W3D_FWD_HOIST_IDX
+            // (a VGPR copy made ONCE per entry: handed to the select helper as a scalar, the index is re-materialised by a v_mov in
+            //  every quadrant block)
+            uint32_t contributor;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(contributor) : "s"(base - start + j + 1));
+#else
             const uint32_t contributor = base - start + j + 1;
+#endif
             float wk[4] = {0.f, 0.f, 0.f, 0.f};
             bool any_applied = false;
 #pragma unroll
