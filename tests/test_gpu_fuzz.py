@@ -136,3 +136,16 @@ def test_knn_on_random_point_clouds():
         got = distCUDA2(pts.cuda()).cpu().numpy()
         assert np.array_equal(got, ref), (case, kind, N, float(np.abs(got - ref).max()))
 
+
+def test_sparse_exchange_kernels_on_random_sizes():
+    """pack -> index -> rows_adam against the dense pipeline (apply per view, low-rank SH step, Adam sweep), bit for bit, on
+    16 random (P, SH degree, skipped blocks) — P ragged against every granule of the kernels (64 lanes, 256-lane workgroups,
+    2048-Gaussian pack groups, 4-float block alignment)."""
+    import numpy as np
+    from test_gpu_dist import test_rows_adam_equals_dense_pipeline_three_views as one
+    rs = np.random.RandomState(3)
+    skips = [(), ("opacity",), ("xyz", "f_rest"), ("f_dc", "scaling", "rotation")]
+    for case in range(16):
+        P = int(rs.choice([1, 2, 63, 65, 255, 257, 2047, 2049, 4095, 6001, int(rs.randint(1, 9000))]))
+        one(P, int(rs.randint(4)), skips[int(rs.randint(len(skips)))])
+
