@@ -1,0 +1,210 @@
+"""CPU: w3d_amd.dropin's import redirect.
+
+* against the REAL reference checkout where it exists (/root/reference: this container only — nothing of it travels to the
+  GPU box): `train_vanilla_3dgs.py`, `run_3d_seg.py` and `render.py` are imported UNMODIFIED in fresh interpreters under each
+  of the three ways of switching the redirect on, and the names they bound must be this repo's while every module still comes
+  from the checkout;
+* on the stand-in checkout (tests/standin_checkout) everywhere: redirected / partially redirected / not redirected;
+* the host-side surface the reference's scripts use on the model they get (checkpoint 13-tuple, optimizer groups, deepcopy +
+  prune_points(during_training=False) of run_3d_seg.py:327-346) on CPU tensors.
+"""
+import copy
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "wheat-3dgs_amd")
+REF = "/root/reference"
+needs_ref = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "train_vanilla_3dgs.py")),
+                               reason="the reference checkout exists in the build container only")
+
+# Third-party modules the reference imports and this image lacks (wandb, plyfile, ffmpeg, torchvision, shapely, ...) are
+# replaced by inert stubs — found by retrying on ModuleNotFoundError, never for a module that lives in the checkout.
+PROBE = textwrap.dedent('''
+    import importlib, json, os, sys, types
+    REF = %(ref)r
+    class _Anything(types.ModuleType):
+        __path__ = []
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            m = _Anything(self.__name__ + "." + k); sys.modules[m.__name__] = m
+            return m
+        def __call__(self, *a, **k):
+            return None
+    stubbed = []
+    def imp(name):
+        while True:
+            try:
+                return importlib.import_module(name)
+            except ModuleNotFoundError as e:
+                top = e.name.split(".")[0]
+                assert not os.path.exists(os.path.join(REF, top)) and not os.path.exists(os.path.join(REF, top + ".py")), e
+                sys.modules[e.name] = _Anything(e.name); stubbed.append(e.name)
+                for n in list(sys.modules):
+                    f = getattr(sys.modules[n], "__file__", None) or ""
+                    if f.startswith(REF):
+                        del sys.modules[n]
+    %(activate)s
+    T, S, R = imp("train_vanilla_3dgs"), imp("run_3d_seg"), imp("render")
+    import scene, scene.gaussian_model as G, utils.loss_utils as L, gaussian_renderer as GR, utils.general_utils as U
+    from w3d_amd import dropin
+    own = lambda o: (getattr(o, "__module__", "") or "")
+    print("RESULT " + json.dumps({
+        "train": {k: own(getattr(T, k)) for k in ("GaussianModel", "render", "l1_loss", "ssim", "Scene", "psnr")},
+        "seg": {k: own(getattr(S, k)) for k in ("GaussianModel", "flashsplat_render", "Scene", "multi_instance_opt")},
+        "render": {k: own(getattr(R, k)) for k in ("GaussianModel", "render")},
+        "scene_init": own(scene.GaussianModel),
+        "files": {m.__name__: m.__file__ for m in (T, S, R, scene, G, L, GR, U)},
+        "kept": {"BasicPointCloud": own(G.BasicPointCloud), "l2_loss": own(L.l2_loss), "reference_model": own(G._reference_GaussianModel),
+                 "reference_render": own(GR._reference_render), "reference_ssim": own(L._reference_ssim)},
+        "distCUDA2": own(G.distCUDA2), "rasterizer": own(GR.GaussianRasterizer), "flash": own(GR.FlashSplat_GaussianRasterizer),
+        "status": dropin.status(), "stubbed": stubbed}))
+''')
+
+
+def _check_reference_result(r):
+    assert r["train"] == {"GaussianModel": "w3d_amd.gaussian_model", "render": "w3d_amd.gaussian_renderer",
+                          "l1_loss": "w3d_amd.loss", "ssim": "w3d_amd.loss", "Scene": "scene", "psnr": "utils.image_utils"}
+    assert r["seg"] == {"GaussianModel": "w3d_amd.gaussian_model", "flashsplat_render": "w3d_amd.gaussian_renderer",
+                        "Scene": "scene", "multi_instance_opt": "run_3d_seg"}
+    assert r["render"] == {"GaussianModel": "w3d_amd.gaussian_model", "render": "w3d_amd.gaussian_renderer"}
+    assert r["scene_init"] == "w3d_amd.gaussian_model"
+    assert all(f.startswith(REF + "/") for f in r["files"].values()), r["files"]        # every module is still the checkout's
+    assert r["kept"] == {"BasicPointCloud": "utils.graphics_utils", "l2_loss": "utils.loss_utils",
+                         "reference_model": "scene.gaussian_model", "reference_render": "gaussian_renderer",
+                         "reference_ssim": "utils.loss_utils"}
+    assert r["distCUDA2"] == "w3d_amd.rasterizer" and r["rasterizer"] == "w3d_amd.rasterizer" and r["flash"] == "w3d_amd.rasterizer"
+    assert all(v is True for v in r["status"].values()), r["status"]
+    assert not any(s.split(".")[0] in ("scene", "utils", "gaussian_renderer", "arguments", "w3d_amd", "torch") for s in r["stubbed"])
+
+
+def _run(code, env_extra=None, argv=(), cwd=None):
+    env = dict(os.environ)
+    env.pop("PYTHONPATH", None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, *argv] if argv else [sys.executable, "-c", code], env=env, cwd=cwd, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):]), p
+
+
+@needs_ref
+def test_reference_scripts_resolve_to_this_repo_with_install():
+    """`import w3d_amd.dropin; w3d_amd.dropin.install()` ahead of the checkout's imports."""
+    act = f"sys.path[:0] = [REF, {PKG!r}]\nimport w3d_amd.dropin as d\nd.install()"
+    r, _ = _run(PROBE % {"ref": REF, "activate": act})
+    _check_reference_result(r)
+
+
+@needs_ref
+def test_reference_scripts_resolve_to_this_repo_with_sitecustomize():
+    """PYTHONPATH=<repo>/wheat-3dgs_amd/dropin_site:<repo>/wheat-3dgs_amd — no line of Python added anywhere."""
+    act = "sys.path.insert(0, REF)\nassert 'w3d_amd.dropin' in sys.modules, 'sitecustomize did not run'"
+    r, _ = _run(PROBE % {"ref": REF, "activate": act},
+                {"PYTHONPATH": os.pathsep.join([os.path.join(PKG, "dropin_site"), PKG])}, cwd=REF)
+    _check_reference_result(r)
+
+
+@needs_ref
+def test_reference_scripts_resolve_to_this_repo_with_dash_m(tmp_path):
+    """python -m w3d_amd.dropin <script>: the script runs as __main__ with its directory first on sys.path."""
+    script = tmp_path / "probe_main.py"
+    act = "assert __name__ == '__main__' and sys.argv[1:] == ['--flag', '7'], (__name__, sys.argv)\nsys.path.insert(0, REF)"
+    script.write_text(PROBE % {"ref": REF, "activate": act})
+    r, p = _run(None, {"PYTHONPATH": PKG}, argv=["-m", "w3d_amd.dropin", str(script), "--flag", "7"], cwd=REF)
+    _check_reference_result(r)
+    assert "[w3d_amd.dropin] redirect installed" in p.stderr
+
+
+@needs_ref
+def test_without_the_redirect_the_reference_keeps_its_own_python():
+    """Control: only the rasterizer packages on the path -> the model, render() and the loss are the checkout's."""
+    act = f"sys.path[:0] = [REF, {PKG!r}]"
+    code = (PROBE % {"ref": REF, "activate": act}).replace('"reference_model": own(G._reference_GaussianModel),', "") \
+        .replace('"reference_render": own(GR._reference_render), "reference_ssim": own(L._reference_ssim)', "")
+    r, _ = _run(code)
+    assert r["train"]["GaussianModel"] == "scene.gaussian_model" and r["train"]["render"] == "gaussian_renderer"
+    assert r["train"]["l1_loss"] == "utils.loss_utils" and r["seg"]["flashsplat_render"] == "gaussian_renderer"
+    assert r["rasterizer"] == "w3d_amd.rasterizer" and r["distCUDA2"] == "w3d_amd.rasterizer"
+    assert all(v is False for v in r["status"].values())
+
+
+# ------------------------------------------------------------------ stand-in checkout (runs everywhere)
+def _owners(mod):
+    return {k: getattr(mod, k).__module__ for k in ("GaussianModel", "render", "l1_loss", "ssim")}
+
+
+def test_standin_checkout_redirected_partially_and_not():
+    from util import standin_checkout
+    from w3d_amd import dropin
+    with standin_checkout(False) as m:
+        assert _owners(m) == {"GaussianModel": "scene.gaussian_model", "render": "gaussian_renderer",
+                              "l1_loss": "utils.loss_utils", "ssim": "utils.loss_utils"}
+        assert not dropin.installed()
+    with standin_checkout(True) as m:
+        assert _owners(m) == {"GaussianModel": "w3d_amd.gaussian_model", "render": "w3d_amd.gaussian_renderer",
+                              "l1_loss": "w3d_amd.loss", "ssim": "w3d_amd.loss"}
+        import utils.loss_utils as L
+        assert L.l2_loss.__module__ == "utils.loss_utils" and L._reference_ssim.__module__ == "utils.loss_utils"
+        assert all(dropin.status().values())
+    with standin_checkout(("utils.loss_utils",)) as m:
+        assert _owners(m) == {"GaussianModel": "scene.gaussian_model", "render": "gaussian_renderer",
+                              "l1_loss": "w3d_amd.loss", "ssim": "w3d_amd.loss"}
+    with standin_checkout(("scene.gaussian_model", "gaussian_renderer")) as m:
+        assert _owners(m) == {"GaussianModel": "w3d_amd.gaussian_model", "render": "w3d_amd.gaussian_renderer",
+                              "l1_loss": "utils.loss_utils", "ssim": "utils.loss_utils"}
+    assert not dropin.installed() and "train_loop" not in sys.modules and "scene" not in sys.modules
+    with pytest.raises(ValueError):
+        dropin.install(only=("utils.general_utils",))
+
+
+def test_late_install_patches_in_place_and_warns():
+    from util import standin_checkout
+    from w3d_amd import dropin
+    with standin_checkout(False) as m:
+        with pytest.warns(UserWarning, match="imported before the redirect"):
+            dropin.install()
+        import utils.loss_utils as L
+        assert L.ssim.__module__ == "w3d_amd.loss"            # the module is patched ...
+        assert m.ssim.__module__ == "utils.loss_utils"        # ... a name already bound elsewhere is not (documented)
+
+
+def test_host_surface_the_reference_scripts_use_on_the_model():
+    """What train_vanilla_3dgs.py / run_3d_seg.py do with the object `GaussianModel(sh_degree)` gives them, on CPU tensors:
+    restore() from a checkpoint 13-tuple (:38-40), optimizer groups by name, capture() / torch.save (:117-119), deepcopy +
+    prune_points(mask=..., during_training=False) + save_ply (run_3d_seg.py:327-347)."""
+    from util import checkpoint_tuple
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.synth import small_test_scene
+    sc, _ = small_test_scene(P=37, W=32, H=32, seed=3)
+    opt = OptimizationParams()
+    m = GaussianModel(3, device="cpu")
+    m.restore(checkpoint_tuple(sc, device="cpu"), opt)
+    assert m.active_sh_degree == 3 and len(m.get_xyz) == 37 and m._xyz.shape == (37, 3) and m._features_rest.shape == (37, 15, 3)
+    assert [g["name"] for g in m.optimizer.param_groups] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    assert m.optimizer.param_groups[0]["params"][0] is m._xyz
+    cap = m.capture()
+    assert len(cap) == 13 and set(cap[11]) == {"state", "param_groups"} and cap[12] == 1.0
+    m2 = GaussianModel(3, device="cpu")
+    m2.restore(cap, opt)
+    assert torch.equal(m2.flat, m.flat)
+    # run_3d_seg.py:326-347
+    m._which_object[:11] = 4
+    obj = copy.deepcopy(m)
+    assert obj._xyz.untyped_storage().data_ptr() == obj.flat.untyped_storage().data_ptr() != m.flat.untyped_storage().data_ptr()
+    assert obj.optimizer.model is obj and torch.equal(obj.flat, m.flat)
+    obj.prune_points(mask=torch.flatten(obj.get_which_object.detach() != 4), during_training=False)
+    assert len(obj.get_xyz) == 11 and len(m.get_xyz) == 37
+    assert torch.equal(obj._xyz, m._xyz[:11]) and int((obj.get_which_object == 4).sum()) == 11
+    with torch.no_grad():
+        obj._xyz.add_(1.0)                                     # the parameters of the copy are views of ITS flat buffer
+    a, b = obj.block_slices()["xyz"]
+    assert torch.equal(obj.flat[a:b].view(11, 3), obj._xyz.detach()) and not torch.equal(m._xyz[:11], obj._xyz)

@@ -73,3 +73,49 @@ def needle_scene(seed, P=20000):
     sc.xyz[:, 1] *= 3.0
     sc.opacity[:] = torch.empty(P, 1).normal_(0.0, 2.0, generator=g)
     return sc
+
+
+# ------------------------------------------------------------------ the import redirect on the stand-in checkout
+STANDIN_TOPS = ("scene", "gaussian_renderer", "utils", "train_loop")
+
+
+class standin_checkout:
+    """Context manager: `tests/standin_checkout/` (the reference's module names and import lines, tests/standin_checkout/README.md)
+    first on sys.path, its modules freshly imported — under w3d_amd.dropin's redirect (hook=True: all of it; a tuple: those
+    modules only) or as they are (hook=False: only the rasterizer packages are this repo's).  Yields the `train_loop` module;
+    on exit the redirect is removed and the stand-in's modules are dropped from sys.modules."""
+
+    def __init__(self, hook):
+        self.hook = hook
+
+    def __enter__(self):
+        import importlib
+        import os
+        import sys
+        from w3d_amd import dropin
+        self.dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "standin_checkout")
+        dropin.uninstall(purge=STANDIN_TOPS)
+        sys.path.insert(0, self.dir)
+        if self.hook:
+            dropin.install(only=None if self.hook is True else tuple(self.hook))
+        mod = importlib.import_module("train_loop")
+        assert os.path.dirname(os.path.abspath(mod.__file__)) == self.dir, mod.__file__
+        return mod
+
+    def __exit__(self, *exc):
+        import sys
+        from w3d_amd import dropin
+        dropin.uninstall(purge=STANDIN_TOPS)
+        if self.dir in sys.path:
+            sys.path.remove(self.dir)
+        return False
+
+
+def checkpoint_tuple(sc, sh_degree=3, spatial_lr_scale=1.0, device="cuda"):
+    """A scene's pre-activation blocks as the 13-tuple of reference GaussianModel.capture() (scene/gaussian_model.py:63-79)
+    with no optimizer state: what `--start_checkpoint` hands to restore() (train_vanilla_3dgs.py:38-40)."""
+    P = sc.xyz.shape[0]
+    t = lambda x: x.to(device).float().contiguous()  # noqa: E731
+    return (sh_degree, t(sc.xyz), t(sc.features_dc), t(sc.features_rest), t(sc.scaling), t(sc.rotation), t(sc.opacity),
+            torch.zeros(P, 1, dtype=torch.int, device=device), torch.zeros(P, device=device), torch.zeros(P, 1, device=device),
+            torch.zeros(P, 1, device=device), None, spatial_lr_scale)

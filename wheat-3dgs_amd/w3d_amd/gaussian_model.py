@@ -383,10 +383,35 @@ class GaussianModel:
         else:
             self.xyz_gradient_accum, self.denom, self.max_radii2D = stats
 
-    def prune_points(self, mask):
-        """reference :340-354 — drops the rows where mask is True, keeps the statistics of the survivors."""
+    def prune_points(self, mask, during_training=True):
+        """reference :328-352 — drops the rows where mask is True, keeps the statistics of the survivors.
+        `during_training=False` (run_3d_seg.py:334,346: one object's Gaussians cut out of a deepcopy for its PLY) leaves the
+        optimizer alone there; here parameters and moments share one compaction pass, so both flavours take it."""
         src = (~mask).nonzero().squeeze(1)
         self._compact(src, n_keep=src.numel(), reset_stats=False)
+
+    def __deepcopy__(self, memo):
+        """run_3d_seg.py:327 deep-copies the model per identified object.  The generic deepcopy would clone every
+        nn.Parameter on its own and break the invariant that they are VIEWS of the flat buffers; this one copies the flat
+        buffers and rebinds.  Per-call caches kept on the model (scratch buffers, capacity hints, streams) are not copied."""
+        new = GaussianModel(self.max_sh_degree, device=self.device)
+        memo[id(self)] = new
+        for k in ("active_sh_degree", "tile_cull", "deterministic", "percent_dense", "spatial_lr_scale", "_train_args"):
+            setattr(new, k, getattr(self, k))
+        if self.num_points:
+            new._bind({n: p.detach() for n, p in self._p.items()})
+            new.flat_grad.copy_(self.flat_grad)
+            for n, p in self._p.items():
+                if p.grad is None:
+                    new._p[n].grad = None
+        new._which_object = self._which_object.clone()
+        new.max_radii2D, new.xyz_gradient_accum, new.denom = (self.max_radii2D.clone(), self.xyz_gradient_accum.clone(),
+                                                              self.denom.clone())
+        if self.optimizer is not None:
+            opt = self.optimizer
+            new.training_setup(self._train_args, moments=(opt.exp_avg.clone(), opt.exp_avg_sq.clone(), dict(opt.steps)))
+            new.optimizer.lrs.update(opt.lrs)
+        return new
 
     def _split_children(self, sel_idx, N):
         """xyz and (raw) scaling of the N children of every selected Gaussian, reference :407-414 (same torch.normal

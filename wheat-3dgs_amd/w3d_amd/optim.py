@@ -100,9 +100,18 @@ class FlatAdam:
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, d):
-        if "param_groups" not in d:      # round-1 flat layout
-            self.exp_avg.copy_(d["exp_avg"])
-            self.exp_avg_sq.copy_(d["exp_avg_sq"])
+        if "param_groups" not in d:      # round-1 flat layout: the blocks back to back, no alignment padding (59*P floats)
+            from .gaussian_model import BLOCKS
+            P, sl = self.model.num_points, self.model.block_slices()
+            dims = [(n, P * int(torch.Size(s).numel())) for n, s in BLOCKS]
+            if d["exp_avg"].numel() != sum(k for _, k in dims) or d["exp_avg_sq"].numel() != d["exp_avg"].numel():
+                raise ValueError(f"FlatAdam.load_state_dict: a flat-layout checkpoint of {d['exp_avg'].numel()} floats does not "
+                                 f"belong to a model of {P} Gaussians ({sum(k for _, k in dims)} expected)")
+            for dst, src in ((self.exp_avg, d["exp_avg"].reshape(-1)), (self.exp_avg_sq, d["exp_avg_sq"].reshape(-1))):
+                off = 0
+                for n, k in dims:
+                    dst[sl[n][0]:sl[n][1]].copy_(src[off:off + k])
+                    off += k
             self._set_steps(d["step"])
             self.lrs.update(d["lrs"])
             return
