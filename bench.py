@@ -14,10 +14,10 @@ weak scaling) and the ranks exchange gradients over RCCL; `value` counts views/s
       the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
 Prints ONE JSON line on rank 0.  `value` is the fused raw-parameter step (the repo's own trainer);
-`dropin_iters_per_s` is the UNMODIFIED reference loop body (train_vanilla_3dgs.py:55-115 statement by
+`dropin_iters_per_s` is the UNMODIFIED reference loop (train_vanilla_3dgs.py:16-18,55-115 statement by
 statement: render() -> l1_loss / ssim -> loss.backward() -> loss.item() -> max_radii2D / add_densification_stats
--> optimizer.step() -> zero_grad(set_to_none=True)) on this package's render / GaussianModel / loss_utils
-drop-ins; `trained_scene` repeats the headline measurement after 3000 more training steps (fixed P).
+-> optimizer.step() -> zero_grad(set_to_none=True)) under the import redirect w3d_amd.dropin.install(), and
+`modules_only_iters_per_s` the same script without it (only the rasterizer packages swapped); `trained_scene` repeats the headline measurement after 3000 more training steps (fixed P).
 """
 import argparse
 import ctypes
@@ -422,77 +422,49 @@ def cpu_baseline(args, own_view0=None):
 
 
 # ------------------------------------------------------------------------------------------------ drop-in loop
-def reference_loop(model, opt, cams, bg, pipe, first_iter, n_steps, perm, iter_events=None, loss_fns=None):
-    """The loop body of reference train_vanilla_3dgs.py:55-115, statement by statement (logging, saving and the
-    densification branch — not due in these iterations — left out; cameras cycled instead of randint), on this package's
-    drop-ins for the names that script imports: render (gaussian_renderer), GaussianModel (scene), l1_loss / ssim
-    (utils.loss_utils).  Returns the last loss value."""
-    from w3d_amd.gaussian_renderer import render
-    from w3d_amd.loss import l1_loss, ssim
-    if loss_fns is not None:                        # (time_modules_only: the reference's torch formulas)
-        l1_loss, ssim = loss_fns
-    gaussians, background = model, bg
-    ema_loss_for_log = 0.0
-    for iteration in range(first_iter, first_iter + n_steps):
-        gaussians.update_learning_rate(iteration)
-        if iteration % 1000 == 0:
-            gaussians.oneupSHdegree()
-        viewpoint_cam = cams[perm[(iteration - 1) % len(cams)]]
-        if iter_events is not None:                 # iter_start.record() of train_vanilla_3dgs.py:56
-            iter_events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
-            iter_events[-1][0].record()
-        render_pkg = render(viewpoint_cam, gaussians, pipe, background)
-        image, viewspace_point_tensor, visibility_filter, radii = (render_pkg["render"], render_pkg["viewspace_points"],
-                                                                   render_pkg["visibility_filter"], render_pkg["radii"])
-        gt_image = viewpoint_cam.original_image.cuda()
-        Ll1 = l1_loss(image, gt_image)
-        loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, gt_image))
-        loss.backward()
-        if iter_events is not None:                 # iter_end.record() :82 — the reference's own `iter_time` bracket
-            iter_events[-1][1].record()
-        with torch.no_grad():
-            ema_loss_for_log = 0.4 * loss.item() + 0.6 * ema_loss_for_log
-            if iteration < opt.densify_until_iter:
-                gaussians.max_radii2D[visibility_filter] = torch.max(gaussians.max_radii2D[visibility_filter],
-                                                                     radii[visibility_filter])
-                gaussians.add_densification_stats(viewspace_point_tensor, visibility_filter)
-            if iteration < opt.iterations:
-                gaussians.optimizer.step()
-                gaussians.optimizer.zero_grad(set_to_none=True)
-    return ema_loss_for_log
-
-
-def time_dropin(args, sc, cams, bg, dev, perm, loss_fns=None, n=None):
-    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+def time_standin(args, sc, cams, bg, dev, perm, hook, n, warm):
+    """tests/standin_checkout/train_loop.py — the import lines and the loop body of reference train_vanilla_3dgs.py:16-18,55-115,
+    statement by statement, starting from a checkpoint 13-tuple as --start_checkpoint does (:38-40) — timed as a whole
+    (loss.item() and the boolean-mask statistics lines, i.e. the reference loop's host syncs, included).  The GPU box has no
+    reference checkout, so the script imports its GaussianModel / render / l1_loss / ssim from the stand-in modules of the same
+    names (tests/standin_checkout/README.md: six nn.Parameters with torch activations, torch.optim.Adam over six groups,
+    render() marshalling into `diff_gaussian_rasterization`, conv2d SSIM).  hook=False: as it is — only the rasterizer packages
+    are this repo's (INTEGRATION.md section 1 without the redirect).  hook=True: under w3d_amd.dropin.install() — the same
+    unmodified script and modules, the four names redirected to this repo's fast path.  A tuple: only those modules."""
+    from util import standin_checkout, checkpoint_tuple
+    from w3d_amd.gaussian_model import OptimizationParams
     from w3d_amd.train import PipelineParams
+    opt, pipe = OptimizationParams(), PipelineParams()
+    with standin_checkout(hook) as loop:
+        owners = {k: getattr(loop, k).__module__ for k in ("GaussianModel", "render", "l1_loss", "ssim")}
+        g, _ = loop.training(checkpoint_tuple(sc, device=dev), opt, pipe, cams, bg, perm, 1, warm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop.training(None, opt, pipe, cams, bg, perm, 1 + warm, n, gaussians=g)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # the reference's own timer (TensorBoard `iter_time`, train_vanilla_3dgs.py:56,82,149): CUDA/HIP events around
+        # render + loss + backward — a separate short run, so the event pairs do not sit in the timed loop above
+        ev = []
+        loop.training(None, opt, pipe, cams, bg, perm, 1 + warm + n, min(n, 36), gaussians=g, iter_events=ev)
+        torch.cuda.synchronize()
+        iter_ms = sorted(a.elapsed_time(b) for a, b in ev)
+        del g
+    torch.cuda.empty_cache()
+    return {"iters_per_s": round(n / dt, 2), "ms_per_step": round(1e3 * dt / n, 4), "steps": n,
+            "iter_time_ms_median": round(iter_ms[len(iter_ms) // 2], 4), "resolved": owners}
+
+
+def time_dropin(args, sc, cams, bg, dev, perm, n=None):
+    """The unmodified loop script under the import redirect (w3d_amd.dropin.install())."""
     if n is None:
         n = args.steps if args.dropin_steps < 0 else args.dropin_steps
     if n <= 0:
         return None
-    model = GaussianModel(3, device=dev)
-    model.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
-    model.active_sh_degree = 3
-    opt = OptimizationParams()
-    model.training_setup(opt)
-    pipe = PipelineParams()
-    w = max(3, min(args.warmup, 10))
-    reference_loop(model, opt, cams, bg, pipe, 1, w, perm, loss_fns=loss_fns)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    reference_loop(model, opt, cams, bg, pipe, 1 + w, n, perm, loss_fns=loss_fns)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    # the reference's own timer (TensorBoard `iter_time`, train_vanilla_3dgs.py:56,82,149): CUDA/HIP events around
-    # render + loss + backward — a separate short run, so the event pairs do not sit in the timed loop above
-    ev = []
-    reference_loop(model, opt, cams, bg, pipe, 1 + w + n, min(n, 36), perm, iter_events=ev, loss_fns=loss_fns)
-    torch.cuda.synchronize()
-    iter_ms = sorted(a.elapsed_time(b) for a, b in ev)
-    del model
-    torch.cuda.empty_cache()
-    return {"iters_per_s": round(n / dt, 2), "ms_per_step": round(1e3 * dt / n, 4), "steps": n,
-            "iter_time_ms_median": round(iter_ms[len(iter_ms) // 2], 4),
-            "iter_time": "HIP events around render + loss + backward, the bracket of train_vanilla_3dgs.py:56,82 (no optimizer step)"}
+    out = time_standin(args, sc, cams, bg, dev, perm, True, n, max(3, min(args.warmup, 10)))
+    assert all(v.startswith("w3d_amd.") for v in out["resolved"].values()), out["resolved"]
+    out["iter_time"] = "HIP events around render + loss + backward, the bracket of train_vanilla_3dgs.py:56,82 (no optimizer step)"
+    return out
 
 
 
@@ -780,99 +752,25 @@ def densified_scene(args, dev, bg, log):
 
 
 # ------------------------------------------------------------------------------------------------ modules-only loop
-class RefStyleModel:
-    """INTEGRATION.md section 1 AS WRITTEN: the user only puts the three rasterizer packages on PYTHONPATH and keeps the
-    reference's own GaussianModel.  This is that model's training-time surface restated for the measurement (six
-    nn.Parameters with torch activations — scene/gaussian_model.py:33-41,101-121 —, torch.optim.Adam over six groups with
-    eps 1e-15 — :172-186 —, add_densification_stats :461-463); it is NOT this package's flat model."""
-
-    def __init__(self, sc, opt, dev):
-        import torch.nn as nn
-        self.max_sh_degree, self.active_sh_degree = 3, 3
-        self._xyz = nn.Parameter(sc.xyz.to(dev).contiguous().requires_grad_(True))
-        self._features_dc = nn.Parameter(sc.features_dc.to(dev).contiguous().requires_grad_(True))
-        self._features_rest = nn.Parameter(sc.features_rest.to(dev).contiguous().requires_grad_(True))
-        self._scaling = nn.Parameter(sc.scaling.to(dev).contiguous().requires_grad_(True))
-        self._rotation = nn.Parameter(sc.rotation.to(dev).contiguous().requires_grad_(True))
-        self._opacity = nn.Parameter(sc.opacity.to(dev).contiguous().requires_grad_(True))
-        P = sc.xyz.shape[0]
-        self.max_radii2D = torch.zeros(P, device=dev)
-        self.xyz_gradient_accum = torch.zeros(P, 1, device=dev)
-        self.denom = torch.zeros(P, 1, device=dev)
-        groups = [{"params": [self._xyz], "lr": opt.position_lr_init, "name": "xyz"},
-                  {"params": [self._features_dc], "lr": opt.feature_lr, "name": "f_dc"},
-                  {"params": [self._features_rest], "lr": opt.feature_lr / 20.0, "name": "f_rest"},
-                  {"params": [self._opacity], "lr": opt.opacity_lr, "name": "opacity"},
-                  {"params": [self._scaling], "lr": opt.scaling_lr, "name": "scaling"},
-                  {"params": [self._rotation], "lr": opt.rotation_lr, "name": "rotation"}]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
-        from w3d_amd.gaussian_model import get_expon_lr_func
-        self._xyz_lr = get_expon_lr_func(opt.position_lr_init, opt.position_lr_final, lr_delay_mult=opt.position_lr_delay_mult,
-                                         max_steps=opt.position_lr_max_steps)
-
-    get_xyz = property(lambda self: self._xyz)
-    get_scaling = property(lambda self: torch.exp(self._scaling))
-    get_rotation = property(lambda self: torch.nn.functional.normalize(self._rotation))
-    get_opacity = property(lambda self: torch.sigmoid(self._opacity))
-    get_features = property(lambda self: torch.cat((self._features_dc, self._features_rest), dim=1))
-
-    def update_learning_rate(self, iteration):
-        for g in self.optimizer.param_groups:
-            if g["name"] == "xyz":
-                g["lr"] = self._xyz_lr(iteration)
-
-    def oneupSHdegree(self):
-        self.active_sh_degree = min(self.active_sh_degree + 1, self.max_sh_degree)
-
-    def add_densification_stats(self, viewspace_point_tensor, update_filter):
-        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
-        self.denom[update_filter] += 1
-
-
 def time_modules_only(args, sc, cams, bg, dev, perm):
-    """The reference loop body (reference_loop) with ONLY the rasterizer module swapped: the reference's own render()
-    marshalling through diff_gaussian_rasterization.GaussianRasterizer on ACTIVATED tensors (this package's render() takes
-    exactly that branch for a model that is not its flat GaussianModel), RefStyleModel's torch activations / six-group
-    torch.optim.Adam, and the reference's loss formulas with torch ops (l1 = mean |a - b|, conv2d SSIM)."""
-    from w3d_amd.gaussian_model import OptimizationParams
-    from w3d_amd.train import PipelineParams
-    from w3d_amd import loss as L
+    """The same loop script WITHOUT the redirect — INTEGRATION.md section 1's first step alone: only the three rasterizer
+    packages on the path are this repo's; the model (six nn.Parameters, torch activations, six-group torch.optim.Adam), render()'s
+    marshalling and the conv2d SSIM are the checkout's own Python — then with the redirect on for the loss module only, for the
+    model + render modules only, and (time_dropin) for all of them."""
     n = min(args.steps, 60) if args.modules_only_steps < 0 else args.modules_only_steps
     if n <= 0:
         return None
-    opt = OptimizationParams()
-    pipe = PipelineParams()
-    torch_l1 = lambda a, b: torch.abs(a - b).mean()          # noqa: E731  (utils/loss_utils.py:17-18)
-    torch_fns = (torch_l1, L.ssim_torch)
     w = max(3, min(args.warmup, 6))
-
-    def run(fns):
-        model = RefStyleModel(sc, opt, dev)
-        reference_loop(model, opt, cams, bg, pipe, 1, w, perm, loss_fns=fns)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reference_loop(model, opt, cams, bg, pipe, 1 + w, n, perm, loss_fns=fns)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        ev = []
-        reference_loop(model, opt, cams, bg, pipe, 1 + w + n, min(n, 20), perm, iter_events=ev, loss_fns=fns)
-        torch.cuda.synchronize()
-        iter_ms = sorted(a.elapsed_time(b) for a, b in ev)
-        del model
-        torch.cuda.empty_cache()
-        return n / dt, iter_ms[len(iter_ms) // 2]
-    base, base_iter = run(torch_fns)
-    out = {"iters_per_s": round(base, 2), "ms_per_step": round(1e3 / base, 4), "steps": n,
-           "iter_time_ms_median": round(base_iter, 4),
-           "what": "INTEGRATION.md section 1 as written: only diff_gaussian_rasterization is this repo's; six nn.Parameters with "
-                   "torch exp / sigmoid / normalize / cat, torch.optim.Adam (6 groups), torch conv2d SSIM, the reference loop's "
-                   "host syncs"}
-    # which of the other swaps buys what (same loop, one more module of this repo at a time)
+    base = time_standin(args, sc, cams, bg, dev, perm, False, n, w)
+    assert not any(v.startswith("w3d_amd.") for v in base["resolved"].values()), base["resolved"]
+    out = dict(base, what="tests/standin_checkout/train_loop.py as it is, no import redirect: only diff_gaussian_rasterization is this "
+                          "repo's; six nn.Parameters with torch exp / sigmoid / normalize / cat, torch.optim.Adam (6 groups), torch "
+                          "conv2d SSIM, the reference loop's host syncs")
+    # which of the other swaps buys what (same script, the redirect switched on for one part at a time)
     try:
-        plus_loss, _ = run(None)                                  # + utils.loss_utils -> w3d_amd.loss (fused L1 + SSIM pair)
-        out["plus_loss_module_iters_per_s"] = round(plus_loss, 2)
-        d = time_dropin(args, sc, cams, bg, dev, perm, loss_fns=torch_fns, n=n)     # + scene.GaussianModel / render, torch loss
-        out["plus_model_and_render_modules_iters_per_s"] = d["iters_per_s"]
+        out["redirect_loss_module_only_iters_per_s"] = time_standin(args, sc, cams, bg, dev, perm, ("utils.loss_utils",), n, w)["iters_per_s"]
+        out["redirect_model_and_render_only_iters_per_s"] = time_standin(args, sc, cams, bg, dev, perm,
+                                                                         ("scene.gaussian_model", "gaussian_renderer"), n, w)["iters_per_s"]
     except Exception as e:
         out["breakdown_error"] = repr(e)
     return out
@@ -1231,11 +1129,15 @@ def main():
         }
         out.update(extras)
         if dropin is not None:
-            out["dropin"] = dict(dropin, loop="reference train_vanilla_3dgs.py:55-115 body on the drop-in render / "
-                                              "GaussianModel / l1_loss / ssim; loss.item() and the boolean-mask statistics "
-                                              "lines (host syncs of the reference loop) included")
+            out["dropin"] = dict(dropin, loop="tests/standin_checkout/train_loop.py (import lines + loop body of reference "
+                                              "train_vanilla_3dgs.py:16-18,55-115) UNMODIFIED under w3d_amd.dropin.install(): render / "
+                                              "GaussianModel / l1_loss / ssim redirected to this repo; loss.item() and the "
+                                              "boolean-mask statistics lines (host syncs of the reference loop) included")
         if modules_only is not None:
             out["modules_only"] = modules_only
+            if dropin is not None and "iters_per_s" in modules_only:
+                out["modules_only"]["with_redirect_iters_per_s"] = dropin["iters_per_s"]
+                out["modules_only"]["redirect_speedup"] = round(dropin["iters_per_s"] / modules_only["iters_per_s"], 2)
         if trained is not None:
             out["trained_scene"] = trained
         if densified is not None:

@@ -93,8 +93,11 @@ def test_redirected_loop_continues_from_a_reference_style_checkpoint_and_back():
         assert type(g2).__module__ == "w3d_amd.gaussian_model"
         assert [int(s["step"]) for s in g2.capture()[11]["state"].values()] == [8] * 6
         cap_b = _fresh(g2.capture())
+        losses_b = []
+        loop.training(None, opt, PipelineParams(), cams, bg, perm, 9, 2, gaussians=g2, losses=losses_b)
     assert np.allclose(losses, losses_ref, rtol=2e-4, atol=2e-6), (losses, losses_ref)
     with standin_checkout(False) as loop:
         losses_c = []
         g3, _ = loop.training(cap_b, opt, PipelineParams(), cams, bg, perm, 9, 2, losses=losses_c)
-        assert type(g3).__module__ == "scene.gaussian_model" and np.isfinite(losses_c).all() and losses_c[-1] < losses_ref[0]
+        assert type(g3).__module__ == "scene.gaussian_model"
+    assert np.allclose(losses_c, losses_b, rtol=2e-4, atol=2e-6), (losses_c, losses_b)
