@@ -108,9 +108,9 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
 #include <stddef.h>
 #include "w3d.h"
 int main(void) {
-    printf("view %zu %zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(w3d_view), offsetof(w3d_view, bg), offsetof(w3d_view, tile_cull),
+    printf("view %zu %zu %zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(w3d_view), offsetof(w3d_view, bg), offsetof(w3d_view, tile_cull),
            offsetof(w3d_view, deterministic), offsetof(w3d_view, det_list_capacity), offsetof(w3d_view, tile_walk_hint),
-           offsetof(w3d_view, records_kept_clean), offsetof(w3d_view, struct_size), W3D_ABI_VERSION);
+           offsetof(w3d_view, records_kept_clean), offsetof(w3d_view, list_share), offsetof(w3d_view, struct_size), W3D_ABI_VERSION);
     printf("raw %zu %zu\\n", sizeof(w3d_raw_params), sizeof(w3d_raw_grads));
     printf("stats %zu\\n", sizeof(w3d_densify_stats));
     printf("adam %zu %zu %zu %zu\\n", sizeof(w3d_adam_fused), offsetof(w3d_adam_fused, lr), offsetof(w3d_adam_fused, beta1),
@@ -123,7 +123,8 @@ int main(void) {
     out = dict((ln.split()[0], [int(x) for x in ln.split()[1:]]) for ln in subprocess.check_output([str(exe)], text=True).splitlines())
     V = _lib.W3DView
     assert out["view"] == [ctypes.sizeof(V), V.bg.offset, V.tile_cull.offset, V.deterministic.offset, V.det_list_capacity.offset,
-                           V.tile_walk_hint.offset, V.records_kept_clean.offset, V.struct_size.offset, _lib.lib.w3d_version()]
+                           V.tile_walk_hint.offset, V.records_kept_clean.offset, V.list_share.offset, V.struct_size.offset,
+                           _lib.lib.w3d_version()]
     assert V().struct_size == ctypes.sizeof(V) and out["view"][-1] // 100 == _lib.ABI_MAJOR
     assert out["raw"] == [ctypes.sizeof(fused_step.W3DRawParams), ctypes.sizeof(fused_step.W3DRawGrads)]
     assert out["stats"] == [ctypes.sizeof(fused_step.W3DDensifyStats)]

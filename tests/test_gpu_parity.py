@@ -23,25 +23,28 @@ from w3d_amd.synth import small_test_scene, make_scene, make_cameras
 pytestmark = pytest.mark.gpu
 
 
-def _settings(cam, bg, sh_degree, scale_modifier, dev, flash=None, tile_cull=True):
+def _settings(cam, bg, sh_degree, scale_modifier, dev, flash=None, tile_cull=True, list_share=None):
     from w3d_amd.rasterizer import GaussianRasterizationSettings, FlashSplatRasterizationSettings
     kw = dict(image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
               tanfovy=math.tan(cam.FoVy * 0.5), bg=torch.tensor(bg, dtype=torch.float32, device=dev),
               scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform.to(dev),
               projmatrix=cam.full_proj_transform.to(dev), sh_degree=sh_degree, campos=cam.camera_center.to(dev),
               prefiltered=False, debug=False, tile_cull=tile_cull)
+    if list_share is not None:
+        kw["list_share"] = list_share
     if flash is None:
         return GaussianRasterizationSettings(**kw)
     return FlashSplatRasterizationSettings(**kw, mask_grad=False, num_obj=flash)
 
 
-def run_hip(d, cam, bg, sh_degree=3, scale_modifier=1.0, grads=None, tile_cull=True):
+def run_hip(d, cam, bg, sh_degree=3, scale_modifier=1.0, grads=None, tile_cull=True, list_share=None):
     """forward (+ backward with the given image gradients) on cuda:0 through the drop-in module."""
     from diff_gaussian_rasterization import GaussianRasterizer
     dev = torch.device("cuda:0")
     t = {k: (None if v is None else v.to(dev).requires_grad_(True)) for k, v in d.items()}
     means2D = torch.zeros_like(t["means3D"], requires_grad=True)
-    rast = GaussianRasterizer(raster_settings=_settings(cam, bg, sh_degree, scale_modifier, dev, tile_cull=tile_cull))
+    rast = GaussianRasterizer(raster_settings=_settings(cam, bg, sh_degree, scale_modifier, dev, tile_cull=tile_cull,
+                                                        list_share=list_share))
     color, radii, depth, alpha = rast(means3D=t["means3D"], means2D=means2D, shs=t["shs"],
                                       colors_precomp=t["colors_precomp"], opacities=t["opacities"],
                                       scales=t["scales"], rotations=t["rotations"], cov3D_precomp=t["cov3D_precomp"])
@@ -93,19 +96,24 @@ def check_integers(out, o, ref):
 
 
 def check_culled_lists(out, o, ref, W, H):
-    """tile_cull on: every per-tile list is a SUBSEQUENCE of the oracle's (order preserved) and every
-    dropped (Gaussian, tile) instance has alpha < 1/255 on all pixels of the tile under the oracle's own
-    formula — i.e. it could not have contributed."""
+    """tile_cull on: the list every tile reads — its own, or with list_share the one it shares with the other tiles of its
+    list cell — holds the oracle's entries of that tile IN THE ORACLE'S ORDER except for dropped ones, every dropped
+    (Gaussian, tile) instance has alpha < 1/255 on all pixels of the tile under the oracle's own formula — i.e. it could not
+    have contributed —, and a list holds nothing but entries of the oracle's lists of the tiles that read it (for an unshared
+    list: it is a SUBSEQUENCE of the oracle's)."""
     np.testing.assert_array_equal(out["radii"], ref["radii"])
     ranges, pl = o.binning()
     g = o.geom()
     gx = (W + 15) // 16
     dropped = 0
+    readers = {}
     for t, ((b, e), (cb, ce)) in enumerate(zip(ranges, out["ranges"])):
         full, kept = pl[b:e], out["point_list"][cb:ce]
-        it = iter(full.tolist())
-        assert all(any(k == f for f in it) for k in kept.tolist()), f"tile {t}: culled list is not a subsequence"
-        gone = np.setdiff1d(full, kept)
+        if ce > cb:
+            readers.setdefault((int(cb), int(ce)), []).append(full)
+        here = np.isin(full, kept)
+        assert np.array_equal(kept[np.isin(kept, full)], full[here]), f"tile {t}: the list read is not in the oracle's order"
+        gone = full[~here]
         if gone.size == 0:
             continue
         dropped += gone.size
@@ -117,6 +125,10 @@ def check_culled_lists(out, o, ref, W, H):
         power = -0.5 * (co[:, 0, None, None] * dx * dx + co[:, 2, None, None] * dy * dy) - co[:, 1, None, None] * dx * dy
         alpha = np.where(power > 0, 0.0, co[:, 3, None, None] * np.exp(np.minimum(power, 0.0)))
         assert alpha.max() < 1.0 / 255.0, f"tile {t}: a dropped instance reaches alpha {alpha.max():.5f}"
+    for (cb, ce), fulls in readers.items():
+        kept = out["point_list"][cb:ce]
+        assert len(fulls) <= 4 and np.unique(kept).size == kept.size, f"list [{cb}, {ce}): {len(fulls)} readers / duplicate entries"
+        assert np.isin(kept, np.concatenate(fulls)).all(), f"list [{cb}, {ce}) holds an entry none of its tiles' oracle lists has"
     return dropped
 
 
@@ -173,12 +185,20 @@ def test_forward_backward_parity(P, W, H, deg, pc, pcov, bg, mod, da):
         vis = ref["radii"] > 0
         assert vis.sum() > 0.5 * P
         ft, nc = o.pixel_state()
-        for cull in (False, True):
-            out, g = run_hip(d, cam, bg, sh_degree=deg, scale_modifier=mod, grads=(gc, gd, ga), tile_cull=cull)
-            tag = f"[P={P} {W}x{H} deg={deg} cam={ci} cull={cull}] "
+        base = None
+        for cull, share in ((False, 0), (True, 0), (True, 1), (True, 2)):
+            out, g = run_hip(d, cam, bg, sh_degree=deg, scale_modifier=mod, grads=(gc, gd, ga), tile_cull=cull, list_share=share)
+            tag = f"[P={P} {W}x{H} deg={deg} cam={ci} cull={cull} share={share}] "
             if cull:
                 dropped = check_culled_lists(out, o, ref, W, H)
-                assert dropped > 0.1 * o.num_rendered(), "culling removed suspiciously little"
+                if share == 0:
+                    assert dropped > 0.1 * o.num_rendered(), "culling removed suspiciously little"
+                    base = out
+                else:
+                    # shared lists (w3d_view.list_share) change which list a tile reads, never what it blends
+                    assert out["num_rendered"] < base["num_rendered"], tag
+                    for k in ("color", "depth", "alpha", "final_T", "radii"):
+                        assert np.array_equal(out[k], base[k]), tag + f"{k} differs from the unshared lists' result"
             else:
                 check_integers(out, o, ref)
                 assert (out["n_contrib"] != nc).mean() <= 2e-3       # state kept for backward
@@ -282,13 +302,14 @@ def test_large_and_odd_frames(W, H, P, scale):
     out, g = run_hip(d, cam, bg, tile_cull=False, grads=(torch.from_numpy(gc), None, None))
     check_integers(out, o, ref)
     check_images(out, ref, f"[{W}x{H}] ")
-    out2, g2 = run_hip(d, cam, bg, tile_cull=True, grads=(torch.from_numpy(gc), None, None))
-    assert check_culled_lists(out2, o, ref, W, H) > 0
-    for k in ("color", "depth", "alpha"):
-        assert np.array_equal(out[k], out2[k]), f"{k} changes under the culls"
     vis = ref["radii"] > 0
     check_grads(g, gref, vis, f"[{W}x{H}] ", tol=3e-3)
-    check_grads(g2, gref, vis, f"[{W}x{H}, culled] ", tol=3e-3)
+    for share in (0, 1, 2):         # (ragged list cells: an odd number of tile columns / rows)
+        out2, g2 = run_hip(d, cam, bg, tile_cull=True, grads=(torch.from_numpy(gc), None, None), list_share=share)
+        assert check_culled_lists(out2, o, ref, W, H) > 0
+        for k in ("color", "depth", "alpha"):
+            assert np.array_equal(out[k], out2[k]), f"{k} changes under the culls (list_share {share})"
+        check_grads(g2, gref, vis, f"[{W}x{H}, culled, share {share}] ", tol=3e-3)
     o.free()
 
 
@@ -308,16 +329,20 @@ def test_culls_are_exact_on_needles(seed):
     for ci, cam in enumerate(make_cameras(3, W, H)):
         d = view_inputs(sc, cam)
         a, _ = run_hip(d, cam, bg, tile_cull=False)
-        b, _ = run_hip(d, cam, bg, tile_cull=True)
-        assert b["num_rendered"] < 0.8 * a["num_rendered"]          # the culls do remove a lot here
-        for k in ("color", "depth", "alpha", "radii"):
-            assert np.array_equal(a[k], b[k]), f"view {ci}: {k} changes under the culls " \
-                f"({int((a[k] != b[k]).sum())} elements, max {np.abs(a[k].astype(np.float64) - b[k]).max():.2e})"
+        o = None
         if ci == 0:
             o = make_oracle(cam, bg, nthreads=8)
             ref = o.forward(**np_inputs(d))
             check_integers(a, o, ref)
-            assert check_culled_lists(b, o, ref, W, H) > 0
+        for share in (0, 1, 2):
+            b, _ = run_hip(d, cam, bg, tile_cull=True, list_share=share)
+            assert b["num_rendered"] < 0.8 * a["num_rendered"]          # the culls do remove a lot here
+            for k in ("color", "depth", "alpha", "radii"):
+                assert np.array_equal(a[k], b[k]), f"view {ci}, list_share {share}: {k} changes under the culls " \
+                    f"({int((a[k] != b[k]).sum())} elements, max {np.abs(a[k].astype(np.float64) - b[k]).max():.2e})"
+            if o is not None:
+                assert check_culled_lists(b, o, ref, W, H) > 0
+        if o is not None:
             o.free()
 
 

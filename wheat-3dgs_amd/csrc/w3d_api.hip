@@ -63,6 +63,7 @@ static int check_view(const w3d_view *v) {
     if (v->image_height <= 0 || v->image_width <= 0) { w3d_set_error("image size must be positive"); return W3D_ERR_INVALID; }
     if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos) { w3d_set_error("view holds a NULL device pointer"); return W3D_ERR_INVALID; }
     if (v->sh_degree < 0 || v->sh_degree > 3) { w3d_set_error("sh_degree %d unsupported (0..3)", v->sh_degree); return W3D_ERR_UNSUPPORTED; }
+    if (v->list_share < 0 || v->list_share > 2) { w3d_set_error("list_share %d unsupported (0..2)", v->list_share); return W3D_ERR_UNSUPPORTED; }
     return W3D_OK;
 }
 
@@ -156,6 +157,7 @@ int w3d_forward_stage1(const w3d_view *view, int32_t P, const float *means3D, co
     W3DLayout L;
     rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
     if (rc) { w3d_set_error("bad sizes"); return rc; }
+    w3d_set_list_share(&L, view);
     if (!state || !scratch) { w3d_set_error("state/scratch is NULL"); return W3D_ERR_INVALID; }
     if (P > 0) {
         if (!means3D || !opacities || !radii) { w3d_set_error("means3D/opacities/radii is NULL"); return W3D_ERR_INVALID; }
@@ -180,6 +182,7 @@ int w3d_forward_stage2(const w3d_view *view, int32_t P, void *state, void *scrat
     W3DLayout L;
     rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
     if (rc) { w3d_set_error("bad sizes"); return rc; }
+    w3d_set_list_share(&L, view);
     if (!state || !scratch || !out_color) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
     const bool flash_out = gt_mask || used_count || contrib_num;
     if ((out_depth == nullptr) != (out_alpha == nullptr) || (flash_out && !out_depth)) {
@@ -211,6 +214,7 @@ int w3d_flash_reblend(const w3d_view *view, int32_t P, void *state, const uint32
     W3DLayout L;
     rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
     if (rc) { w3d_set_error("bad sizes"); return rc; }
+    w3d_set_list_share(&L, view);
     if (!state || !out_color || !out_depth || !out_alpha) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
     if (list_capacity > 0 && !point_list) { w3d_set_error("point_list is NULL"); return W3D_ERR_INVALID; }
     if (gt_mask && used_count && num_obj < 0) { w3d_set_error("num_obj must be >= 0"); return W3D_ERR_INVALID; }
@@ -246,6 +250,7 @@ int w3d_backward(const w3d_view *view, int32_t P, const float *means3D, const fl
     W3DLayout L;
     rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
     if (rc) { w3d_set_error("bad sizes"); return rc; }
+    w3d_set_list_share(&L, view);
     if (P == 0) return W3D_OK;
     if (!state || !scratch || !dL_dcolor || !means3D || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity) {
         w3d_set_error("NULL buffer");
@@ -279,6 +284,7 @@ int w3d_forward_stage1_raw_subset(const w3d_view *view, int32_t P, const w3d_raw
     W3DLayout L;
     rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
     if (rc) { w3d_set_error("bad sizes"); return rc; }
+    w3d_set_list_share(&L, view);
     if (!state || !scratch) { w3d_set_error("state/scratch is NULL"); return W3D_ERR_INVALID; }
     if (P > 0) {
         if (!prm || !prm->xyz || !prm->f_dc || !prm->f_rest || !prm->opacity || !prm->scaling || !prm->rotation || !radii) {
@@ -307,6 +313,7 @@ int w3d_backward_raw(const w3d_view *view, int32_t P, const w3d_raw_params *prm,
     W3DLayout L;
     rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
     if (rc) { w3d_set_error("bad sizes"); return rc; }
+    w3d_set_list_share(&L, view);
     if (P == 0) return W3D_OK;
     if (!state || !scratch || !dL_dcolor || !prm || !grads || !grads->xyz || !grads->f_dc || !grads->f_rest ||
         !grads->opacity || !grads->scaling || !grads->rotation) {
@@ -341,6 +348,7 @@ int w3d_backward_raw_adam(const w3d_view *view, int32_t P, const w3d_raw_blocks 
     W3DLayout L;
     rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
     if (rc) { w3d_set_error("bad sizes"); return rc; }
+    w3d_set_list_share(&L, view);
     if (P == 0) return W3D_OK;
     if (!state || !scratch || !dL_dcolor || !prm || !adam) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
     for (int i = 0; i < 6; i++) {
@@ -380,6 +388,7 @@ int w3d_backward_raw_lowrank(const w3d_view *view, int32_t P, const w3d_raw_para
     W3DLayout L;
     rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
     if (rc) { w3d_set_error("bad sizes"); return rc; }
+    w3d_set_list_share(&L, view);
     if (P == 0) return W3D_OK;
     // dL_dcolor == NULL: the blend backward of this view already ran into `scratch` (w3d_backward_blend_dcolor); then
     // dcolor_out may be NULL as well
@@ -415,6 +424,7 @@ int w3d_backward_blend_dcolor(const w3d_view *view, int32_t P, const void *state
     W3DLayout L;
     rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
     if (rc) { w3d_set_error("bad sizes"); return rc; }
+    w3d_set_list_share(&L, view);
     if (P == 0) return W3D_OK;
     if (!state || !scratch || !dL_dcolor || !dcolor_out) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
     const char *st = static_cast<const char *>(state);

@@ -210,6 +210,8 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
     // software pipeline: the (key, id) pairs of the next two batches and the rect line of the next batch are in flight while
     // the current batch is ranked
     // (first pass: the value of key i is i — the preprocess writes the Gaussians in index order — so no value array is read)
+    // pass 0 (drop_invalid) reads keys in Gaussian order: the value of key i IS i — the preprocess writes no id array, and
+    // vals_in must not be read in that pass
     auto val_at = [&](uint32_t i) -> uint32_t { return drop_invalid ? i : vals_in[i]; };
     uint32_t k1 = (beg + lane < end) ? keys_in[beg + lane] : 0u, v1 = (beg + lane < end) ? val_at(beg + lane) : 0u;
     uint32_t k2 = (beg + 64 + lane < end) ? keys_in[beg + 64 + lane] : 0u, v2 = (beg + 64 + lane < end) ? val_at(beg + 64 + lane) : 0u;
@@ -518,7 +520,7 @@ seg_sum_kernel(const uint16_t *__restrict__ cnt, uint32_t C, uint32_t T, uint32_
 // eight block scans with their barriers took 15 us to move 0.5 MB).
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, uint32_t *__restrict__ tile_start,
-                 uint32_t *__restrict__ counters) {
+                 uint32_t *__restrict__ counters, uint32_t share_code) {
     constexpr uint32_t PER = 8, SPAN = 1024u * PER;
     __shared__ uint32_t wave_tot[17];
     __shared__ uint32_t tot_s[SPAN];
@@ -554,6 +556,7 @@ tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, u
     if (threadIdx.x == 0) {
         tile_start[T] = carry;
         counters[1] = carry;
+        counters[6] = share_code;       // lsx | lsy << 8 of the list grid these ranges live on (w3d_debug_tile_ranges)
     }
 }
 
@@ -580,9 +583,17 @@ chunk_off_kernel(const uint16_t *__restrict__ cnt, const uint32_t *__restrict__ 
     }
 }
 
-__global__ void copy_ranges_kernel(const uint32_t *__restrict__ tile_start, uint32_t T, uint32_t *__restrict__ out) {
+// per 16x16 tile: the range of the list it reads (with w3d_view.list_share the tiles of one list cell report the same range;
+// the share mode of the forward that wrote this state is kept in counters[6])
+__global__ void copy_ranges_kernel(const uint32_t *__restrict__ tile_start, uint32_t T, uint32_t gx,
+                                   const uint32_t *__restrict__ counters, uint32_t *__restrict__ out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < T) { out[2 * t] = tile_start[t]; out[2 * t + 1] = tile_start[t + 1]; }
+    const uint32_t lsx = counters[6] & 0xFFu, lsy = (counters[6] >> 8) & 0xFFu;
+    const uint32_t lgx = (gx + (1u << lsx) - 1u) >> lsx;
+    if (t < T) {
+        const uint32_t l = ((t / gx) >> lsy) * lgx + ((t % gx) >> lsx);
+        out[2 * t] = tile_start[l]; out[2 * t + 1] = tile_start[l + 1];
+    }
 }
 
 // Bands of tile rows for the chunk walk: each (chunk, band) pair is one wave.  Narrow bands shrink the wave's LDS
@@ -599,12 +610,12 @@ W3DBands w3d_pick_bands(const W3DLayout &L, int mode) {
 #endif
     uint32_t band_tiles = mode == 0 ? W3D_COUNT_BAND_TILES : W3D_FILL_BAND_TILES;  // tiles per band (the fill pass holds 12 B of LDS per tile, the count pass 2 B;
                                                      // measured fill at 1600x1200: 200 -> 0.188 ms, 300 -> 0.171, 500 -> 0.179, 700 -> 0.193)
-    uint32_t rows = band_tiles / (uint32_t)L.gx;
+    uint32_t rows = band_tiles / (uint32_t)L.lgx;
     if (rows < 1) rows = 1;
-    if (rows > (uint32_t)L.gy) rows = (uint32_t)L.gy;
+    if (rows > (uint32_t)L.lgy) rows = (uint32_t)L.lgy;
     b.rows = rows;
-    b.count = ((uint32_t)L.gy + rows - 1) / rows;
-    b.tbpad = (rows * (uint32_t)L.gx + 63u) & ~63u;
+    b.count = ((uint32_t)L.lgy + rows - 1) / rows;
+    b.tbpad = (rows * (uint32_t)L.lgx + 63u) & ~63u;
     return b;
 }
 }  // namespace
@@ -663,10 +674,10 @@ static void launch_walk(const W3DLayout &L, const w3d_view &v, char *state, char
     const uint32_t *off = reinterpret_cast<const uint32_t *>(scratch + L.s_off);
     if (v.tile_cull)
         hipLaunchKernelGGL((chunk_walk_kernel<MODE, true>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C,
-                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, wave_bytes);
+                           (uint32_t)L.LT, (uint32_t)L.lgx, (uint32_t)L.lgy, bands.rows, cnt, off, point_list, capacity, wave_bytes);
     else
         hipLaunchKernelGGL((chunk_walk_kernel<MODE, false>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C,
-                           (uint32_t)L.T, (uint32_t)L.gx, (uint32_t)L.gy, bands.rows, cnt, off, point_list, capacity, wave_bytes);
+                           (uint32_t)L.LT, (uint32_t)L.lgx, (uint32_t)L.lgy, bands.rows, cnt, off, point_list, capacity, wave_bytes);
 }
 
 // per-chunk per-tile counts and the list offsets
@@ -676,14 +687,15 @@ int w3d_launch_tile_count(const W3DLayout &L, const w3d_view &v, char *state, ch
     uint16_t *cnt = reinterpret_cast<uint16_t *>(scratch + L.s_cnt);
     uint32_t *part = reinterpret_cast<uint32_t *>(scratch + L.s_part);
     uint32_t *off = reinterpret_cast<uint32_t *>(scratch + L.s_off);
-    const uint32_t T = (uint32_t)L.T;
+    const uint32_t T = (uint32_t)L.LT;           // (lists live on the list grid: w3d_view.list_share)
     W3D_PROF("tile_count_scan", stream);
     launch_walk<0>(L, v, state, scratch, nullptr, 0, stream);
     W3D_LAUNCH_CHECK(v.debug, stream);
     const uint32_t tb = (T + 255) / 256;
     hipLaunchKernelGGL(seg_sum_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, L.C, T, L.seg, part);
     W3D_LAUNCH_CHECK(v.debug, stream);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, part, T, (uint32_t)W3D_SCAN_SEGS, tile_start, counters);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, part, T, (uint32_t)W3D_SCAN_SEGS, tile_start, counters,
+                       (uint32_t)L.lsx | ((uint32_t)L.lsy << 8));
     W3D_LAUNCH_CHECK(v.debug, stream);
     hipLaunchKernelGGL(chunk_off_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, part, tile_start, L.C, T, L.seg, off);
     W3D_LAUNCH_CHECK(v.debug, stream);
@@ -701,7 +713,8 @@ int w3d_launch_fill_lists(const W3DLayout &L, const w3d_view &v, char *state, ch
 int w3d_debug_tile_ranges_impl(const W3DLayout &L, const char *state, uint32_t *ranges_out, hipStream_t stream) {
     const uint32_t T = (uint32_t)L.T;
     hipLaunchKernelGGL(copy_ranges_kernel, dim3((T + 255) / 256), dim3(256), 0, stream,
-                       reinterpret_cast<const uint32_t *>(state + L.o_tile_start), T, ranges_out);
+                       reinterpret_cast<const uint32_t *>(state + L.o_tile_start), T, (uint32_t)L.gx,
+                       reinterpret_cast<const uint32_t *>(state + L.o_counters), ranges_out);
     W3D_HIP_CHECK(hipGetLastError());
     return W3D_OK;
 }

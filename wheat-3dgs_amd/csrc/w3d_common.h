@@ -8,6 +8,7 @@
 #include "../../include/w3d.h"
 
 #define W3D_TILE 16
+#define W3D_LOG2E 1.4426950408889634f
 #define W3D_WAVE 64
 #define W3D_NEAR 0.2f
 #define W3D_INVALID_KEY 0xFFFFFFFFu
@@ -27,15 +28,24 @@ static inline uint64_t w3d_align_up(uint64_t x, uint64_t a = 256) { return (x + 
 // Everything derived from (P, H, W) that host and kernels agree on.
 struct W3DLayout {
     int32_t P, H, W, gx, gy, T;
+    // the grid the per-tile LISTS live on (w3d_view.list_share): list cell (lx, ly) serves the tiles (lx << lsx .. , ly << lsy ..);
+    // lsx = lsy = 0: one list per tile.  Binning (tile masks, count, scan, fill) works on this grid, the blend on the tile grid.
+    int32_t lsx, lsy, lgx, lgy, LT;
     uint32_t chunk;   // Gaussians per binning chunk (multiple of 64)
     uint32_t C;       // number of chunks
     uint32_t seg;     // chunks per scan segment
     // ---- state buffer (kept until backward)
     uint64_t o_counters;   // u32[16]: [0]=num_visible [1]=num_rendered [3]=capacity of the list buffer given to stage 2
                            //          [4]=(min depth key)>>16 [5]=1 if the depth sort needs three passes only (w3d_binning.hip)
-    uint64_t o_xy;         // float2[P]
-    uint64_t o_conic_op;   // float4[P]
-    uint64_t o_rgbd;       // float4[P]  (r,g,b,depth)
+    uint64_t o_grec;       // float4[4P]: ONE 64-B line per Gaussian, in the layout the blend kernels stage (w3d_render.hip StagedLDS):
+                           //   [0] x, y, rect lo (minx | miny << 16), rect hi (maxx | maxy << 16) — the PUBLISHED tile rect: with shared
+                           //       lists (w3d_view.list_share) a tile also sees entries of its neighbours and drops those whose rect it
+                           //       is not in (the reference blends a Gaussian in the tiles of its 3-sigma bounding square only);
+                           //       the staging lane replaces the two words by pmin * log2e and the Gaussian's index
+                           //   [1] conic.x, conic.y, conic.z, opacity   [2] r, g, b, depth
+                           //   [3] -0.5 log2e conic.x, -log2e conic.y, -0.5 log2e conic.z, opacity
+                           // (rounds 1-4 kept xy / conic+opacity / rgb+depth in three arrays: three cache lines per gathered list
+                           //  entry — 375 B through the fabric per walked entry of the blend backward, PMC — instead of one)
     uint64_t o_rect;       // ushort4[P] (minx,miny,maxx,maxy) tile units
     uint64_t o_clamped;    // u8[P] bit c set: SH colour channel c clamped at 0
     uint64_t o_tile_mask;  // uint4[P] {rect lo, rect hi, mask lo, mask hi}; mask bit k: k-th tile of the rect (row-major) is
@@ -67,6 +77,7 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->gy = (H + W3D_TILE - 1) / W3D_TILE;
     L->T = L->gx * L->gy;
     if (L->gx > 65535 || L->gy > 65535) return W3D_ERR_UNSUPPORTED;
+    L->lsx = L->lsy = 0; L->lgx = L->gx; L->lgy = L->gy; L->LT = L->T;
     uint64_t Pp = P > 0 ? (uint64_t)P : 1;
     const uint64_t max_chunks = W3D_MAX_CHUNKS;
     uint64_t chunk = (Pp + max_chunks - 1) / max_chunks;
@@ -79,9 +90,7 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     uint64_t HW = (uint64_t)H * W, T = (uint64_t)L->T;
     uint64_t o = 0;
     L->o_counters = o;   o += w3d_align_up(16 * 4);
-    L->o_xy = o;         o += w3d_align_up(Pp * 8);
-    L->o_conic_op = o;   o += w3d_align_up(Pp * 16);
-    L->o_rgbd = o;       o += w3d_align_up(Pp * 16);
+    L->o_grec = o;       o += w3d_align_up(Pp * 64);
     L->o_rect = o;       o += w3d_align_up(Pp * 8);
     L->o_clamped = o;    o += w3d_align_up(Pp);
     L->o_tile_mask = o;  o += w3d_align_up(Pp * 16);
@@ -113,6 +122,20 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->s_rec_mask = o; o += w3d_align_up(Pp * 8);
     L->scratch_bytes = o;
     return W3D_OK;
+}
+
+// The list grid a view asks for (w3d.h: list_share needs tile_cull and the atomic backward).  Buffer sizes do not depend on it
+// (every per-list array is sized for the tile grid, which is never smaller).
+static inline void w3d_set_list_share(W3DLayout *L, const w3d_view *v) {
+    int mode = (v && v->tile_cull && !v->deterministic) ? v->list_share : 0;
+#ifdef W3D_FORCE_LIST_SHARE        // (A/B builds: profiles/build_variant.sh <name> all -DW3D_FORCE_LIST_SHARE=k)
+    if (v && v->tile_cull && !v->deterministic) mode = W3D_FORCE_LIST_SHARE;
+#endif
+    L->lsx = mode >= 1 ? 1 : 0;
+    L->lsy = mode >= 2 ? 1 : 0;
+    L->lgx = (L->gx + (1 << L->lsx) - 1) >> L->lsx;
+    L->lgy = (L->gy + (1 << L->lsy) - 1) >> L->lsy;
+    L->LT = L->lgx * L->lgy;
 }
 
 // error plumbing (w3d_api.hip)

@@ -205,8 +205,11 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float *c, const float *
 // exponent over the rect (w3d_q_noise, w3d_common.h) and the intervals a +0.01 px margin, the determinant is taken to ~1 ulp
 // (w3d_conic_det), so a tile is only dropped when the Gaussian provably contributes nothing there:
 // every output is unchanged, R and R_walk shrink.  Bit k of the result = k-th tile of the rect, row-major.
+// LIST GRID (w3d_view.list_share): with lsx / lsy > 0 the mask lives on the grid of list cells (2^lsx x 2^lsy tiles each): the rect
+// is the cells the tile rect touches, and a cell's bit is the OR of its tiles' bits — every tile row still contributes its own
+// run [t_lo, t_hi] of tiles (so nothing is lost to the coarser grid), shifted down to cells.  Bit k = k-th cell of the cell rect.
 __device__ __forceinline__ uint64_t footprint_tile_mask(float mx, float my, float A, float B, float C, float tau,
-                                                        int minx, int miny, int maxx, int maxy) {
+                                                        int minx, int miny, int maxx, int maxy, int lsx = 0, int lsy = 0) {
     if (tau < 0.f) return 0ull;                       // o <= 1/255: alpha >= 1/255 is unreachable anywhere
     const float det = w3d_conic_det(A, B, C);
     if (!(A > 0.f && C > 0.f && det > 0.f)) return ~0ull;
@@ -216,7 +219,8 @@ __device__ __forceinline__ uint64_t footprint_tile_mask(float mx, float my, floa
     const float wmax = __builtin_amdgcn_sqrtf(T2 * A * idet) + pad;    // the ellipse's half height
     const float xext = __builtin_amdgcn_sqrtf(T2 * C * idet) + pad;    // ... and half width
     const float wstar = B * __builtin_amdgcn_sqrtf(T2 * idet * __builtin_amdgcn_rcpf(C));     // l is extremal at +wstar, r at -wstar
-    const int rw = maxx - minx;
+    const int cminx = minx >> lsx, cminy = miny >> lsy;
+    const int rw = ((maxx + (1 << lsx) - 1) >> lsx) - cminx;
     uint64_t m = 0ull;
     for (int ty = miny; ty < maxy; ty++) {
         const float w0 = (float)(ty * W3D_TILE) - my, w1 = w0 + (float)(W3D_TILE - 1);
@@ -231,7 +235,8 @@ __device__ __forceinline__ uint64_t footprint_tile_mask(float mx, float my, floa
         const int t_lo = max(minx, (int)ceilf((xl - (float)(W3D_TILE - 1)) * (1.0f / W3D_TILE)));
         const int t_hi = min(maxx - 1, (int)floorf(xr * (1.0f / W3D_TILE)));
         if (t_lo > t_hi) continue;
-        const int cnt = t_hi - t_lo + 1, start = (ty - miny) * rw + (t_lo - minx);
+        const int c_lo = t_lo >> lsx, c_hi = t_hi >> lsx;
+        const int cnt = c_hi - c_lo + 1, start = ((ty >> lsy) - cminy) * rw + (c_lo - cminx);
         m |= (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) << start;
     }
     return m;
@@ -250,12 +255,12 @@ __device__ __forceinline__ void act_normalize(const float *r, float *q, float &i
 // rotations are un-normalised quaternions; the activations are applied here.
 template <bool RAW>
 __global__ void __launch_bounds__(256)
-preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict__ means3D,
+preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, int lsx, int lsy, const float *__restrict__ means3D,
                       const float *__restrict__ shs, const float *__restrict__ f_rest, const float *__restrict__ colors_precomp,
                       const float *__restrict__ opacities, const float *__restrict__ scales,
                       const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
-                      int32_t *__restrict__ radii, float2 *__restrict__ xy, float4 *__restrict__ conic_op,
-                      float4 *__restrict__ rgbd, ushort4 *__restrict__ rect, uint8_t *__restrict__ clamped_out,
+                      int32_t *__restrict__ radii, float4 *__restrict__ grec, ushort4 *__restrict__ rect,
+                      uint8_t *__restrict__ clamped_out,
                       uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ counters,
                       uint4 *__restrict__ tile_mask, const uint8_t *__restrict__ used_mask) {
 #pragma clang fp contract(off)
@@ -394,9 +399,15 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
             sh_to_rgb(v.sh_degree, c, p, cam.campos, rgb, cl);
         }
         key = __float_as_uint(depth);
-        xy[g] = make_float2(px, py);
         const float opac = RAW ? act_sigmoid(op_in) : op_in;
-        conic_op[g] = make_float4(conx, cony, conz, opac);
+        {
+            // the Gaussian's 64-B record, in the layout the blend kernels stage (W3DLayout::o_grec)
+            float4 *r = grec + 4 * (size_t)g;
+            r[0] = make_float4(px, py, __uint_as_float((uint32_t)minx | ((uint32_t)miny << 16)),
+                               __uint_as_float((uint32_t)maxx | ((uint32_t)maxy << 16)));
+            r[1] = make_float4(conx, cony, conz, opac);
+            r[3] = make_float4(-0.5f * W3D_LOG2E * conx, -W3D_LOG2E * cony, -0.5f * W3D_LOG2E * conz, opac);
+        }
         if (v.tile_cull) {
             // which tiles of the rect can this Gaussian reach at all?
             // o <= 1/255 can never reach alpha >= 1/255: tau < 0 drops every tile
@@ -430,28 +441,37 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
                 cmaxy = min(maxy, (int)fminf(floorf((py + yext) * (1.0f / W3D_TILE)), 65535.f) + 1);
                 if (cminx >= cmaxx || cminy >= cmaxy) cminx = cminy = cmaxx = cmaxy = 0;
             }
-            // (b) within it, tile by tile — for rects of up to 64 tiles (larger ones are left whole)
-            const int rw = cmaxx - cminx, rn = rw * (cmaxy - cminy);
+            // (b) within it, tile by tile — for rects of up to 64 tiles (larger ones are left whole); on the LIST grid when the
+            // view shares lists between neighbouring tiles (lsx, lsy: cells of 2^lsx x 2^lsy tiles — the record then holds the
+            // rect of cells and one bit per cell, which is what the binning stage bins)
+            const int lminx = cminx >> lsx, lminy = cminy >> lsy;
+            const int lmaxx = (cmaxx + (1 << lsx) - 1) >> lsx, lmaxy = (cmaxy + (1 << lsy) - 1) >> lsy;
+            const int rw = lmaxx - lminx, rn = rw * (lmaxy - lminy);
             uint64_t m = ~0ull;
-            if (rn <= 64) m = footprint_tile_mask(px, py, conx, cony, conz, tau, cminx, cminy, cmaxx, cmaxy);
-            tile_mask[g] = make_uint4((uint32_t)cminx | ((uint32_t)cminy << 16), (uint32_t)cmaxx | ((uint32_t)cmaxy << 16), (uint32_t)m,
+            if (rn <= 64) m = footprint_tile_mask(px, py, conx, cony, conz, tau, cminx, cminy, cmaxx, cmaxy, lsx, lsy);
+            tile_mask[g] = make_uint4((uint32_t)lminx | ((uint32_t)lminy << 16), (uint32_t)lmaxx | ((uint32_t)lmaxy << 16), (uint32_t)m,
                                       (uint32_t)(m >> 32));
         }
-        rgbd[g] = make_float4(rgb[0], rgb[1], rgb[2], depth);
+        grec[4 * (size_t)g + 2] = make_float4(rgb[0], rgb[1], rgb[2], depth);
         rect[g] = make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy);
         clamped_out[g] = (uint8_t)cl;
     }
     else if (valid) {
         // culled Gaussians write zeros: whole 64-B lines leave the wave (stores with holes where the culled lanes sit
         // cost more than the 40 % extra bytes: 0.16 -> 0.14 ms)
-        xy[g] = make_float2(0.f, 0.f); conic_op[g] = make_float4(0.f, 0.f, 0.f, 0.f); rgbd[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            float4 *r = grec + 4 * (size_t)g;
+            r[0] = r[1] = r[2] = r[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         if (v.tile_cull) tile_mask[g] = make_uint4(0, 0, 0, 0);
         clamped_out[g] = 0;
     }
     if (!valid) return;
     radii[g] = radius;
     keys[g] = key;
-    vals[g] = (uint32_t)g;
+    // (no id array is written: the depth sort's first pass — the only reader of the unsorted order — takes the value of key i
+    //  to be i, w3d_binning.hip radix_scatter_kernel `drop_invalid`; s_vals0 only serves as a ping-pong buffer of later passes)
+    (void)vals;
     // an all-zero rect marks a culled Gaussian for the binning walk and for the backward pass; written
     // here for EVERY Gaussian so that no stale bytes of a recycled state buffer can ever be read
     if (radius == 0) rect[g] = make_ushort4(0, 0, 0, 0);
@@ -461,8 +481,8 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, const float *__restrict
 }
 
 // proj_xy / gs_depth outputs of the FlashSplat variant (zeros for culled Gaussians)
-__global__ void flash_extras_kernel(int P, const uint32_t *__restrict__ keys_unused, const float2 *__restrict__ xy,
-                                    const float4 *__restrict__ rgbd, const ushort4 *__restrict__ rect,
+__global__ void flash_extras_kernel(int P, const uint32_t *__restrict__ keys_unused, const float4 *__restrict__ grec,
+                                    const ushort4 *__restrict__ rect,
                                     const int32_t *__restrict__ radii, float *__restrict__ proj_xy,
                                     float *__restrict__ gs_depth) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -471,10 +491,10 @@ __global__ void flash_extras_kernel(int P, const uint32_t *__restrict__ keys_unu
     const bool vis = ((int)rc.z - (int)rc.x) * ((int)rc.w - (int)rc.y) > 0;
     (void)radii;
     if (proj_xy) {
-        float2 p = vis ? xy[g] : make_float2(0.f, 0.f);
+        const float4 p = vis ? grec[4 * (size_t)g] : make_float4(0.f, 0.f, 0.f, 0.f);
         proj_xy[2 * (size_t)g] = p.x; proj_xy[2 * (size_t)g + 1] = p.y;
     }
-    if (gs_depth) gs_depth[g] = vis ? rgbd[g].w : 0.f;
+    if (gs_depth) gs_depth[g] = vis ? grec[4 * (size_t)g + 2].w : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1079,9 +1099,8 @@ int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *me
     const int block = 256, grid = (L.P + block - 1) / block;
     W3D_PROF("preprocess_fwd", stream);
 #define ARGS                                                                                                          \
-    v, L.P, L.gx, L.gy, means3D, shs, f_rest_raw, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, \
-        reinterpret_cast<float2 *>(state + L.o_xy), reinterpret_cast<float4 *>(state + L.o_conic_op),                \
-        reinterpret_cast<float4 *>(state + L.o_rgbd), reinterpret_cast<ushort4 *>(state + L.o_rect),                 \
+    v, L.P, L.gx, L.gy, L.lsx, L.lsy, means3D, shs, f_rest_raw, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, \
+        reinterpret_cast<float4 *>(state + L.o_grec), reinterpret_cast<ushort4 *>(state + L.o_rect),                 \
         reinterpret_cast<uint8_t *>(state + L.o_clamped), reinterpret_cast<uint32_t *>(scratch + L.s_keys0),         \
         reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(state + L.o_counters),       \
         reinterpret_cast<uint4 *>(state + L.o_tile_mask), used_mask
@@ -1097,7 +1116,7 @@ int w3d_launch_flash_extras(const W3DLayout &L, const w3d_view &v, const int32_t
     if (L.P == 0 || (!proj_xy && !gs_depth)) return W3D_OK;
     const int block = 256, grid = (L.P + block - 1) / block;
     hipLaunchKernelGGL(flash_extras_kernel, dim3(grid), dim3(block), 0, stream, L.P, (const uint32_t *)nullptr,
-                       reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_rgbd),
+                       reinterpret_cast<const float4 *>(state + L.o_grec),
                        reinterpret_cast<const ushort4 *>(state + L.o_rect), radii, proj_xy, gs_depth);
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;

@@ -30,7 +30,7 @@ namespace {
 #ifndef W3D_TILE_ORDER
 #define W3D_TILE_ORDER 1  // blend backward: every XCD takes its tiles longest walk first (tile_order_kernel)
 #endif
-#define LOG2E 1.4426950408889634f
+#define LOG2E W3D_LOG2E
 #define W3D_FLASH_LABELS 4     // FlashSplat: labels per tile that take the LDS row-sum path (more: one wave reduction per label and entry)
 #define W3D_ACC_SLOTS 128      // backward: (entry of a 32-entry half batch) x (16-lane row) slots per accumulated value
 #ifndef W3D_ACC_PITCH
@@ -119,6 +119,13 @@ __device__ __forceinline__ uint32_t wave_to_tile(uint32_t T, uint32_t &tile, con
     return tile < T;
 }
 
+// tile -> list cell (w3d_view.list_share; lshift = lsx | lsy << 4, lgx = cells per row; lshift = 0: the tile itself)
+__device__ __forceinline__ uint32_t list_of_tile(uint32_t tile, uint32_t gx, uint32_t lshift, uint32_t lgx) {
+    if (lshift == 0u) return tile;
+    const uint32_t ty = tile / gx, tx = tile - ty * gx;
+    return (ty >> (lshift >> 4)) * lgx + (tx >> (lshift & 15u));
+}
+
 struct StagedLDS {
     float4 a[64];  // x, y, pmin2 (log2-domain power below which alpha < 1/255 for sure), id bits
     float4 b[64];  // conic.x, conic.y, conic.z, opacity            (only the backward's flush reads it)
@@ -165,23 +172,31 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
 
 // Returns this lane's entry mask: bits 0..3 = quadrants it can touch.  The masks stay in registers; the loops read
 // them with v_readlane and skip entries that touch no quadrant on a scalar bit scan.
+// record words 2, 3 of a Gaussian (its published tile rect) -> may this tile blend it at all?  (only a tile that reads a SHARED
+// list ever meets an entry whose rect it is not in)
+__device__ __forceinline__ bool tile_in_rect(float lo_bits, float hi_bits, uint32_t tcol, uint32_t trow) {
+    const uint32_t lo = __float_as_uint(lo_bits), hi = __float_as_uint(hi_bits);
+    return tcol >= (lo & 0xFFFFu) && tcol < (hi & 0xFFFFu) && trow >= (lo >> 16) && trow < (hi >> 16);
+}
+// alpha = min(0.99, o*exp(power)) >= 1/255 needs power >= -log(255 o) =: pmin; 1e-4 slack covers the rounding of the fast exp,
+// so skipping below pmin never changes a result
+__device__ __forceinline__ float pmin_of(float opacity) { return (opacity > 0.f) ? (-__logf(255.0f * opacity) - 1e-4f) : 1.0f; }
+
 __device__ __forceinline__ uint32_t stage_entries(StagedLDS &s, uint32_t lane, uint32_t n, const uint32_t *__restrict__ list,
-                                              const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
-                                              const float4 *__restrict__ rgbd, float tx0, float ty0) {
+                                              const float4 *__restrict__ grec, uint32_t tcol, uint32_t trow) {
     uint32_t q = 0u;
     if (lane < n) {
+        // ONE 64-B line per entry, (almost) in the staged layout (W3DLayout::o_grec)
         const uint32_t g = list[lane];
-        const float2 p = xy[g];
-        const float4 co = conic_op[g];
-        const float4 cd = rgbd[g];
-        // alpha = min(0.99, o*exp(power)) >= 1/255 needs power >= -log(255 o); 1e-4 slack covers
-        // the rounding of the fast exp, so skipping below pmin never changes a result.
-        const float pmin = (co.w > 0.f) ? (-__logf(255.0f * co.w) - 1e-4f) : 1.0f;
-        s.a[lane] = make_float4(p.x, p.y, pmin * LOG2E, __uint_as_float(g));
+        const float4 *r = grec + 4 * (size_t)g;
+        const float4 a = r[0], co = r[1], cd = r[2], d = r[3];
+        const float pmin = pmin_of(co.w);
+        s.a[lane] = make_float4(a.x, a.y, pmin * LOG2E, __uint_as_float(g));
         s.b[lane] = co;
         s.c[lane] = cd;
-        s.d[lane] = make_float4(-0.5f * LOG2E * co.x, -LOG2E * co.y, -0.5f * LOG2E * co.z, co.w);
-        q = quadrant_mask(p.x, p.y, co.x, co.y, co.z, pmin, tx0, ty0);
+        s.d[lane] = d;
+        if (tile_in_rect(a.z, a.w, tcol, trow))
+            q = quadrant_mask(a.x, a.y, co.x, co.y, co.z, pmin, (float)(tcol * W3D_TILE), (float)(trow * W3D_TILE));
     }
     __builtin_amdgcn_wave_barrier();
     return q;
@@ -196,13 +211,13 @@ __device__ __forceinline__ uint32_t stage_entries(StagedLDS &s, uint32_t lane, u
 template <bool FLASH, bool DA = true>
 __global__ void __launch_bounds__(64 * W3D_RW, FLASH ? 4 : W3D_FWD_OCC)
 render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restrict__ tile_start,
-                  const uint32_t *__restrict__ point_list, const float2 *__restrict__ xy,
-                  const float4 *__restrict__ conic_op, const float4 *__restrict__ rgbd, const float *__restrict__ bg,
+                  const uint32_t *__restrict__ point_list, const float4 *__restrict__ grec, const float *__restrict__ bg,
                   float *__restrict__ out_color, float *__restrict__ out_depth, float *__restrict__ out_alpha,
                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                   const float *__restrict__ gt_mask, int num_obj, int P, float *__restrict__ used_count,
                   int32_t *__restrict__ contrib_num, uint32_t list_cap, uint32_t *__restrict__ counters,
-                  uint32_t *__restrict__ tile_walk, const uint32_t *__restrict__ tile_order, uint32_t *__restrict__ walk_hint) {
+                  uint32_t *__restrict__ tile_walk, const uint32_t *__restrict__ tile_order, uint32_t *__restrict__ walk_hint,
+                  uint32_t lshift, uint32_t lgx) {
     __shared__ StagedLDS lds[W3D_RW];
     __shared__ int s_labels[W3D_RW][FLASH ? 256 : 1];
     // FlashSplat: row sums of the per-entry, per-label weights of the current batch: [label slot][entry][16-lane row]
@@ -265,11 +280,14 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         }
         __builtin_amdgcn_wave_barrier();
     }
-    const uint32_t start = min(tile_start[tile], list_cap), end = min(tile_start[tile + 1], list_cap);
+    // the list this tile reads: its own, or (w3d_view.list_share) the one it shares with its neighbours in the list cell —
+    // the entries that cannot touch THIS tile have an empty quadrant mask and are skipped on the scalar bit scan below
+    const uint32_t ltile = list_of_tile(tile, gx, lshift, lgx);
+    const uint32_t start = min(tile_start[ltile], list_cap), end = min(tile_start[ltile + 1], list_cap);
     for (uint32_t base = start; base < end; base += 64) {
         if ((w3d_ballot(hi[0] == 0.f) | w3d_ballot(hi[1] == 0.f) | w3d_ballot(hi[2] == 0.f) | w3d_ballot(hi[3] == 0.f)) == 0ull) break;
         const uint32_t n = min(64u, end - base);
-        uint32_t myq = stage_entries(s, lane, n, point_list + base, xy, conic_op, rgbd, (float)tx0, (float)ty0);
+        uint32_t myq = stage_entries(s, lane, n, point_list + base, grec, tx0 / W3D_TILE, ty0 / W3D_TILE);
         {
             // quadrants whose 64 pixels are all done (saturated or outside the image) take no further entries: their bit is
             // cleared from every entry mask of the batch, so entries that only touch finished quadrants cost nothing
@@ -432,16 +450,12 @@ __device__ __forceinline__ void row_sum_n(float (&v)[N]) {
     for (int i = 0; i < N; i++) v[i] += dpp_mov<0x140>(v[i]);
 }
 
-struct Staged { float4 a, b, c; };
-__device__ __forceinline__ Staged gather_entry(uint32_t g, const float2 *__restrict__ xy, const float4 *__restrict__ conic_op,
-                                               const float4 *__restrict__ rgbd) {
-    const float2 p = xy[g];
-    const float4 co = conic_op[g];
+struct Staged { float4 a, b, c; uint32_t g; };
+__device__ __forceinline__ Staged gather_entry(uint32_t g, const float4 *__restrict__ grec) {
+    const float4 *r = grec + 4 * (size_t)g;
     Staged s;
-    const float pmin = (co.w > 0.f) ? (-__logf(255.0f * co.w) - 1e-4f) : 1.0f;
-    s.a = make_float4(p.x, p.y, pmin * LOG2E, __uint_as_float(g));
-    s.b = co;
-    s.c = rgbd[g];
+    s.a = r[0]; s.b = r[1]; s.c = r[2];       // (the fourth quarter of the line is three multiples of b: recomputed at staging, 4 VGPRs less in flight)
+    s.g = g;
     return s;
 }
 
@@ -452,13 +466,12 @@ __device__ __forceinline__ Staged gather_entry(uint32_t g, const float2 *__restr
 template <bool HAS_DA, bool DET>
 __global__ void __launch_bounds__(64 * W3D_RW, HAS_DA ? 3 : W3D_BWD_OCC)   // 2nd argument = waves per SIMD: caps VGPRs at 168 / 128
 render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restrict__ tile_start,
-                  const uint32_t *__restrict__ point_list, const float2 *__restrict__ xy,
-                  const float4 *__restrict__ conic_op, const float4 *__restrict__ rgbd, const float *__restrict__ bg,
+                  const uint32_t *__restrict__ point_list, const float4 *__restrict__ grec, const float *__restrict__ bg,
                   const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                   const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
                   const float *__restrict__ dL_dalpha_px, float *__restrict__ grad2d,
                   const uint32_t *__restrict__ counters, float *__restrict__ inst, uint32_t inst_cap,
-                  const uint32_t *__restrict__ tile_order) {
+                  const uint32_t *__restrict__ tile_order, uint32_t lshift, uint32_t lgx) {
     constexpr int NV = HAS_DA ? 10 : 9;
     __shared__ StagedLDS lds[W3D_RW];
     // row sums of the current half batch: acc[value][entry * 4 + row].  Every (entry, row) slot is written exactly once
@@ -515,7 +528,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     maxc = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(maxc));   // (an SGPR: everything derived from it stays scalar)
     if (maxc == 0) return;
     const uint32_t cap = counters[3];
-    const uint32_t start = min(tile_start[tile], cap);
+    const uint32_t start = min(tile_start[list_of_tile(tile, gx, lshift, lgx)], cap);     // (shared lists: see the forward)
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const bool has_bg = (bg0 != 0.f) || (bg1 != 0.f) || (bg2 != 0.f);     // wave-uniform: black background skips the term
     const int nb = (int)((maxc + 63) / 64);
@@ -551,18 +564,19 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     Staged nxt;
     {
         const uint32_t g = batch_id(nb - 1);
-        nxt = (g != 0xFFFFFFFFu) ? gather_entry(g, xy, conic_op, rgbd) : Staged{};
+        nxt = (g != 0xFFFFFFFFu) ? gather_entry(g, grec) : Staged{};
     }
     uint32_t ids = batch_id(nb - 2);
     for (int b = nb - 1; b >= 0; b--) {
         const uint32_t n = min(64u, maxc - (uint32_t)b * 64u);
-        s.a[lane] = nxt.a; s.b[lane] = nxt.b; s.c[lane] = nxt.c;
+        const float pmin = pmin_of(nxt.b.w);
+        s.a[lane] = make_float4(nxt.a.x, nxt.a.y, pmin * LOG2E, __uint_as_float(nxt.g)); s.b[lane] = nxt.b; s.c[lane] = nxt.c;
         s.d[lane] = make_float4(-0.5f * LOG2E * nxt.b.x, -LOG2E * nxt.b.y, -0.5f * LOG2E * nxt.b.z, nxt.b.w);
         // this lane's entry: quadrant mask (bits 0..3); it stays in the register — the walk below reads it with v_readlane
         // and skips entries without any quadrant on a scalar bit scan
         uint32_t myq = 0u;
-        if (lane < n) {
-            myq = quadrant_mask(nxt.a.x, nxt.a.y, nxt.b.x, nxt.b.y, nxt.b.z, nxt.a.z * (1.0f / LOG2E), (float)tx0, (float)ty0);
+        if (lane < n && tile_in_rect(nxt.a.z, nxt.a.w, tx0 / W3D_TILE, ty0 / W3D_TILE)) {
+            myq = quadrant_mask(nxt.a.x, nxt.a.y, nxt.b.x, nxt.b.y, nxt.b.z, pmin, (float)tx0, (float)ty0);
         }
         const uint64_t todo_all = w3d_ballot(myq != 0u);
 #ifdef W3D_BWD_STATS
@@ -570,7 +584,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
 #endif
         __builtin_amdgcn_wave_barrier();
         if (b > 0) {
-            nxt = (ids != 0xFFFFFFFFu) ? gather_entry(ids, xy, conic_op, rgbd) : Staged{};
+            nxt = (ids != 0xFFFFFFFFu) ? gather_entry(ids, grec) : Staged{};
             ids = batch_id(b - 2);
         }
         // the batch is consumed in two halves of 32 entries, each followed by its flush (the row-sum slots are per half)
@@ -760,7 +774,7 @@ __global__ void __launch_bounds__(256) zero_visible_records_kernel(float4 *__res
 __global__ void __launch_bounds__(256)
 det_gather_kernel(int P, int gx, const uint2 *__restrict__ rect, const uint4 *__restrict__ rect_mask, int cull,
                   const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
-                  const float4 *__restrict__ rgbd, const uint32_t *__restrict__ counters, const float *__restrict__ inst,
+                  const float4 *__restrict__ grec, const uint32_t *__restrict__ counters, const float *__restrict__ inst,
                   uint32_t inst_cap, float *__restrict__ grad2d) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= P) return;
@@ -775,7 +789,7 @@ det_gather_kernel(int P, int gx, const uint2 *__restrict__ rect, const uint4 *__
     uint64_t mask = ~0ull;
     if (cull && nt <= 64u) mask = (uint64_t)rm.z | ((uint64_t)rm.w << 32);
     const uint32_t cap = min(counters[3], inst_cap);
-    const uint32_t mykey = __float_as_uint(rgbd[g].w);
+    const uint32_t mykey = __float_as_uint(grec[4 * (size_t)g + 2].w);
     float sum[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) sum[k] = 0.f;
@@ -788,7 +802,7 @@ det_gather_kernel(int P, int gx, const uint2 *__restrict__ rect, const uint4 *__
             while (lo < hi) {                        // first entry whose (depth bits, id) is not below mine
                 const uint32_t mid = (lo + hi) >> 1;
                 const uint32_t e = point_list[mid];
-                const uint32_t ek = __float_as_uint(rgbd[e].w);
+                const uint32_t ek = __float_as_uint(grec[4 * (size_t)e + 2].w);
                 if (ek < mykey || (ek == mykey && e < (uint32_t)g)) lo = mid + 1; else hi = mid;
             }
             if (lo < min(tile_start[t + 1], cap) && point_list[lo] == (uint32_t)g) {
@@ -891,12 +905,11 @@ int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const 
 #endif
 #define ARGS                                                                                                          \
     T, (uint32_t)L.gx, L.W, L.H, ts, point_list,                                                                      \
-        reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_conic_op),     \
-        reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg, out_color, out_depth, out_alpha,                    \
+        reinterpret_cast<const float4 *>(state + L.o_grec), v.bg, out_color, out_depth, out_alpha,                    \
         reinterpret_cast<float *>(state + L.o_final_T), reinterpret_cast<uint32_t *>(state + L.o_n_contrib), gt_mask, \
         num_obj, L.P, used_count, contrib_num, (uint32_t)(list_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : list_capacity),      \
         reinterpret_cast<uint32_t *>(state + L.o_counters), reinterpret_cast<uint32_t *>(state + L.o_tile_walk), order,        \
-        v.tile_walk_hint
+        v.tile_walk_hint, (uint32_t)L.lsx | ((uint32_t)L.lsy << 4), (uint32_t)L.lgx
     {
         W3D_PROF("render_fwd", stream);
         if (flash) hipLaunchKernelGGL((render_fwd_kernel<true>), dim3(blocks), dim3(64 * W3D_RW), 0, stream, ARGS);
@@ -943,10 +956,10 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
     }
 #define ARGS                                                                                                      \
     T, (uint32_t)L.gx, L.W, L.H, reinterpret_cast<const uint32_t *>(state + L.o_tile_start), point_list,          \
-        reinterpret_cast<const float2 *>(state + L.o_xy), reinterpret_cast<const float4 *>(state + L.o_conic_op), \
-        reinterpret_cast<const float4 *>(state + L.o_rgbd), v.bg,                                                 \
+        reinterpret_cast<const float4 *>(state + L.o_grec), v.bg,                                                 \
         reinterpret_cast<const float *>(state + L.o_final_T), reinterpret_cast<const uint32_t *>(state + L.o_n_contrib), \
-        dL_dcolor, dL_ddepth, dL_dalpha, grad2d, reinterpret_cast<const uint32_t *>(state + L.o_counters), inst, inst_cap, order
+        dL_dcolor, dL_ddepth, dL_dalpha, grad2d, reinterpret_cast<const uint32_t *>(state + L.o_counters), inst, inst_cap, order, \
+        (uint32_t)L.lsx | ((uint32_t)L.lsy << 4), (uint32_t)L.lgx
     {
         W3D_PROF("render_bwd", stream);
         const bool da = dL_ddepth || dL_dalpha;
@@ -963,7 +976,7 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
         hipLaunchKernelGGL(det_gather_kernel, dim3((unsigned)((Pz + 255) / 256)), dim3(256), 0, stream, (int)Pz, (int)L.gx,
                            reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint4 *>(state + L.o_tile_mask),
                            (int)v.tile_cull, reinterpret_cast<const uint32_t *>(state + L.o_tile_start), point_list,
-                           reinterpret_cast<const float4 *>(state + L.o_rgbd),
+                           reinterpret_cast<const float4 *>(state + L.o_grec),
                            reinterpret_cast<const uint32_t *>(state + L.o_counters), inst, inst_cap, grad2d);
     }
 #undef ARGS

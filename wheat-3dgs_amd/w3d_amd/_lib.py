@@ -29,14 +29,14 @@ class W3DView(ctypes.Structure):
                 ("projmatrix", ctypes.c_void_p), ("campos", ctypes.c_void_p),
                 ("tile_cull", ctypes.c_int32), ("deterministic", ctypes.c_int32),
                 ("det_list_capacity", ctypes.c_uint64), ("tile_walk_hint", ctypes.c_void_p),
-                ("records_kept_clean", ctypes.c_int32)]
+                ("records_kept_clean", ctypes.c_int32), ("list_share", ctypes.c_int32)]
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self.struct_size = ctypes.sizeof(W3DView)      # checked by every entry point (include/w3d.h)
 
 
-ABI_MAJOR = 2       # W3D_ABI_VERSION // 100 of the include/w3d.h these ctypes mirrors were written against
+ABI_MAJOR = 3       # W3D_ABI_VERSION // 100 of the include/w3d.h these ctypes mirrors were written against
 
 
 def _load():

@@ -13,7 +13,8 @@ import math
 import torch
 
 from ._lib import W3DView, check, lib, ptr, stream_ptr
-from .rasterizer import GaussianRasterizationSettings, _View, backward_scratch, list_capacity, scratch_done
+from .rasterizer import (GaussianRasterizationSettings, list_share_of, _View, backward_scratch, list_capacity,
+                         scratch_done)
 
 _vp, _i32 = ctypes.c_void_p, ctypes.c_int32
 
@@ -113,7 +114,8 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, flash=None
     s = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg_color,
                                       scaling_modifier, cam.world_view_transform, cam.full_proj_transform,
                                       model.active_sh_degree, cam.camera_center, False, False,
-                                      bool(getattr(model, "tile_cull", True)), bool(getattr(model, "deterministic", False)))
+                                      bool(getattr(model, "tile_cull", True)), bool(getattr(model, "deterministic", False)),
+                                      list_share_of(model))
     view = _View(s, (model.max_sh_degree + 1) ** 2, dev)
     prm = _raw_params(model)
     um = None

@@ -5,8 +5,8 @@ import math
 
 import torch
 
-from .rasterizer import (FlashSplatRasterizationSettings, FlashSplatRasterizer, GaussianRasterizationSettings,
-                         GaussianRasterizer)
+from .rasterizer import (list_share_of, FlashSplatRasterizationSettings, FlashSplatRasterizer,
+                         GaussianRasterizationSettings, GaussianRasterizer)
 
 
 def _sh_python(pc, viewpoint_camera):
@@ -23,7 +23,8 @@ def _settings(cls, cam, pc, bg_color, scaling_modifier, debug, **extra):
                scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform,
                projmatrix=cam.full_proj_transform, sh_degree=pc.active_sh_degree, campos=cam.camera_center,
                prefiltered=False, debug=debug, tile_cull=bool(getattr(pc, "tile_cull", True)),
-               deterministic=bool(getattr(pc, "deterministic", False)), **extra)
+               deterministic=bool(getattr(pc, "deterministic", False)),
+               list_share=list_share_of(pc), **extra)
 
 
 # render() on this package's flat GaussianModel hands the PRE-ACTIVATION parameter blocks to the kernels (one autograd

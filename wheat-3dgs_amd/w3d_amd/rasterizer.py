@@ -25,7 +25,16 @@ from ._lib import W3DView, check, lib, ptr, stream_ptr
 #   deterministic  w3d_view.deterministic: the blend backward stores every (tile, Gaussian) contribution in the slot of its
 #                  list entry and adds them per Gaussian in tile order instead of float atomics — bit-identical gradients
 #                  from run to run, about 2x the backward time (debugging; tests that compare k-step parameters bit for bit).
-# The raw-parameter path (fused_step.py) reads the same two switches from attributes of the GaussianModel it is given.
+#   list_share     w3d_view.list_share (speed only; needs tile_cull and the atomic backward): 0 = one list per 16x16 tile,
+#                  1 = one per 32x16 pair of tiles, 2 = one per 32x32 block.  The blend still runs one wave per 16x16 tile.
+# The raw-parameter path (fused_step.py) reads the same switches from attributes of the GaussianModel it is given.
+LIST_SHARE_DEFAULT = 1
+
+
+def list_share_of(obj):
+    """obj.list_share, or the default when the attribute is missing or None."""
+    x = getattr(obj, "list_share", None)
+    return LIST_SHARE_DEFAULT if x is None else int(x)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -44,6 +53,7 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
     tile_cull: bool = True
     deterministic: bool = False
+    list_share: int = LIST_SHARE_DEFAULT
 
 
 class FlashSplatRasterizationSettings(NamedTuple):
@@ -64,6 +74,7 @@ class FlashSplatRasterizationSettings(NamedTuple):
     num_obj: int = 2
     tile_cull: bool = True
     deterministic: bool = False
+    list_share: int = LIST_SHARE_DEFAULT
 
 
 class ListCapacity:
@@ -142,6 +153,9 @@ class _View:
         v.projmatrix, v.campos = self.pm.data_ptr(), self.cp.data_ptr()
         v.tile_cull = int(bool(getattr(s, "tile_cull", True)))
         self.deterministic = bool(getattr(s, "deterministic", False))
+        # (the forward must already know that the backward will be the deterministic one: shared lists are an atomic-mode layout)
+        v.deterministic = int(self.deterministic)
+        v.list_share = list_share_of(s)
         # per-camera walk-length hint of the blend forward (w3d_view.tile_walk_hint; speed only): kept on the camera's own
         # view-matrix tensor — the object a training loop hands in again every time it renders that camera
         tiles = ((v.image_width + 15) // 16) * ((v.image_height + 15) // 16)
