@@ -29,6 +29,7 @@ import numpy as np
 import pytest
 import torch
 
+from util import raw_grads_from_oracle, per_gaussian_error, flip_pixels, gradient_stats, densify_norm_error  # noqa: F401
 from util import view_inputs, make_oracle, np_inputs, psnr
 from w3d_amd.synth import make_scene, make_cameras
 
@@ -56,43 +57,6 @@ def _model(sc, dev):
     return m
 
 
-def raw_grads_from_oracle(gref, sc):
-    """Chain the oracle's gradients w.r.t. the ACTIVATED inputs through the activations of reference
-    scene/gaussian_model.py:33-41 (exp, sigmoid, normalize, cat(dc, rest)) — float64 torch formulas."""
-    t = lambda a: torch.from_numpy(np.asarray(a)).double()  # noqa: E731
-    out = {"xyz": t(gref["means3D"])}
-    shs = t(gref["shs"])
-    out["f_dc"], out["f_rest"] = shs[:, :1], shs[:, 1:]
-    o = torch.sigmoid(sc.opacity.double())
-    out["opacity"] = t(gref["opacities"]).reshape(-1, 1) * o * (1 - o)
-    out["scaling"] = t(gref["scales"]) * torch.exp(sc.scaling.double())
-    r = sc.rotation.double()
-    n = r.norm(dim=1, keepdim=True)
-    q = r / n
-    gq = t(gref["rotations"])
-    out["rotation"] = (gq - q * (q * gq).sum(1, keepdim=True)) / n
-    return {k: v.numpy() for k, v in out.items()}
-
-
-def per_gaussian_error(got, ref):
-    """max_d |got - ref| / max_d |ref| per Gaussian, over the Gaussians whose reference gradient is not zero (hidden
-    Gaussians behind saturated pixels have none; a tiny floor keeps denormal-sized gradients from dominating)."""
-    got, ref = np.asarray(got, np.float64).reshape(len(ref), -1), np.asarray(ref, np.float64).reshape(len(ref), -1)
-    mag = np.abs(ref).max(1)
-    nz = mag > 0
-    floor = 1e-4 * np.median(mag[nz]) if nz.any() else 1.0
-    return np.abs(got - ref).max(1) / (mag + floor), nz, np.abs(got - ref).max(1) / (1e-4 * mag + 1e-3 * (np.median(mag[nz]) if nz.any() else 1.0))
-
-
-def flip_pixels(out, ref):
-    """Pixels whose contributor set evidently differs between the two implementations: a colour / alpha difference far
-    above fp32 noise (5e-5; rounding noise of the blend is ~1e-6).  (n_contrib cannot be compared: it is a position in the
-    tile's list, and the footprint-culled lists of the product path are shorter than the oracle's.)"""
-    d = np.abs(out["color"] - ref["color"]).max(0) > 5e-5
-    d |= np.abs(out["alpha"][0] - ref["alpha"][0]) > 5e-5
-    return int(d.sum())
-
-
 def check_images_fullsize(out, ref, tag):
     rng = np.random.RandomState(0)
     stats = {}
@@ -105,20 +69,6 @@ def check_images_fullsize(out, ref, tag):
         stats[k] = dict(dpsnr=dp, max=float(diff.max()), frac_gt_2e4=float((diff > 2e-4 * scale).mean()))
         assert dp <= 1e-3, f"{tag}{k}: PSNR differs by {dp:.2e} dB"
         assert stats[k]["frac_gt_2e4"] <= 1e-4, f"{tag}{k}: {stats[k]['frac_gt_2e4']:.2e} of the pixels differ by more than 2e-4"
-    return stats
-
-
-def gradient_stats(got, want, vis, bulk=1e-4):
-    """Per block: percentiles of the per-Gaussian relative error, number of Gaussians beyond `bulk`."""
-    stats = {}
-    for k, ref in want.items():
-        g = np.asarray(got[k]).reshape(ref.shape)
-        e, nz, mixed = per_gaussian_error(g, ref)
-        e = e[nz & vis]
-        stats[k] = dict(n=int(e.size), p50=float(np.percentile(e, 50)), p99=float(np.percentile(e, 99)),
-                        p999=float(np.percentile(e, 99.9)), max=float(e.max()), outliers=int((e > bulk).sum()),
-                        worst_mixed=float(mixed[vis].max()),
-                        culled_zero=bool(np.all(g.reshape(len(ref), -1)[~vis] == 0)))
     return stats
 
 
@@ -173,13 +123,6 @@ def test_c1_size_through_the_dropin_module():
 
 
 _cache = {}
-
-
-def densify_norm_error(n_own, n_ref, vis):
-    nz = vis & (n_ref > 0)
-    e = np.abs(n_own - n_ref)[nz] / (n_ref[nz] + 1e-4 * np.median(n_ref[nz]))
-    return dict(n=int(e.size), p50=float(np.percentile(e, 50)), p99=float(np.percentile(e, 99)), p999=float(np.percentile(e, 99.9)),
-                max=float(e.max()), outliers=int((e > 1e-4).sum()))
 
 
 def oracle_view(P, cam_index, seed=0):
