@@ -793,7 +793,10 @@ def scale_model(model, opt, cams, bg, dev, it, steps=30):
     mach, rows_per_view = {}, None
     try:
         if not dist.is_initialized():
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+            # an in-process store: no TCP rendezvous (on one box the c10d TCP store spent 3 minutes in reverse-lookups of a
+            # hostname that does not resolve), and RCCL's own bootstrap kept on the loopback interface
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            dist.init_process_group("nccl", store=dist.HashStore(), rank=0, world_size=1, device_id=dev)
         for mode in ("rows", "lowrank"):
             tr = Trainer(model, cams, opt, bg, densify=False, force_exchange=True, exchange=mode)
             for _ in range(10):

@@ -67,6 +67,9 @@ def _worker(rank, world, port, out):
         radii = (torch.rand(P, generator=g) * 30).to(torch.int32) * vis
         nsum, vcount, rmax = tr.exchange(gnorm, vis, radii)
         tr.wait_stats()
+        # visibility counts and radii are NOT exchanged per step: every rank tracks its own views and Trainer.sync_stats()
+        # reduces them when something reads them (below, before the densification)
+        ok &= vcount is None and rmax is None
 
         def gather(t):
             lst = [torch.zeros_like(t) for _ in range(world)]
@@ -74,12 +77,16 @@ def _worker(rank, world, port, out):
             return lst
         norms, viss, rads = gather(gnorm), gather(vis.to(torch.float32)), gather(radii)
         ok &= torch.allclose(nsum, sum(n * v for n, v in zip(norms, viss)), atol=1e-9)
-        ok &= torch.equal(vcount, sum(viss))
-        ok &= torch.equal(rmax, torch.stack(rads).max(0).values)
+        want_count = sum(viss) if step == 0 else want_count + sum(viss)
+        want_rmax = torch.stack(rads).max(0).values if step == 0 else torch.maximum(want_rmax, torch.stack(rads).max(0).values)
+        m.xyz_gradient_accum += nsum[:, None]
         tr.optimizer_step_and_gather(zero_grad=False, skip=())
-    # lock-step densification: whole moments first, then identical decisions on every rank
-    m.xyz_gradient_accum += nsum[:, None]
-    m.denom += vcount[:, None]
+    # lock-step densification: whole statistics and moments first, then identical decisions on every rank
+    ok &= float(m.denom.abs().max()) == 0.0                     # nothing folded in yet
+    tr.sync_stats()
+    ok &= torch.equal(m.denom.reshape(-1), want_count) and torch.equal(m.max_radii2D, want_rmax.to(m.max_radii2D.dtype))
+    tr.sync_stats()                                             # (idempotent: nothing tracked since)
+    ok &= torch.equal(m.denom.reshape(-1), want_count)
     tr.gather_moments()
     moments = m.optimizer.exp_avg.clone()
     torch.manual_seed(1234)
@@ -180,8 +187,11 @@ def _lowrank_worker(rank, world, port, out, mode):
         ex = tr.exchange_rows if mode.startswith("rows") else tr.exchange_lowrank
         nsum, vcount, rmax = ex(dcol / world, gnorm, vis, radii)
         tr.wait_stats()
-        stats.append((nsum.clone().numpy(), vcount.float().numpy(), rmax.clone().numpy()))
+        assert vcount is None and rmax is None               # tracked per rank, reduced by sync_stats()
+        stats.append((nsum.clone().numpy(),))
         tr.optimizer_step_lowrank(step, skip=({"opacity"} if step == 2 else ()))
+    tr.sync_stats()
+    stats.append((m.denom.numpy().copy(), m.max_radii2D.numpy().copy()))
     out.put((rank, m.flat.detach().numpy().copy(), m.optimizer.exp_avg.numpy().copy(), m.optimizer.exp_avg_sq.numpy().copy(),
              m.optimizer.step_count, stats, dict(tr.exchange_used)))
     dist.barrier()

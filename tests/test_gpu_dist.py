@@ -53,6 +53,7 @@ def test_exchange_paths_equal_single_gpu_step(one_rank_group):
         tr.early_gather = name == "lowrank_early"                  # ... issued between the two halves of the backward
         tr.step(1)
         assert name != "rows" or tr._rows_cap is not None             # later steps size the row collective speculatively
+        tr.sync_stats()                     # (visibility counts / radii: tracked per rank, reduced when read)
         one = (m.flat.clone(), m.optimizer.exp_avg.clone(), m.optimizer.exp_avg_sq.clone(), m.xyz_gradient_accum.clone(),
                m.denom.clone(), m.max_radii2D.clone())
         for it in range(2, 5):

@@ -110,6 +110,7 @@ def worker(rank, world, port, mode, outdir, backend="gloo_staged"):
         tr.step(it)
         if it in (1, 7):
             tr.gather_moments()
+            tr.sync_stats()         # (visibility counts / radii are tracked per rank and reduced when read)
             snaps[it] = dict(flat=m.flat.detach().cpu().numpy(), m=m.optimizer.exp_avg.cpu().numpy(),
                              v=m.optimizer.exp_avg_sq.cpu().numpy(), accum=m.xyz_gradient_accum.cpu().numpy(),
                              denom=m.denom.cpu().numpy(), radii=m.max_radii2D.cpu().numpy(), P=np.array(m.num_points))

@@ -192,13 +192,38 @@ class Trainer:
                 self._rs_work = None
             if not tracking:
                 return None, None, None
-            stats = torch.stack([grad2d_norm * visible, visible.to(grad2d_norm.dtype)])
-            w1 = dist.all_reduce(stats, op=dist.ReduceOp.SUM, async_op=True)
-            r = radii.clone()
-            w2 = dist.all_reduce(r, op=dist.ReduceOp.MAX, async_op=True)
-            self._stat_work = (w1, w2)
-            return stats[0], stats[1], r
+            self.track_local(visible, radii)
+            nsum = grad2d_norm * visible
+            self._stat_work = (dist.all_reduce(nsum, op=dist.ReduceOp.SUM, async_op=True),)
+            return nsum, None, None
         return grad2d_norm * visible, visible.to(grad2d_norm.dtype), radii
+
+    def track_local(self, visible, radii):
+        """Visibility counts and radii of THIS rank's views since the last sync_stats().  `denom` (a sum of 0 / 1 over views) and
+        `max_radii2D` (a maximum) are only read when a densification or a checkpoint consumes them, and both reductions are
+        exact in any order — integer-valued sums, maxima — so the ranks accumulate their own views locally and reduce ONCE,
+        right before the consumer (sync_stats), instead of with two all-reduces of P-sized arrays in every step (rounds 1-4).
+        The sum of the gradient norms still travels every step (in the rows, or as one all-reduce): a float sum is not."""
+        P = int(visible.shape[0])
+        if getattr(self, "_vis_local", None) is None or self._vis_local.shape[0] != P or self._vis_local.device != visible.device:
+            self._vis_local = torch.zeros(P, dtype=torch.int32, device=visible.device)
+            self._rmax_local = torch.zeros(P, dtype=torch.int32, device=visible.device)
+        self._vis_local += visible.to(torch.int32)
+        torch.maximum(self._rmax_local, radii.to(torch.int32), out=self._rmax_local)
+
+    def sync_stats(self):
+        """Fold the locally tracked visibility counts and radii of all ranks into model.denom / model.max_radii2D (track_local).
+        Called before anything reads them: densify_and_prune, capture().  A collective pair — every rank must call it."""
+        v = getattr(self, "_vis_local", None)
+        if v is None:
+            return
+        m = self.model
+        if v.shape[0] == m.num_points:
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self._rmax_local, op=dist.ReduceOp.MAX)
+            m.denom += v[:, None].to(m.denom.dtype)
+            m.max_radii2D = torch.max(m.max_radii2D, self._rmax_local.to(m.max_radii2D.dtype))
+        self._vis_local = self._rmax_local = None
 
     def campos_of_all_ranks(self, iteration):
         """(world, 3) camera centres of the views all ranks render in this iteration (known locally: same camera list,
@@ -225,12 +250,10 @@ class Trainer:
         self._geo_work = [dist.all_reduce(m.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True)]
         if not tracking:
             return None, None, None
-        stats = torch.stack([grad2d_norm * visible, visible.to(grad2d_norm.dtype)])
-        w1 = dist.all_reduce(stats, op=dist.ReduceOp.SUM, async_op=True)
-        r = radii.clone()
-        w2 = dist.all_reduce(r, op=dist.ReduceOp.MAX, async_op=True)
-        self._stat_work = (w1, w2)
-        return stats[0], stats[1], r
+        self.track_local(visible, radii)              # (visibility counts and radii: reduced when consumed, sync_stats)
+        nsum = grad2d_norm * visible
+        self._stat_work = (dist.all_reduce(nsum, op=dist.ReduceOp.SUM, async_op=True),)
+        return nsum, None, None
 
     def rows_limit(self, P):
         """Largest per-view row count for which the sparse form moves fewer bytes than the low-rank one.  Per rank and step
@@ -255,11 +278,14 @@ class Trainer:
         first step (and every step after one that was too dense) waits for them on the host, sizes the collective exactly
         and decides — identically on every rank — whether the views are sparse enough (rows_limit) or go through
         exchange_lowrank (as do the ROWS_RETRY steps after such a one, without counting rows).  Later steps are SPECULATIVE:
-        the collective is sized 1.25 x the previous step's largest count and enqueued together with the indexing kernel
-        before the host looks at the counts (which arrive in pinned memory in the meantime); only if a view produced more
-        rows than that does a second all-gather carry the remainder.  The host wait then falls where the GPU still has the
+        the collective is sized 1.15 x the largest count of the last ROWS_WINDOW steps (never beyond rows_limit, the size at
+        which the sparse form stops paying) and enqueued together with the indexing kernel before the host looks at the counts
+        (which arrive in pinned memory in the meantime); a view that produced more rows than that gets a second all-gather for
+        the remainder, a step that turned out too dense altogether abandons the rows (`rows_abandoned`) for the low-rank form.  The host wait then falls where the GPU still has the
         collective to run, instead of leaving it idle.
-        Statistics: the norms travel in the rows; visibility counts as a u8 SUM, radii as an int32 MAX all-reduce."""
+        Statistics: the norms travel in the rows; visibility counts and radii are tracked per rank and reduced when a
+        densification or a checkpoint reads them (track_local / sync_stats) — an ordinary step of this form issues TWO
+        collectives: the counts and the rows."""
         from .fused_step import ROW_FLOATS, GatheredRows, apply_gradient_rows, pack_gradient_rows
         m = self.model
         P = m.num_points
@@ -295,12 +321,9 @@ class Trainer:
         # everything that does not depend on the counts is enqueued BEFORE the host reads them
         gpu = dcolor.is_cuda
         vcount = rmax = nsum = None
+        self._stat_work = ()
         if tracking:
-            vcount = visible.to(torch.uint8)
-            w1 = dist.all_reduce(vcount, op=dist.ReduceOp.SUM, async_op=True)
-            rmax = radii.clone()
-            w2 = dist.all_reduce(rmax, op=dist.ReduceOp.MAX, async_op=True)
-            self._stat_work = (w1, w2)
+            self.track_local(visible, radii)          # no collective: reduced when consumed (sync_stats); the norms travel in the rows
         sl = m.block_slices()
         a, b = sl["xyz"][0], sl["rotation"][1]                    # xyz | opacity | scaling | rotation: one contiguous span
         assert 11 * P <= b - a <= 11 * P + 9
@@ -360,7 +383,7 @@ class Trainer:
         # (the views differ: one camera's row count says little about the next one's — sized from the previous STEP alone, 27 of
         #  100 benchmark steps outgrew the guess and paid a second collective; the largest count of a window of steps, + 15 %)
         self._rows_recent = (self._rows_recent + [nmax])[-self.ROWS_WINDOW:]
-        self._rows_cap = None if nmax > limit or not self.rows_speculate else \
+        self._rows_cap = None if not self.rows_speculate else \
             min(max(P, 1), (int(1.15 * max(self._rows_recent)) + 1024) // 1024 * 1024)
         if gpu:
             # the optimizer kernel reads the rows through the per-Gaussian index (optimizer_step_lowrank -> w3d_rows_adam):
@@ -477,6 +500,7 @@ class Trainer:
         """GaussianModel.capture() of a consistent replica: in the dense exchange every rank only steps the Adam moments
         of its shard, so they are gathered first."""
         self.gather_moments()
+        self.sync_stats()
         assert not getattr(self, "_moments_sharded", False)
         return self.model.capture()
 
@@ -507,11 +531,13 @@ class Trainer:
         skip = set()
         if iteration < opt.densify_until_iter:
             if not stats_done:
-                m.max_radii2D = torch.max(m.max_radii2D, rmax.to(m.max_radii2D.dtype))
                 m.xyz_gradient_accum += nsum[:, None]
-                m.denom += vcount[:, None]
+                if vcount is not None:              # (several ranks: tracked locally, reduced by sync_stats below when read)
+                    m.max_radii2D = torch.max(m.max_radii2D, rmax.to(m.max_radii2D.dtype))
+                    m.denom += vcount[:, None]
             if self.densify:
                 if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+                    self.sync_stats()
                     self.gather_moments()
                     size_threshold = 20 if iteration > opt.opacity_reset_interval else None
                     torch.manual_seed(1234 + iteration)     # identical split samples on every rank
