@@ -78,6 +78,9 @@ def parse(argv=None):
     ap.add_argument("--densify-grad-threshold", type=float, default=1.5e-5,
                     help="densify_grad_threshold of that schedule (reference default 2e-4, arguments/__init__.py:88, tuned for "
                          "photographs: the smooth synthetic views only grow to ~0.26 M Gaussians with it; stated in the line)")
+    ap.add_argument("--opaque-iterations", type=int, default=15_000,
+                    help="iterations of the reference schedule that trains the opaque-surface scene (opaque_scene leg; 15000 = "
+                         "arguments/__init__.py:73-89 as it is); 0: skip")
     ap.add_argument("--densified-only", action="store_true",
                     help="of the extra measurements keep only the densified-scene one")
     ap.add_argument("--modules-only-steps", type=int, default=-1,
@@ -208,7 +211,9 @@ def workload_stats(model, cam, bg, dev):
     from w3d_amd.gaussian_renderer import _settings
     from w3d_amd.rasterizer import GaussianRasterizationSettings
     with torch.no_grad():
-        s = _settings(GaussianRasterizationSettings, cam, model, bg, 1.0, False)
+        # (one list per tile, whatever list_share the trainer currently runs: R and the walk lengths are then the culled
+        #  per-tile figures, comparable between scenes and rounds)
+        s = _settings(GaussianRasterizationSettings, cam, model, bg, 1.0, False)._replace(list_share=0)
         _, radii, _, _, saved, _ = _forward_impl(s, model.get_xyz, model.get_features, None, model.get_opacity,
                                                  model.get_scaling, model.get_rotation, None)
         _, nc = debug_pixel_state(saved)
@@ -217,8 +222,15 @@ def workload_stats(model, cam, bg, dev):
         pad = torch.zeros(gy * 16, gx * 16, dtype=torch.int64, device=dev)
         pad[:H, :W] = nc.to(torch.int64)
         r_walk = int(pad.view(gy, 16, gx, 16).amax(dim=(1, 3)).sum())
+        # contributors = entries a pixel actually BLENDS (alpha >= 1/255, before it saturates): the FlashSplat forward counts
+        # them (contrib_num); n_contrib above is the list POSITION of the last one — every entry of the tile's list in front of
+        # it counts there, whether it touches the pixel or not
+        from w3d_amd.rasterizer import FlashSplatRasterizationSettings
+        sf = FlashSplatRasterizationSettings(*s[:12], mask_grad=False, num_obj=1, tile_cull=True, deterministic=False, list_share=0)
+        ex = _forward_impl(sf, model.get_xyz, model.get_features, None, model.get_opacity, model.get_scaling, model.get_rotation,
+                           None, flash=dict(gt_mask=None, num_obj=1))[5]
         return dict(V=saved["num_visible"], R=saved["num_rendered"], R_walk=r_walk,
-                    mean_contrib=float(nc.float().mean()))
+                    mean_last=float(nc.float().mean()), mean_contrib=float(ex[0].float().mean()))
 
 
 def _newest(pattern):
@@ -854,7 +866,7 @@ def scale_model(model, opt, cams, bg, dev, it, steps=30):
 
 def mean_workload(model, cams, bg, dev):
     ws = [workload_stats(model, cams[i], bg, dev) for i in (0, len(cams) // 2)]
-    return {k: sum(w[k] for w in ws) / len(ws) for k in ("V", "R", "R_walk", "mean_contrib")}
+    return {k: sum(w[k] for w in ws) / len(ws) for k in ("V", "R", "R_walk", "mean_contrib", "mean_last")}
 
 
 # ------------------------------------------------------------------------------------------------ densified scene
@@ -967,7 +979,7 @@ def densified_scene(args, dev, bg, log, with_scale_model=False):
     ips = args.steps / meas["elapsed"]
     rep.update(value=round(ips, 3), ms_per_step=round(1e3 * meas["elapsed"] / args.steps, 4), steps=args.steps,
                stage_ms=meas["stage_ms"], visible_per_view=int(ws["V"]), tile_instances_per_view=int(ws["R"]),
-               walked_instances_per_view=int(ws["R_walk"]), mean_contributors_per_pixel=round(ws["mean_contrib"], 2),
+               walked_instances_per_view=int(ws["R_walk"]), mean_contributors_per_pixel=round(ws["mean_contrib"], 2), mean_last_contributor_list_position=round(ws["mean_last"], 2),
                final_loss=round(float(tr.last["loss"]), 6),
                roofline=roofline_object(meas, P, ws, HW, True, ips, "densified"))
     if with_scale_model:
@@ -977,6 +989,138 @@ def densified_scene(args, dev, bg, log, with_scale_model=False):
         except Exception as e:
             rep["scale_model"] = {"error": repr(e)}
     return rep, m
+
+
+# ------------------------------------------------------------------------------------------------ opaque-surface scene
+def opaque_scene(args, dev, bg, log, with_scale_model=False):
+    """A trained scene that SATURATES like a photographed one.  The benchmark scene is a random translucent slab (its pixels
+    saturate after 15 % of their lists, 107 k of 1.2 M visible Gaussians get a gradient) and the densified leg fits renders of
+    such a slab (724 contributors per pixel at the end); a real 3DGS model is made of opaque surfaces, tens of contributors per
+    pixel.  Here the ground truth is synth.make_opaque_scene — a sheet of opaque ground discs with ears on stems — seen by the
+    same 36 cameras (30 training, 6 held out); a 150 k-point cloud of it goes through create_from_pcd and the REFERENCE schedule
+    as it is (arguments/__init__.py:73-89: 15 000 iterations, densify_and_prune every 100 from 500 to 11 000 at
+    densify_grad_threshold 2e-4, opacity reset every 3 000, SH degree up every 1 000, position_lr_max_steps 30 000) to whatever
+    size that reaches (`as_trained`); then the model is padded to ~--points Gaussians by ONE densify_and_prune of the
+    reference's own clone / split rule with the threshold at the matching quantile of the accumulated gradient norms, settled
+    for 600 steps, and measured again (`padded`): BASELINE.json's size with a converged scene's walk statistics."""
+    from collections import namedtuple
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.rasterizer import list_share_of
+    from w3d_amd.synth import make_cameras, make_opaque_scene
+    from w3d_amd.train import Trainer, render_views
+    iterations = args.opaque_iterations
+    cams = [c.to(dev) for c in make_cameras(36, args.width, args.height)]
+    # (sized like the benchmark: ~1.9 M opaque Gaussians in the ground truth, a 1 M-point cloud to start from)
+    gt_sc = make_opaque_scene(seed=3, ground=1_400_000, heads=8000, per_head=50, per_stem=15)
+    gt = GaussianModel(3, device=dev)
+    gt.create_from_tensors(gt_sc.xyz, gt_sc.features_dc, gt_sc.features_rest, gt_sc.scaling, gt_sc.rotation, gt_sc.opacity)
+    gt.active_sh_degree = 3
+    for cam, img in zip(cams, render_views(gt, cams, bg)):
+        cam.original_image = img.clamp(0.0, 1.0).contiguous()
+    gt_ws = mean_workload(gt, cams, bg, dev)
+    del gt
+    torch.cuda.empty_cache()
+    train, held = [c for i, c in enumerate(cams) if i % 12 < 10], [c for i, c in enumerate(cams) if i % 12 >= 10]
+    g = torch.Generator().manual_seed(4)
+    init_points = 1_000_000
+    sel = torch.randperm(gt_sc.P, generator=g)[:init_points]
+    pts = gt_sc.xyz[sel] + 0.0015 * torch.randn(init_points, 3, generator=g)
+    col = (0.28209479177387814 * gt_sc.features_dc[sel, 0] + 0.5).clamp(0, 1)
+    PCD = namedtuple("BasicPointCloud", ["points", "colors", "normals"])
+    opt = OptimizationParams()                # the reference's defaults, unchanged except the iteration count when shortened
+    opt.iterations = iterations
+    if iterations < 15_000:                   # (a shortened run keeps the proportions of the schedule)
+        opt.densify_until_iter = int(iterations * 11_000 / 15_000)
+    m = GaussianModel(3, device=dev)
+    m.create_from_pcd(PCD(pts.numpy(), col.numpy(), None), 1.0)
+    m.training_setup(opt)
+    tr = Trainer(m, train, opt, bg, densify=True, cameras_extent=2.0)
+
+    def quality(views):
+        return sum(_psnr_db(i, v.original_image) for i, v in zip(render_views(m, views, bg), views)) / len(views)
+    q0 = (quality(train), quality(held))
+    trace = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(1, iterations + 1):
+        tr.step(it)
+        if it % 1000 == 0 or it == iterations:
+            torch.cuda.synchronize()
+            trace.append([it, m.num_points, round(time.perf_counter() - t0, 2)])
+            log(f"opaque scene: iteration {it}, {m.num_points} Gaussians")
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t0
+    q1 = (quality(train), quality(held))
+    rep = {"ground_truth": {"gaussians": gt_sc.P, "mean_contributors_per_pixel": round(gt_ws["mean_contrib"], 2),
+                            "mean_last_contributor_list_position": round(gt_ws["mean_last"], 2),
+                            "what": "synth.make_opaque_scene(seed=3, ground=1.4 M discs, 8000 ears x 50 on stems x 15)"},
+           "schedule": {"iterations": iterations, "densify_from_iter": opt.densify_from_iter, "densify_until_iter": opt.densify_until_iter,
+                        "densification_interval": opt.densification_interval, "opacity_reset_interval": opt.opacity_reset_interval,
+                        "densify_grad_threshold": opt.densify_grad_threshold, "position_lr_max_steps": opt.position_lr_max_steps,
+                        "initial_points": init_points, "views": "30 training + 6 held out of 36",
+                        "reference": "arguments/__init__.py:73-89 as it is" if iterations == 15_000 else "arguments/__init__.py:73-89, shortened"},
+           "train_seconds": round(t_train, 2), "iters_per_s_overall": round(iterations / t_train, 1),
+           "psnr_train_db_before_after": [round(q0[0], 2), round(q1[0], 2)],
+           "psnr_heldout_db_before_after": [round(q0[1], 2), round(q1[1], 2)],
+           "parameters_finite": bool(torch.isfinite(m.flat).all()), "trace_iteration_gaussians_seconds": trace}
+
+    def measure(tag, it):
+        t = Trainer(m, train, opt, bg, densify=False)
+        meter = StepMeter(t, 1, dev)
+        for _ in range(max(5, args.warmup)):
+            it += 1
+            t.step(it)
+        meas = meter.measure(args.steps, it, args.profile, args.all_stages)
+        ws = mean_workload(m, train, bg, dev)
+        P, HW = m.num_points, args.width * args.height
+        ips = args.steps / meas["elapsed"]
+        out = dict(gaussians=P, value=round(ips, 3), ms_per_step=round(1e3 * meas["elapsed"] / args.steps, 4), steps=args.steps,
+                   stage_ms=meas["stage_ms"], visible_per_view=int(ws["V"]), tile_instances_per_view=int(ws["R"]),
+                   walked_instances_per_view=int(ws["R_walk"]), mean_contributors_per_pixel=round(ws["mean_contrib"], 2), mean_last_contributor_list_position=round(ws["mean_last"], 2),
+                   list_share=list_share_of(m), walk_fraction=None if t.share_rho is None else round(t.share_rho, 3),
+                   roofline=roofline_object(meas, P, ws, HW, True, ips, "opaque_" + tag))
+        return out, meas["it"]
+    it = iterations
+    opt.iterations = opt.densify_until_iter = 10 ** 9        # keep stepping and tracking statistics; Trainer(densify=False) keeps P
+    log("opaque scene: measuring as trained")
+    rep["as_trained"], it = measure("as_trained", it)
+    # ---- pad to --points with the reference's own clone / split rule
+    target = args.points
+    if m.num_points < 0.97 * target:
+        t = Trainer(m, train, opt, bg, densify=False)
+        rounds = []
+        for rnd in range(4):                       # (a Gaussian is cloned / split once per round: the gap may take several)
+            if m.num_points >= 0.97 * target:
+                break
+            m._reset_stats()
+            for _ in range(150):                   # five views of every training camera: fresh densification statistics
+                it += 1
+                t.step(it)
+            grads = (m.xyz_gradient_accum / m.denom).nan_to_num_(0.0).reshape(-1)
+            k = min(target - m.num_points, int((grads > 0).sum()) - 1)
+            if k < 1:
+                break
+            thr = float(torch.topk(grads, k).values[-1])
+            torch.manual_seed(99 + rnd)
+            before = m.num_points
+            m.densify_and_prune(thr, 0.005, 2.0, None)
+            rounds.append({"max_grad": float(f"{thr:.3e}"), "from": before, "to": m.num_points})
+        for _ in range(600):
+            it += 1
+            t.step(it)
+        q2 = (quality(train), quality(held))
+        log(f"opaque scene: padded to {m.num_points} Gaussians, measuring")
+        rep["padded"], it = measure("padded", it)
+        rep["padded"].update(how="rounds of densify_and_prune(max_grad = the quantile of the mean gradient norms of 150 steps that closes "
+                                 "the gap to --points, min_opacity 0.005, no size threshold), then 600 steps at fixed size",
+                             rounds=rounds, psnr_train_db=round(q2[0], 2), psnr_heldout_db=round(q2[1], 2))
+        if with_scale_model:
+            log("scale model: opaque scene (padded)")
+            try:
+                rep["scale_model"], _ = scale_model(m, opt, train, bg, dev, it + 64)
+            except Exception as e:
+                rep["scale_model"] = {"error": repr(e)}
+    return rep
 
 
 # ------------------------------------------------------------------------------------------------ modules-only loop
@@ -1326,7 +1470,7 @@ def main():
             w2 = mean_workload(model, cams, bg, dev)
             trained.update(visible_per_view=int(w2["V"]), tile_instances_per_view=int(w2["R"]),
                            walked_instances_per_view=int(w2["R_walk"]),
-                           mean_contributors_per_pixel=round(w2["mean_contrib"], 2),
+                           mean_contributors_per_pixel=round(w2["mean_contrib"], 2), mean_last_contributor_list_position=round(w2["mean_last"], 2),
                            roofline=roofline_object(tm, P, w2, HW, fused_adam, args.steps / tm["elapsed"], "trained"))
         if do_scale and scale is not None and "error" not in scale:
             _progress("scale model: trained scene")
@@ -1351,6 +1495,19 @@ def main():
             densified = {"error": repr(e)}
         torch.cuda.empty_cache()
 
+    # ... and on a scene of OPAQUE surfaces trained by the reference's schedule as it is (what a photographed plot converges to)
+    opaque = None
+    if not args.no_extras and not args.trained_only and not args.densified_only and args.opaque_iterations > 0 and single and is_fused \
+            and rank == 0:
+        _progress("opaque scene")
+        try:
+            opaque = opaque_scene(args, dev, bg, _progress, with_scale_model=do_scale)
+            if scale is not None and "scale_model" in opaque:
+                scale["opaque_padded"] = opaque.pop("scale_model")
+        except Exception as e:
+            opaque = {"error": repr(e)}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         it_per_s = args.steps / elapsed          # per GPU (weak scaling: every rank runs this step)
         roof = roofline_object(meas, P, ws, HW, fused_adam, it_per_s, "untrained")
@@ -1371,6 +1528,9 @@ def main():
             "trained_ms_per_step": None if trained is None else trained["ms_per_step"],
             "densified_value": None if not densified or "value" not in densified else densified["value"],
             "densified_ms_per_step": None if not densified or "value" not in densified else densified["ms_per_step"],
+            # ... and a scene of opaque surfaces trained by the reference's schedule as it is, padded to --points (opaque_scene)
+            "opaque_value": None if not opaque or "padded" not in opaque else opaque["padded"]["value"],
+            "opaque_ms_per_step": None if not opaque or "padded" not in opaque else opaque["padded"]["ms_per_step"],
             "dropin_iters_per_s": None if dropin is None else dropin["iters_per_s"],
             "modules_only_iters_per_s": None if not modules_only or "iters_per_s" not in modules_only else modules_only["iters_per_s"],
             "config": {"workload": f"C3: plot-shaped synthetic scene, {P} Gaussians, SH degree 3, "
@@ -1380,6 +1540,7 @@ def main():
                        "visible_per_view": int(ws["V"]), "tile_instances_per_view": int(ws["R"]),
                        "walked_instances_per_view": int(ws["R_walk"]),
                        "mean_contributors_per_pixel": round(ws["mean_contrib"], 2),
+                       "mean_last_contributor_list_position": round(ws["mean_last"], 2),
                        "loss": "torch conv2d" if args.torch_loss else "fused HIP L1+SSIM",
                        "step": step_desc,
                        "final_loss": round(final_loss, 6)},
@@ -1402,6 +1563,8 @@ def main():
             out["trained_scene"] = trained
         if densified is not None:
             out["densified_scene"] = densified
+        if opaque is not None:
+            out["opaque_scene"] = opaque
         if exchange is not None:
             out["exchange"] = exchange
         if scale is not None:

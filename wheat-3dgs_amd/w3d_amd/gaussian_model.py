@@ -107,7 +107,8 @@ class GaussianModel:
         # optional behaviours of the raw-parameter rasterizer path (fused_step.render_raw reads them; rasterizer.py header)
         self.tile_cull = True           # exact footprint culling of tile instances (identical outputs, shorter lists)
         self.deterministic = False      # deterministic blend backward (bit-identical gradients run to run)
-        self.list_share = None          # None: rasterizer.LIST_SHARE_DEFAULT; 0 / 1 / 2: w3d_view.list_share (speed only)
+        self.list_share = None          # 0 / 1 / 2: w3d_view.list_share (speed only); None: what a Trainer measured to be best for
+        self._list_share_chosen = None  # this model (train.Trainer.adapt_list_share), else rasterizer.LIST_SHARE_DEFAULT
         self._bucket_claimed = False    # a backward node of this pass already writes the flat gradient bucket directly
         self.percent_dense = 0.0
         self.spatial_lr_scale = 1.0
@@ -397,7 +398,7 @@ class GaussianModel:
         buffers and rebinds.  Per-call caches kept on the model (scratch buffers, capacity hints, streams) are not copied."""
         new = GaussianModel(self.max_sh_degree, device=self.device)
         memo[id(self)] = new
-        for k in ("active_sh_degree", "tile_cull", "deterministic", "list_share", "percent_dense", "spatial_lr_scale", "_train_args"):
+        for k in ("active_sh_degree", "tile_cull", "deterministic", "list_share", "_list_share_chosen", "percent_dense", "spatial_lr_scale", "_train_args"):
             setattr(new, k, getattr(self, k))
         if self.num_points:
             new._bind({n: p.detach() for n, p in self._p.items()})

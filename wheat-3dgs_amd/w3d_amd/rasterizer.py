@@ -32,8 +32,11 @@ LIST_SHARE_DEFAULT = 1
 
 
 def list_share_of(obj):
-    """obj.list_share, or the default when the attribute is missing or None."""
+    """obj.list_share; when that is missing or None: what a Trainer last chose for this object from the measured walk fraction
+    (obj._list_share_chosen, train.Trainer.adapt_list_share), else the default."""
     x = getattr(obj, "list_share", None)
+    if x is None:
+        x = getattr(obj, "_list_share_chosen", None)
     return LIST_SHARE_DEFAULT if x is None else int(x)
 
 

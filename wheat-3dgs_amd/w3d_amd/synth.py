@@ -147,3 +147,52 @@ def small_test_scene(P=200, W=64, H=48, seed=0, scale=0.05, n_cams=4):
     cams = make_cameras(n_cams, W, H, focal_mult=1.2)
     _ = g
     return sc, cams
+
+
+def make_opaque_scene(seed=0, ground=400_000, heads=4000, per_head=30, per_stem=12):
+    """A wheat plot made of OPAQUE surfaces — what a trained 3DGS model of a photographed scene converges to, and the regime
+    make_scene's random translucent slab is not: a ground sheet of flat, nearly opaque discs with a low-frequency texture,
+    and `heads` ellipsoidal ears of `per_head` opaque Gaussians on thin stems.  A pixel's ray meets a handful of them before
+    it saturates (contributors per pixel in the tens at most), whatever the number of Gaussians behind.
+    Pre-activation blocks as make_scene; seeded."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g)       # noqa: E731
+    n = lambda *s: torch.randn(*s, generator=g)      # noqa: E731
+    # ---- ground: jittered discs over the plot (slightly larger than the slab of make_scene so the image borders are covered)
+    gx = r(ground) * 3.4 - 1.7
+    gy = r(ground) * 1.9 - 0.95
+    gz = 0.01 * n(ground)
+    g_xyz = torch.stack([gx, gy, gz], 1)
+    s0 = math.log(1.62 * math.sqrt(3.4 * 1.9 / ground))      # disc sigma = 1.6 x the mean spacing: the sheet is closed (0.0065 at 400 k)
+    g_scale = torch.stack([s0 + 0.25 * n(ground), s0 + 0.25 * n(ground), s0 + math.log(0.15) + 0.2 * n(ground)], 1)
+    g_rot = torch.cat([torch.ones(ground, 1), 0.05 * n(ground, 3)], 1)
+    g_op = 3.5 + 0.5 * n(ground, 1)
+    tex = 0.5 + 0.25 * torch.sin(7.0 * gx + 1.3) * torch.cos(9.0 * gy) + 0.15 * torch.sin(23.0 * gx * gy + 0.7)
+    soil = torch.stack([0.45 * tex + 0.15, 0.32 * tex + 0.12, 0.18 * tex + 0.08], 1) + 0.05 * n(ground, 3)
+    # ---- ears on stems
+    hx, hy = r(heads) * 3.0 - 1.5, r(heads) * 1.5 - 0.75
+    hz = 0.25 + 0.3 * r(heads)
+    tilt = 0.05 * n(heads, 2)
+    idx = torch.arange(heads).repeat_interleave(per_head)
+    off = n(heads * per_head, 3) * torch.tensor([0.012, 0.012, 0.03])
+    e_xyz = torch.stack([hx[idx], hy[idx], hz[idx]], 1) + off
+    e_scale = math.log(0.006) + 0.3 * n(heads * per_head, 3)
+    e_rot = n(heads * per_head, 4)
+    e_op = 3.0 + 0.7 * n(heads * per_head, 1)
+    hue = 0.75 + 0.2 * r(heads)
+    ear = torch.stack([hue, 0.85 * hue, 0.25 + 0.1 * r(heads)], 1)[idx] + 0.06 * n(heads * per_head, 3)
+    sidx = torch.arange(heads).repeat_interleave(per_stem)
+    t = r(heads * per_stem)
+    s_xyz = torch.stack([hx[sidx] + tilt[sidx, 0] * t, hy[sidx] + tilt[sidx, 1] * t, hz[sidx] * t], 1) + 0.001 * n(heads * per_stem, 3)
+    s_scale = torch.stack([math.log(0.0025) + 0.2 * n(heads * per_stem), math.log(0.0025) + 0.2 * n(heads * per_stem),
+                           math.log(0.02) + 0.2 * n(heads * per_stem)], 1)
+    s_rot = torch.cat([torch.ones(heads * per_stem, 1), 0.03 * n(heads * per_stem, 3)], 1)
+    s_op = 2.5 + 0.5 * n(heads * per_stem, 1)
+    stem = torch.tensor([0.35, 0.55, 0.2]) + 0.05 * n(heads * per_stem, 3)
+    xyz = torch.cat([g_xyz, e_xyz, s_xyz])
+    rgb = torch.cat([soil, ear, stem]).clamp(0.02, 0.98)
+    P = xyz.shape[0]
+    f_dc = ((rgb - 0.5) / 0.28209479177387814)[:, None, :]
+    f_rest = 0.03 * n(P, 15, 3)
+    return SynthScene(xyz.contiguous(), f_dc.contiguous(), f_rest, torch.cat([g_scale, e_scale, s_scale]).contiguous(),
+                      torch.cat([g_rot, e_rot, s_rot]).contiguous(), torch.cat([g_op, e_op, s_op]).contiguous())

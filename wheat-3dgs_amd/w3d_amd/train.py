@@ -126,15 +126,15 @@ class Trainer:
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.perm = torch.randperm(len(cameras), generator=g).tolist()
         self.last = {}
-        # list_share: None on the model = chosen here from the measured walk fraction (adapt_list_share); a number = the caller's
-        self._share_auto = getattr(model, "list_share", None) is None
+        # list_share: None on the model = chosen here from the measured walk fraction (adapt_list_share, kept on the model as
+        # _list_share_chosen); a number = the caller's
         self._share_steps = 0
         self.share_rho = None
 
     def adapt_list_share(self, handle):
         """Every SHARE_PROBE_EVERY fused steps (and on the first three): the walked fraction of the view just rendered decides
         model.list_share for the following steps (class comment).  One host-synchronous reduction of 7 500 integers."""
-        if not self._share_auto:
+        if getattr(self.model, "list_share", None) is not None:
             return
         self._share_steps += 1
         if self._share_steps > 3 and self._share_steps % self.SHARE_PROBE_EVERY:
@@ -153,7 +153,7 @@ class Trainer:
             edge = lo if {want, mode} == {1, 2} else hi if {want, mode} == {0, 1} else None
             if edge is not None and abs(r - edge) < h:
                 want = mode
-        self.model.list_share = want
+        self.model._list_share_chosen = want
 
     def camera_for(self, iteration):
         """rank r of N renders camera perm[(it*N + r) mod n] — N distinct views per step."""
