@@ -494,7 +494,7 @@ def test_settings_carry_the_optional_switches_behind_the_reference_fields():
     s = GaussianRasterizationSettings(*range(12))
     assert s._fields[:12] == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
                               "projmatrix", "sh_degree", "campos", "prefiltered", "debug")
-    assert s.tile_cull is True and s.deterministic is False
+    assert s.tile_cull is True and s.deterministic is False and s.list_share == 1 and s._fields[12:] == ("tile_cull", "deterministic", "list_share")
     f = FlashSplatRasterizationSettings(*range(12))
     assert f._fields[12:14] == ("mask_grad", "num_obj") and f.num_obj == 2 and f.tile_cull is True
     # the list-length hint lives with the caller's object, not in the module
@@ -502,7 +502,8 @@ def test_settings_carry_the_optional_switches_behind_the_reference_fields():
     list_capacity(a, 10, 20).observe(77)
     assert list_capacity(a, 10, 20).known == 77 and list_capacity(b, 10, 20).known == 0 and list_capacity(a, 20, 10).known == 0
     import w3d_amd.rasterizer as wr
-    assert not [n for n in vars(wr) if n.isupper() and n not in ("KNN_GRID_FROM",)]      # no module-level switches left
+    # no module-level switches left (two constants: the brute-force / grid kNN crossover and the default of the settings' list_share)
+    assert not [n for n in vars(wr) if n.isupper() and n not in ("KNN_GRID_FROM", "LIST_SHARE_DEFAULT")]
 
 
 def test_inplace_collective_aliasing_is_checked():
