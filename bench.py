@@ -992,23 +992,11 @@ def densified_scene(args, dev, bg, log, with_scale_model=False):
 
 
 # ------------------------------------------------------------------------------------------------ opaque-surface scene
-def opaque_scene(args, dev, bg, log, with_scale_model=False):
-    """A trained scene that SATURATES like a photographed one.  The benchmark scene is a random translucent slab (its pixels
-    saturate after 15 % of their lists, 107 k of 1.2 M visible Gaussians get a gradient) and the densified leg fits renders of
-    such a slab (724 contributors per pixel at the end); a real 3DGS model is made of opaque surfaces, tens of contributors per
-    pixel.  Here the ground truth is synth.make_opaque_scene — a sheet of opaque ground discs with ears on stems — seen by the
-    same 36 cameras (30 training, 6 held out); a 150 k-point cloud of it goes through create_from_pcd and the REFERENCE schedule
-    as it is (arguments/__init__.py:73-89: 15 000 iterations, densify_and_prune every 100 from 500 to 11 000 at
-    densify_grad_threshold 2e-4, opacity reset every 3 000, SH degree up every 1 000, position_lr_max_steps 30 000) to whatever
-    size that reaches (`as_trained`); then the model is padded to ~--points Gaussians by ONE densify_and_prune of the
-    reference's own clone / split rule with the threshold at the matching quantile of the accumulated gradient norms, settled
-    for 600 steps, and measured again (`padded`): BASELINE.json's size with a converged scene's walk statistics."""
-    from collections import namedtuple
-    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
-    from w3d_amd.rasterizer import list_share_of
+def opaque_views(args, dev, bg):
+    """(training views, held-out views, ground-truth scene, ground-truth workload) of the opaque-surface leg"""
+    from w3d_amd.gaussian_model import GaussianModel
     from w3d_amd.synth import make_cameras, make_opaque_scene
-    from w3d_amd.train import Trainer, render_views
-    iterations = args.opaque_iterations
+    from w3d_amd.train import render_views
     cams = [c.to(dev) for c in make_cameras(36, args.width, args.height)]
     # (sized like the benchmark: ~1.9 M opaque Gaussians in the ground truth, a 1 M-point cloud to start from)
     gt_sc = make_opaque_scene(seed=3, ground=1_400_000, heads=8000, per_head=50, per_stem=15)
@@ -1020,7 +1008,27 @@ def opaque_scene(args, dev, bg, log, with_scale_model=False):
     gt_ws = mean_workload(gt, cams, bg, dev)
     del gt
     torch.cuda.empty_cache()
-    train, held = [c for i, c in enumerate(cams) if i % 12 < 10], [c for i, c in enumerate(cams) if i % 12 >= 10]
+    return [c for i, c in enumerate(cams) if i % 12 < 10], [c for i, c in enumerate(cams) if i % 12 >= 10], gt_sc, gt_ws
+
+
+def opaque_scene(args, dev, bg, log, with_scale_model=False, return_model=False):
+    """A trained scene that SATURATES like a photographed one.  The benchmark scene is a random translucent slab (its pixels
+    saturate after 15 % of their lists, 107 k of 1.2 M visible Gaussians get a gradient) and the densified leg fits renders of
+    such a slab (724 contributors per pixel at the end); a real 3DGS model is made of opaque surfaces, tens of contributors per
+    pixel.  Here the ground truth is synth.make_opaque_scene — a sheet of opaque ground discs with ears on stems — seen by the
+    same 36 cameras (30 training, 6 held out); a 1 M-point cloud of it goes through create_from_pcd and the REFERENCE schedule
+    as it is (arguments/__init__.py:73-89: 15 000 iterations, densify_and_prune every 100 from 500 to 11 000 at
+    densify_grad_threshold 2e-4, opacity reset every 3 000, SH degree up every 1 000, position_lr_max_steps 30 000) to whatever
+    size that reaches (`as_trained`); then the model is padded to ~--points Gaussians by rounds of densify_and_prune — the
+    reference's own clone / split rule with the threshold at the quantile of the accumulated gradient norms that closes the
+    gap —, settled for 600 steps, and measured again (`padded`): BASELINE.json's size with a converged scene's walk statistics."""
+    from collections import namedtuple
+    from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+    from w3d_amd.rasterizer import list_share_of
+    from w3d_amd.synth import make_cameras, make_opaque_scene
+    from w3d_amd.train import Trainer, render_views
+    iterations = args.opaque_iterations
+    train, held, gt_sc, gt_ws = opaque_views(args, dev, bg)
     g = torch.Generator().manual_seed(4)
     init_points = 1_000_000
     sel = torch.randperm(gt_sc.P, generator=g)[:init_points]
@@ -1120,6 +1128,8 @@ def opaque_scene(args, dev, bg, log, with_scale_model=False):
                 rep["scale_model"], _ = scale_model(m, opt, train, bg, dev, it + 64)
             except Exception as e:
                 rep["scale_model"] = {"error": repr(e)}
+    if return_model:
+        return rep, m, opt, train, it
     return rep
 
 

@@ -23,7 +23,7 @@ import bench  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--scene", default="untrained", choices=("untrained", "trained", "densified"))
+    ap.add_argument("--scene", default="untrained", choices=("untrained", "trained", "densified", "opaque"))
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=40, help="steps before the window (>= 36 so that every camera's walk hint exists)")
     ap.add_argument("--model-file", default=None)
@@ -42,7 +42,20 @@ def main():
     torch.cuda.set_device(dev)
     bg = torch.zeros(3, device=dev)
     have = a.model_file and os.path.exists(a.model_file)
-    if a.scene == "densified":
+    if a.scene == "opaque":             # bench.opaque_scene: trained by the reference schedule as it is, padded to --points
+        if have:
+            pack = torch.load(a.model_file, weights_only=False)
+            cams = bench.opaque_views(args, dev, bg)[0]
+            opt = pack["opt"]
+            model = GaussianModel(3, device=dev)
+            model.restore(pack["model"], opt)
+            it = pack["it"]
+        else:
+            _, model, opt, cams, it = bench.opaque_scene(args, dev, bg, bench._progress, return_model=True)
+            if a.model_file:
+                torch.save({"model": model.capture(), "opt": opt, "it": it}, a.model_file)
+        opt.iterations, opt.densify_until_iter = 10 ** 9, 10 ** 9
+    elif a.scene == "densified":
         if have:
             pack = torch.load(a.model_file, weights_only=False)
             cams = bench.densified_views(args, dev, bg)[0]
