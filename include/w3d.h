@@ -144,7 +144,11 @@ int w3d_forward_stage1(const w3d_view *view, int32_t P, const float *means3D, co
  * (1,H,W); out_depth and out_alpha may BOTH be NULL when no FlashSplat output is asked for (a training step whose loss only reads the
  * colour image: the blend then skips the two channels).  FlashSplat extras are all nullable: gt_mask (H,W) fp32 labels in [0,num_obj],
  * used_count (num_obj+1,P) is ACCUMULATED into (caller zero-fills), contrib_num (H,W) int32,
- * proj_xy (P,2), gs_depth (P,). */
+ * proj_xy (P,2), gs_depth (P,).
+ * The FlashSplat outputs are FORWARD-ONLY by design: the fork's `mask_grad` setting (a gradient through used_count) is hard-coded
+ * to False at the reference's only construction site (gaussian_renderer/__init__.py:145) and every FlashSplat call site runs
+ * under no_grad (run_3d_seg.py:91,130,362; eval_wheatgs.py), so no entry point of this ABI differentiates them; the Python
+ * host refuses mask_grad=True (NotImplementedError) rather than returning an un-differentiated result silently. */
 int w3d_forward_stage2(const w3d_view *view, int32_t P, void *state, void *scratch, uint32_t *point_list,
                        uint64_t list_capacity, float *out_color, float *out_depth, float *out_alpha,
                        const float *gt_mask, int32_t num_obj, float *used_count, int32_t *contrib_num,

@@ -552,6 +552,11 @@ def test_structure_change_schedule_follows_the_reference_loop():
             assert tr._structure_change_due(it) == (densify or reset), (white, it)
             if it < opt.densify_until_iter:
                 assert tr._opacity_reset_due(it) == reset, (white, it)
+    # the flag follows the background the caller hands in, as dataset.white_background sets both in the reference (:44, :109)
+    assert Trainer(m, [0, 1, 2], opt, torch.ones(3), densify=True, fused=False).white_background is True
+    assert Trainer(m, [0, 1, 2], opt, torch.zeros(3), densify=True, fused=False).white_background is False
+    assert Trainer(m, [0, 1, 2], opt, torch.ones(3), densify=True, fused=False, white_background=False).white_background is False
+    assert Trainer(m, [0, 1, 2], opt, torch.ones(3), densify=True, fused=False)._opacity_reset_due(opt.densify_from_iter)
     assert tr.background_for(1) is tr.bg
     opt.random_background = True
     a, b = tr.background_for(1), tr.background_for(2)

@@ -418,7 +418,10 @@ class FlashSplatRasterizer(torch.nn.Module):
         _check_variants(shs, colors_precomp, scales, rotations, cov3D_precomp)
         s = self.raster_settings
         if getattr(s, "mask_grad", False):
-            raise NotImplementedError("mask_grad=True is not used by Wheat-3DGS and is not implemented")
+            # rejected, not deferred (include/w3d.h, w3d_forward_stage2): the reference hard-codes mask_grad=False
+            # (gaussian_renderer/__init__.py:145) and calls the FlashSplat rasterizer under no_grad only
+            raise NotImplementedError("mask_grad=True: the FlashSplat outputs of this rasterizer are forward-only — Wheat-3DGS constructs "
+                                      "its settings with mask_grad=False (gaussian_renderer/__init__.py:145) and never differentiates them")
         with torch.no_grad():
             color, radii, depth, alpha, _, extras = _forward_impl(
                 s, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,

@@ -68,9 +68,11 @@ class Trainer:
 
     def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
                  densify=True, loss_fn=photometric_loss, fused=None, force_exchange=False, fused_adam=True,
-                 exchange="rows", early_gather=False, lowrank_chunks=None, rows_max_fraction=None, white_background=False):
-        """white_background: the dataset flag of reference train_vanilla_3dgs.py:109 — with it the opacities are ALSO reset once at
-        iteration == opt.densify_from_iter (besides every opacity_reset_interval).
+                 exchange="rows", early_gather=False, lowrank_chunks=None, rows_max_fraction=None, white_background=None):
+        """white_background: the dataset flag of reference train_vanilla_3dgs.py:44,109 — with it the opacities are ALSO reset once
+        at iteration == opt.densify_from_iter (besides every opacity_reset_interval).  The reference derives the background colour
+        AND this extra reset from the one flag; None (default) does the same from the other end: a `background` of all ones is a
+        white-background dataset.
         fused_adam: single GPU — the optimizer update is applied by the backward kernel itself
         (fused_step.backward_raw_adam), except in the iterations that densify / reset opacity (there the reference
         skips the replaced parameters' update).
@@ -89,6 +91,8 @@ class Trainer:
         self.pipe = pipe or PipelineParams()
         self.extent = cameras_extent
         self.densify = densify
+        if white_background is None:
+            white_background = bool(torch.all(torch.as_tensor(background).detach().float() == 1.0))
         self.white_background = bool(white_background)
         self.loss_fn = loss_fn
         # fused=None: use the fused raw-parameter step whenever the model lives on the GPU, the
