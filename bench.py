@@ -1265,8 +1265,10 @@ def main():
     multi = world > 1 or force_dist        # (--force-dist: the N > 1 code below runs on a 1-rank group, so that one GPU can test it)
     if multi and trainer.fused and args.exchange == "auto":
         autotune = {}
-        for mode in (("rows", "lowrank") if world <= 32 else ("lowrank",)):   # (rows: one 32-bit view mask per Gaussian)
-            trainer.exchange_mode = mode
+        # (rows: one 32-bit view mask per Gaussian; lowrank_early: the low-rank form with its colour-gradient all-gather issued
+        #  between the blend backward and the per-Gaussian backward, so that 12 of its 23 bytes per Gaussian travel under compute)
+        for mode in (("rows", "lowrank", "lowrank_early") if world <= 32 else ("lowrank", "lowrank_early")):
+            trainer.exchange_mode, trainer.early_gather = mode.split("_")[0], mode.endswith("_early")
             for _ in range(2):
                 it += 1
                 trainer.step(it)
@@ -1280,7 +1282,8 @@ def main():
             dt = torch.tensor([(time.perf_counter() - t0) / 6], device=dev, dtype=torch.float64)
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)                   # the same number, hence the same choice, on every rank
             autotune[mode] = round(1e3 * float(dt), 4)
-        trainer.exchange_mode = min(autotune, key=autotune.get)
+        best = min(autotune, key=autotune.get)
+        trainer.exchange_mode, trainer.early_gather = best.split("_")[0], best.endswith("_early")
     if multi:
         selfcheck = {"mode_requested": trainer.exchange_mode if trainer.fused else "dense",
                      "replicas_identical_after_warmup": replicas_identical(model, world, dev)}
@@ -1306,7 +1309,8 @@ def main():
     exchange = None
     if multi:
         exchange = exchange_bandwidth(model, world, dev, rows=max(getattr(trainer, "last_row_counts", None) or [0]))
-        exchange["mode"] = trainer.exchange_mode if trainer.fused else "dense"
+        exchange["mode"] = (trainer.exchange_mode + ("_early" if trainer.exchange_mode == "lowrank" and trainer.early_gather else "")) \
+            if trainer.fused else "dense"
         exchange["selfcheck"] = selfcheck
         if autotune is not None:
             exchange["autotune_ms_per_step"] = autotune

@@ -1,4 +1,4 @@
-"""-m gpu: bench.py's N > 1 code — exchange autotune (rows vs low-rank), replica self-check, the `exchange` object of the
+"""-m gpu: bench.py's N > 1 code — exchange autotune (rows vs low-rank vs low-rank with the early colour gather), replica self-check, the `exchange` object of the
 JSON line, stdout hygiene — run on a 1-rank RCCL group (`--force-dist`), the only world a 1-GPU box offers.  The collectives
 are real RCCL calls; what N = 1 cannot show is wire time (the driver's SCALE run) and disagreement between replicas
 (tests/test_gpu_two_ranks.py)."""
@@ -28,7 +28,7 @@ def test_bench_multi_rank_code_on_one_rank_group(exchange):
     ex = out["exchange"]
     assert out["n_gpus"] == 1 and ex["selfcheck_ok"] is True and ex["selfcheck"]["replicas_identical_after_warmup"] is True
     if exchange == "auto":
-        assert set(ex["autotune_ms_per_step"]) == {"rows", "lowrank"} and ex["mode"] in ("rows", "lowrank")
+        assert set(ex["autotune_ms_per_step"]) == {"rows", "lowrank", "lowrank_early"} and ex["mode"] in ex["autotune_ms_per_step"]
         assert ex["mode"] == min(ex["autotune_ms_per_step"], key=ex["autotune_ms_per_step"].get)
         if ex["mode"] == "rows":
             assert ex["rows"]["steps_by_form"]["rows"] > 0 and len(ex["rows"]["rows_per_view_last_step"]) == 1
