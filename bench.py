@@ -437,13 +437,13 @@ def cpu_baseline(args, own_view0=None):
         c1 = out["c1"]
         c1["torch_restatement_bracket"] = "render + 0.8*L1+0.2*(1-SSIM) + backward (train_vanilla_3dgs.py:56,82)"
         # n = all host cores (stated), 3 warm-up + 10 timed, median, cameras cycled — if ONE view with that
-        # many threads fits 20 s; the 16-thread figure (thousands of tiny ops per view: more threads mostly add fork / join
+        # many threads fits ~9 s; the 16-thread figure (thousands of tiny ops per view: more threads mostly add fork / join
         # time) beside it under the same rule
         runs = {}
         for nt in ([cores] if cores <= 16 else [cores, 16]):
-            probe = torch_protocol(nt, 0, 1, 20)
+            probe = torch_protocol(nt, 0, 1, 14)
             if "step_s" not in probe:
-                runs[nt] = {"threads": nt, "protocol": "not completed: one view did not finish in 20 s", **probe}
+                runs[nt] = {"threads": nt, "protocol": "not completed: one view (plus ~5 s of imports) did not finish in 14 s", **probe}
                 continue
             full = 13 * probe["step_s"] <= 45.0
             r = torch_protocol(nt, *((3, 10) if full else (1, 3)), 120)
