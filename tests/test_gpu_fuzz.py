@@ -26,6 +26,13 @@ def test_culls_change_nothing_on_random_shapes():
     assert "cases 400 from seed 123: 0 with differences" in out, out[-3000:]
 
 
+def test_shared_lists_change_nothing_on_random_shapes():
+    """list_share 0 vs 1 vs 2 (tile_cull on, atomic backward): images, radii, final_T and FlashSplat contributor counts
+    bit-identical on blobs, needles, pancakes and mixed shapes in random (ragged) frames; gradients of the blobs to atomic noise."""
+    out = _run("fuzz_share_probe.py", 300, 555)
+    assert "cases 300 from seed 555: 0 with differences" in out, out[-3000:]
+
+
 def test_integer_work_matches_the_oracle_on_random_shapes():
     """radii, per-tile ranges, depth-ordered lists bit-identical to the oracle's; images for the well-conditioned shapes."""
     out = _run("fuzz_oracle_probe.py", 400, 321)
