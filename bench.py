@@ -387,8 +387,13 @@ def cpu_baseline(args, own_view0=None):
     sweep = {}
     for nt in sorted({n for n in (8, 32, 128, cores) if n <= cores}):
         sweep[nt] = c_oracle_protocol(10_000, 400, 300, 1, 3, 4, nthreads=nt)[1]
-    c1_threads = min(sweep, key=sweep.get)
-    f1, s1 = c_oracle_protocol(10_000, 400, 300, 3, 10, 4, nthreads=c1_threads)
+    # (the short sweep is noisy on a box whose other cores are busy: the protocol runs with its two best counts, the better one is quoted)
+    best = None
+    for nt in sorted(sweep, key=sweep.get)[:2]:
+        f, t = c_oracle_protocol(10_000, 400, 300, 3, 10, 4, nthreads=nt)
+        if best is None or t < best[2]:
+            best = (nt, f, t)
+    c1_threads, f1, s1 = best
     out = {"value": round(1.0 / s3, 5), "unit": "iters/s", "cores": cores, "kind": "port",
            "bracket": "rasterizer forward + backward only (no loss, no Adam)",
            "sample": f"one {args.points}-Gaussian {args.width}x{args.height} view of the benchmark scene through the C oracle (OpenMP "
