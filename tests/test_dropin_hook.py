@@ -303,6 +303,32 @@ SIDE_BY_SIDE = textwrap.dedent('''
     res["after_switch"] = [max(float((getattr(a, n).detach() - getattr(ref, n).detach()).abs().max()) for n in names),
                            max(float((getattr(b, n).detach() - getattr(ours, n).detach()).abs().max()) for n in names)]
     res["moments"] = float((a.optimizer.moments()["xyz"][0] - ref.optimizer.state[ref._xyz]["exp_avg"]).abs().max())
+    # densify_and_prune (scene/gaussian_model.py:445-459) on both, twice, with steps in between: same rows in the same order
+    dens = []
+    for rnd in range(2):
+        for m_ in (ref, ours):
+            gg = torch.Generator().manual_seed(50 + rnd)
+            n = m_.get_xyz.shape[0]
+            m_.xyz_gradient_accum = torch.rand(n, 1, generator=gg) * 6e-4
+            m_.denom = torch.ones(n, 1)
+            m_.max_radii2D = torch.rand(n, generator=gg) * 30
+            with torch.no_grad():
+                m_._opacity[::7] = -8.0                      # some below min_opacity
+            torch.manual_seed(77 + rnd)                      # the split samples (torch.normal) draw from the global generator
+            m_.densify_and_prune(0.0002, 0.005, 1.0, 20 if rnd else None)
+        same = ref.get_xyz.shape[0] == ours.get_xyz.shape[0]
+        err = max(float((getattr(ref, n).detach() - getattr(ours, n).detach()).abs().max()) for n in names) if same else -1.0
+        mom = float((ours.optimizer.moments()["scaling"][1] - ref.optimizer.state[ref._scaling]["exp_avg_sq"]).abs().max()) if same else -1.0
+        dens.append([int(ref.get_xyz.shape[0]), int(ours.get_xyz.shape[0]), err, mom,
+                     float((ref.max_radii2D - ours.max_radii2D).abs().max()) if same else -1.0])
+        for m_ in (ref, ours):
+            for n in names:
+                p_ = getattr(m_, n)
+                p_.grad = torch.full(p_.shape, 1e-3)
+            m_.optimizer.step()
+            m_.optimizer.zero_grad(set_to_none=True)
+    res["densify"] = dens
+    res["after_densify"] = max(float((getattr(ref, n).detach() - getattr(ours, n).detach()).abs().max()) for n in names)
     print("RESULT " + json.dumps(res))
 ''')
 
@@ -312,7 +338,8 @@ def test_the_references_own_gaussian_model_beside_ours():
     """scene.gaussian_model.GaussianModel AS SHIPPED BY THE REFERENCE (kept as `_reference_GaussianModel` by the redirect) and
     this repo's class through the same calls on the CPU: create_from_pcd, training_setup with the reference's own
     OptimizationParams object, six iterations of update_learning_rate / add_densification_stats / optimizer.step / zero_grad with
-    an opacity reset in the middle, then checkpoints restored across the two classes in both directions and one more step."""
+    an opacity reset in the middle, checkpoints restored across the two classes in both directions and one more step, then two live
+    rounds of densify_and_prune (clone, split with the same random samples, prune by opacity / size) with optimizer steps between."""
     r, _ = _run(SIDE_BY_SIDE % {"ref": REF, "pkg": PKG, "root": ROOT})
     assert all(v == 0.0 for v in r["create"].values()), r["create"]                   # identical initialisation, bit for bit
     assert r["groups_ref"] == r["groups_ours"] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
@@ -321,3 +348,6 @@ def test_the_references_own_gaussian_model_beside_ours():
     assert r["step_err"] <= 1e-6 and r["stats"][0] <= 1e-9 and r["stats"][1] == 0.0, r
     assert r["tuple_lens"] == [13, 13] and r["ref_to_ours"] == 0.0 and r["ours_to_ref"] == 0.0
     assert max(r["after_switch"]) <= 1e-6 and r["moments"] <= 1e-9, r
+    for n_ref, n_ours, err, mom, rad in r["densify"]:           # two live densify_and_prune rounds: same rows, same order
+        assert n_ref == n_ours > 300 and err <= 2e-6 and mom <= 1e-9 and rad == 0.0, r["densify"]
+    assert r["after_densify"] <= 2e-6
