@@ -328,6 +328,30 @@ SIDE_BY_SIDE = textwrap.dedent('''
             m_.optimizer.step()
             m_.optimizer.zero_grad(set_to_none=True)
     res["densify"] = dens
+    # reset_label (scene/gaussian_model.py:465-506: run_3d_seg.py:326 labels every identified object through it): random label
+    # histories and masks, the sequence of return values and the label vectors must be the same
+    import contextlib, io
+    rl = {"returns_equal": True, "labels_equal": True, "merged": 0, "new_inside_old": 0, "plain": 0}
+    for case in range(40):
+        gg = torch.Generator().manual_seed(900 + case)
+        n = ref.get_xyz.shape[0]
+        wo = torch.zeros(n, 1, dtype=torch.int)
+        for obj in range(1, 5):                                # earlier objects: random blobs of indices
+            lo = int(torch.randint(0, n - 40, (1,), generator=gg))
+            wo[lo:lo + int(torch.randint(5, 40, (1,), generator=gg))] = obj
+        ref._which_object, ours._which_object = wo.clone(), wo.clone()
+        for obj in range(5, 9):
+            lo = int(torch.randint(0, n - 60, (1,), generator=gg))
+            mask = torch.zeros(n, dtype=torch.bool)
+            mask[lo:lo + int(torch.randint(3, 60, (1,), generator=gg))] = True
+            mask &= torch.rand(n, generator=gg) < float(torch.rand(1, generator=gg)) * 0.5 + 0.5
+            with contextlib.redirect_stdout(io.StringIO()):
+                ra = ref.reset_label(obj_used_mask=mask, set_which_object_to=obj)
+            rb = ours.reset_label(obj_used_mask=mask, set_which_object_to=obj)
+            rl["returns_equal"] &= (ra == rb)
+            rl["labels_equal"] &= bool(torch.equal(ref._which_object.reshape(-1), ours._which_object.reshape(-1)))
+            rl["merged" if ra is not None else "plain"] += 1
+    res["reset_label"] = rl
     res["after_densify"] = max(float((getattr(ref, n).detach() - getattr(ours, n).detach()).abs().max()) for n in names)
     print("RESULT " + json.dumps(res))
 ''')
@@ -351,3 +375,5 @@ def test_the_references_own_gaussian_model_beside_ours():
     for n_ref, n_ours, err, mom, rad in r["densify"]:           # two live densify_and_prune rounds: same rows, same order
         assert n_ref == n_ours > 300 and err <= 2e-6 and mom <= 1e-9 and rad == 0.0, r["densify"]
     assert r["after_densify"] <= 2e-6
+    rl = r["reset_label"]                                       # 160 labelling calls, merges into earlier objects among them
+    assert rl["returns_equal"] and rl["labels_equal"] and rl["merged"] >= 3 and rl["plain"] >= 50, rl
