@@ -60,6 +60,23 @@ def test_mask_iou_and_bbox_on_the_device():
     assert iou1.numel() == 0 and bbox1 == (0, 0, 4, 6)
 
 
+def test_mask_work_matches_the_references_own_helpers():
+    """tests/golden/masks.npz holds what utils/wheatgs_utils.py ITSELF returns (PILtoTorch + binarize_mask; alpha > 0.5 ->
+    get_bbox_from_mask, calculate_seg_iou — tests/golden/make_golden_masks.py imports them): the device kernels must agree
+    exactly (bbox, pixel count, binarised masks) and to 1e-12 (IoU)."""
+    from w3d_amd.segmentation import binarize_mask_device, mask_iou_device
+    z = np.load(os.path.join(GOLD, "masks.npz"))
+    for i in range(3):
+        got = binarize_mask_device(z[f"pixels{i}"]).cpu().numpy()
+        assert got.shape == z[f"binary{i}"].shape and np.array_equal(got, z[f"binary{i}"]), i
+    iou, bbox, n_pred = mask_iou_device(torch.from_numpy(z["alpha"]).cuda(), torch.from_numpy(z["masks"]).cuda())
+    assert bbox == tuple(int(v) for v in z["bbox"]) and n_pred == int(z["n_pred"])
+    assert np.abs(iou.numpy() - z["iou"]).max() < 1e-12
+    assert bool(z["bbox_empty_is_none"]) and float(z["iou_empty_union"]) == 0.0
+    iou0, bbox0, n0 = mask_iou_device(torch.zeros(4, 4, device="cuda"), torch.zeros(1, 4, 4, dtype=torch.bool, device="cuda"))
+    assert bbox0 is None and n0 == 0 and float(iou0[0]) == 0.0           # the same two edge cases on the device
+
+
 def test_multi_instance_opt_on_gpu_tensors_matches_the_reference_golden():
     from w3d_amd.segmentation import multi_instance_opt
     z = np.load(os.path.join(GOLD, "multi_instance_opt.npz"))
