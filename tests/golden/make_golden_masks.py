@@ -27,10 +27,10 @@ for i, shape in enumerate(((75, 133), (48, 64, 3), (120, 160))):
     out[f"pixels{i}"] = a
     out[f"binary{i}"] = U.binarize_mask(t).squeeze(0).numpy()
 # (2) alpha image -> alpha > 0.5 -> bbox, IoU against candidate masks (run_3d_seg.py:131-163)
-H, W, K = 301, 517, 7
+H, W, K = 151, 259, 5
 alpha = rng.rand(H, W).astype(np.float32)
 alpha[:40] = 0.0
-alpha[:, 500:] = 0.2
+alpha[:, 250:] = 0.2
 masks = rng.rand(K, H, W) < np.linspace(0.05, 0.9, K)[:, None, None]
 masks[3] = False
 pred = alpha > 0.5
