@@ -21,7 +21,7 @@
  *        <- the per-mask inner call of run_3d_seg.py:88-97 / :127-134 (same view, another gt_mask)
  *   w3d_backward_raw_adam (next-row N2, single GPU)
  *        <- train_vanilla_3dgs.py:80 loss.backward() + :113-115 optimizer.step() / zero_grad()
- *   w3d_backward_raw_lowrank, w3d_sh_adam_lowrank, w3d_pack_gradient_rows, w3d_apply_gradient_rows,
+ *   w3d_backward_raw_lowrank, w3d_sh_adam_lowrank, w3d_pack_gradient_rows, w3d_backward_raw_rows, w3d_apply_gradient_rows,
  *   w3d_index_gradient_rows, w3d_rows_norm_sum, w3d_rows_adam (row e, view-parallel exchange)
  *        <- no reference counterpart (the reference is single-GPU); same arithmetic as
  *           w3d_backward_raw + w3d_adam_step on the mean gradient of the views
@@ -119,7 +119,7 @@ typedef struct w3d_view {
 
 /* Version of this ABI: major * 100 + minor.  The major number changes whenever a struct of this header changes its layout or
  * an entry point its signature; a binding must refuse a library whose major number differs from the header it mirrors. */
-#define W3D_ABI_VERSION 300
+#define W3D_ABI_VERSION 301
 int w3d_version(void);
 const char *w3d_last_error(void);
 
@@ -286,6 +286,14 @@ int w3d_sh_adam_lowrank(int32_t P, int32_t n_views, int32_t sh_degree, const flo
  * side, nothing: reference train_vanilla_3dgs.py is single-GPU (SURVEY.md §8e defines the view-parallel step). */
 int w3d_pack_gradient_rows(int32_t P, const float *dcolor, const w3d_raw_grads *grads, const float *grad2d_norm,
                            float norm_scale, float *rows_out, uint32_t capacity_rows, uint32_t *count, w3d_stream_t stream);
+/* w3d_backward_raw_lowrank + w3d_pack_gradient_rows in one pass (ABI 301): the per-Gaussian backward appends the non-zero rows
+ * itself — the same rows, selected by the same rule, in unspecified order — and writes no dense gradient array at all (the 14
+ * floats per Gaussian of the two-call form are written and read again only to be packed: 120 MB at 2 M Gaussians).
+ * norm_scale = 0: no ||dL/dmean2D|| in the rows (densification over).  count is zeroed by the call. */
+int w3d_backward_raw_rows(const w3d_view *view, int32_t P, const w3d_raw_params *params, const void *state,
+                          const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                          float norm_scale, float *rows_out, uint32_t capacity_rows, uint32_t *count, void *scratch,
+                          w3d_stream_t stream);
 int w3d_apply_gradient_rows(int32_t P, const float *rows, const uint32_t *count, uint32_t max_rows, float *dcolor_view,
                             const w3d_raw_grads *sums, float *norm_sum, w3d_stream_t stream);
 /* The optimizer step straight from the gathered rows, without dense per-view arrays.  rows_all: (n_views, cap_rows, 16) as

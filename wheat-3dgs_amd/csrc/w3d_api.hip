@@ -415,6 +415,34 @@ int w3d_backward_raw_lowrank(const w3d_view *view, int32_t P, const w3d_raw_para
                                           grads->opacity, grads->scaling, grads->rotation, nullptr, &ra, stream);
 }
 
+int w3d_backward_raw_rows(const w3d_view *view, int32_t P, const w3d_raw_params *prm, const void *state,
+                          const uint32_t *point_list, const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                          float norm_scale, float *rows_out, uint32_t capacity_rows, uint32_t *count, void *scratch,
+                          w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    int rc = check_view(view);
+    if (rc) return rc;
+    W3DLayout L;
+    rc = w3d_make_layout(P, view->image_height, view->image_width, &L);
+    if (rc) { w3d_set_error("bad sizes"); return rc; }
+    w3d_set_list_share(&L, view);
+    if (!count) { w3d_set_error("NULL buffer"); return W3D_ERR_INVALID; }
+    if (P == 0) { W3D_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(uint32_t), stream)); return W3D_OK; }
+    if (!state || !scratch || !prm || !dL_dcolor || !rows_out || (reinterpret_cast<uintptr_t>(rows_out) & 15)) {
+        w3d_set_error("NULL or misaligned buffer");
+        return W3D_ERR_INVALID;
+    }
+    const char *st = static_cast<const char *>(state);
+    float *grad2d = static_cast<float *>(scratch);
+    rc = w3d_launch_render_backward(L, *view, st, point_list, dL_dcolor, dL_ddepth, dL_dalpha, grad2d, stream);
+    if (rc) return rc;
+    W3DRawBwdArgs ra = {};
+    ra.f_rest = prm->f_rest; ra.opacity_logit = prm->opacity; ra.lowrank = 2;
+    ra.rows_out = rows_out; ra.rows_cap = capacity_rows; ra.rows_count = count; ra.norm_scale = norm_scale;
+    return w3d_launch_preprocess_backward(L, *view, prm->xyz, prm->f_dc, nullptr, prm->scaling, prm->rotation, nullptr, st, grad2d,
+                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ra, stream);
+}
+
 int w3d_backward_blend_dcolor(const w3d_view *view, int32_t P, const void *state, const uint32_t *point_list,
                               const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha, float *dcolor_out,
                               void *scratch, w3d_stream_t stream_) {

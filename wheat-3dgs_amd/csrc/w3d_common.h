@@ -171,7 +171,9 @@ struct W3DRawBwdArgs {
     float *dL_df_rest, *gnorm_out;
     const int32_t *radii;
     float *accum, *denom, *max_radii;
-    int lowrank;                      // view-parallel flavour: geometry gradients only, the SH gradient stays implicit in dL/dRGB
+    int lowrank;                      // view-parallel flavour: geometry gradients only, the SH gradient stays implicit in dL/dRGB;
+                                      // 2: ... and neither is written densely — the non-zero 64-B rows are appended to rows_out
+    float *rows_out; uint32_t rows_cap; uint32_t *rows_count; float norm_scale;
     float *dcolor_out;                // ... which is written here as (P,3) (NULL: already extracted by w3d_launch_dcolor_extract)
     const w3d_adam_fused *adam;       // non-NULL: apply Adam in place instead of writing gradients
     const w3d_raw_blocks *params_rw;  // ... to these parameter blocks

@@ -515,6 +515,11 @@ struct RawBwd {
     float inv_sqrt_bc2[6];              // per block
     const uint32_t *counters;           // forward counters: [1] = list length needed, [3] = list capacity used
     float *dcolor_out;                  // MODE 2: (P,3) clamp-masked dL/dRGB per Gaussian (zeros for culled)
+    // MODE 3: the non-zero 64-B gradient rows themselves (w3d_exchange.hip's row format), appended to rows_out
+    float4 *rows_out;
+    uint32_t rows_cap;
+    uint32_t *rows_count;               // device counter, zeroed by the launcher
+    float norm_scale;                   // row word 1 = ||dL/dmean2D|| * norm_scale (0: no norm wanted)
 };
 
 // Adam on the `rows` x DIM contiguous floats a workgroup owns in parameter block b, gradients taken from an LDS stage
@@ -576,6 +581,11 @@ __device__ __forceinline__ void coop_adam(const RawBwd &raw, int b, size_t g0, i
 // direction with the clamp-masked dL/dRGB, so only those 3 floats per Gaussian are written (dcolor_out) — the ranks
 // exchange them instead of 48 floats and rebuild the sum over views in sh_adam_lowrank_kernel.  The gradients of the
 // other blocks are written as in MODE 0.  No LDS stage, no workgroup barrier.
+// MODE 3 (with RAW, the sparse form of that exchange): the same 14 floats are not written densely and packed by a second kernel
+// (pack_rows_kernel: 120 MB written and read again at 2 M Gaussians) — every Gaussian whose 14 gradient floats and norm are not
+// all zero gets its 64-B row {index, norm * scale, dRGB[3], d xyz[3], d opacity, d scaling[3], d rotation[4]} appended to
+// rows_out right here: ballot + wave totals in LDS + ONE counter atomic per workgroup.  Row order is unspecified (as the pack
+// kernel's was: the replicated optimizer finds a Gaussian's row through the index, and adds views in view order).
 template <bool HAS_SH, bool HAS_SCALE_ROT, bool RAW, bool FAST16, int MODE = 0>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(w3d_view v, int P, const float *means3D, const float *shs, const float *scales, const float *rotations,
@@ -588,11 +598,13 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *means3D, const float *shs,
                       float *__restrict__ dL_dshs, float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
                       float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D) {
     constexpr bool ADAM = MODE == 1;
-    constexpr bool STAGED = HAS_SH && FAST16 && MODE != 2;     // SH gradient rows go through the LDS stage
+    constexpr bool LOWRANK = MODE == 2 || MODE == 3;            // no SH gradient rows: dL/dRGB stands for them
+    constexpr bool STAGED = HAS_SH && FAST16 && !LOWRANK;       // SH gradient rows go through the LDS stage
+    __shared__ uint32_t s_rowtot[MODE == 3 ? 5 : 1];
     __shared__ float sh_stage[STAGED ? 256 * W3D_SHROW : 1];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = gid < P;
-    if (!STAGED && !active) return;
+    if (!STAGED && MODE != 3 && !active) return;      // (MODE 3: every thread reaches the workgroup barrier of the row compaction)
     float dRGB_out[3] = {0.f, 0.f, 0.f};
     const int g = active ? gid : P - 1;       // FAST16: idle lanes of the last block still reach the barrier
     const int Mc = v.sh_coeffs;
@@ -617,7 +629,7 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *means3D, const float *shs,
 #define DSH(k, c) (*(STAGED ? (sh_stage + threadIdx.x * W3D_SHROW + 3 * (k) + (c)) \
                             : ((RAW && (k) > 0) ? (dsh_rest + 3 * ((k)-1) + (c)) : (dsh + 3 * (k) + (c)))))
     if (!vis) {
-        if (HAS_SH && MODE != 2) {
+        if (HAS_SH && !LOWRANK) {
             if (FAST16) {
 #pragma unroll
                 for (int i = 0; i < 48; i++) sh_stage[threadIdx.x * W3D_SHROW + i] = 0.f;
@@ -743,7 +755,7 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *means3D, const float *shs,
             B[14] = SH_C3[5] * z * (xx - yy); B[15] = SH_C3[6] * x * (xx - 3.f * yy);
             const int ncoef = (deg + 1) * (deg + 1);
             dRGB_out[0] = dRGB[0]; dRGB_out[1] = dRGB[1]; dRGB_out[2] = dRGB[2];
-            if (MODE != 2) {
+            if (!LOWRANK) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) {   // static indices keep B[] in registers
                     if (k < Mc) {
@@ -858,6 +870,37 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *means3D, const float *shs,
         }
     }
     if (dL_dmeans2D && active) { dL_dmeans2D[3 * (size_t)g] = dm2[0]; dL_dmeans2D[3 * (size_t)g + 1] = dm2[1]; dL_dmeans2D[3 * (size_t)g + 2] = 0.f; }
+    if (MODE == 3) {
+        // append this Gaussian's row if any of its 14 gradient floats (or its norm) is non-zero: the selection of pack_rows_kernel
+        const float gnr = (RAW && raw.norm_scale != 0.f && vis) ? sqrtf(dm2[0] * dm2[0] + dm2[1] * dm2[1]) * raw.norm_scale : 0.f;
+        const uint32_t bits = __float_as_uint(dRGB_out[0]) | __float_as_uint(dRGB_out[1]) | __float_as_uint(dRGB_out[2]) |
+                              __float_as_uint(dmean[0]) | __float_as_uint(dmean[1]) | __float_as_uint(dmean[2]) | __float_as_uint(dop) |
+                              __float_as_uint(dscale[0]) | __float_as_uint(dscale[1]) | __float_as_uint(dscale[2]) |
+                              __float_as_uint(drot[0]) | __float_as_uint(drot[1]) | __float_as_uint(drot[2]) | __float_as_uint(drot[3]) |
+                              __float_as_uint(gnr);
+        const bool any = active && (bits & 0x7FFFFFFFu) != 0u;
+        const uint64_t bal = w3d_ballot(any);
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        if (lane == 0) s_rowtot[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = s_rowtot[0] + s_rowtot[1] + s_rowtot[2] + s_rowtot[3];
+            s_rowtot[4] = tot ? atomicAdd(raw.rows_count, tot) : 0u;
+        }
+        __syncthreads();
+        if (any) {
+            uint32_t r = s_rowtot[4] + (uint32_t)__popcll(bal & (lane ? (~0ull >> (64u - lane)) : 0ull));
+            for (uint32_t w = 0; w < wv; w++) r += s_rowtot[w];
+            if (r < raw.rows_cap) {
+                float4 *row = raw.rows_out + 4 * (size_t)r;
+                row[0] = make_float4(__uint_as_float((uint32_t)g), gnr, dRGB_out[0], dRGB_out[1]);
+                row[1] = make_float4(dRGB_out[2], dmean[0], dmean[1], dmean[2]);
+                row[2] = make_float4(dop, dscale[0], dscale[1], dscale[2]);
+                row[3] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+            }
+        }
+        return;
+    }
     if (ADAM) {
         // the narrow blocks go through the (now free) LDS stage as well: row = [dmean 3 | dop 1 | dscale 3 | drot 4], stride 15
         __syncthreads();
@@ -1167,7 +1210,16 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
                        reinterpret_cast<const uint8_t *>(state + L.o_clamped), grad2d, dL_dmeans3D, dL_dmeans2D,         \
                        dL_dcolors, dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
     W3D_PROF("preprocess_bwd", stream);
-    if (rawargs && rawargs->lowrank) {
+    if (rawargs && rawargs->lowrank == 2) {
+        if (v.sh_coeffs != 16) { w3d_set_error("gradient rows need 16 SH coefficients"); return W3D_ERR_INVALID; }
+        raw.rows_out = reinterpret_cast<float4 *>(rawargs->rows_out); raw.rows_cap = rawargs->rows_cap;
+        raw.rows_count = rawargs->rows_count; raw.norm_scale = rawargs->norm_scale;
+        W3D_HIP_CHECK(hipMemsetAsync(raw.rows_count, 0, sizeof(uint32_t), stream));
+        hipLaunchKernelGGL((preprocess_bwd_kernel<true, true, true, true, 3>), dim3(grid), dim3(block), 0, stream, v, L.P, means3D, shs,
+                           scales, rotations, cov3D_precomp, raw, reinterpret_cast<const ushort4 *>(state + L.o_rect),
+                           reinterpret_cast<const uint8_t *>(state + L.o_clamped), grad2d, dL_dmeans3D, dL_dmeans2D, dL_dcolors,
+                           dL_dshs, dL_dopacity, dL_dscales, dL_drots, dL_dcov3D);
+    } else if (rawargs && rawargs->lowrank) {
         if (v.sh_coeffs != 16) { w3d_set_error("low-rank colour-gradient output needs 16 SH coefficients"); return W3D_ERR_INVALID; }
         raw.dcolor_out = rawargs->dcolor_out;
         hipLaunchKernelGGL((preprocess_bwd_kernel<true, true, true, true, 2>), dim3(grid), dim3(block), 0, stream, v, L.P, means3D, shs,

@@ -62,6 +62,9 @@ lib.w3d_sh_adam_lowrank.argtypes = [_i32, _i32, _i32] + [_vp] * 9 + [ctypes.c_fl
 lib.w3d_sh_adam_lowrank.restype = ctypes.c_int
 lib.w3d_pack_gradient_rows.argtypes = [_i32, _vp, ctypes.POINTER(W3DRawGrads), _vp, ctypes.c_float, _vp, ctypes.c_uint32, _vp, _vp]
 lib.w3d_pack_gradient_rows.restype = ctypes.c_int
+lib.w3d_backward_raw_rows.argtypes = [ctypes.POINTER(W3DView), _i32, ctypes.POINTER(W3DRawParams), _vp, _vp, _vp, _vp, _vp, ctypes.c_float,
+                                      _vp, ctypes.c_uint32, _vp, _vp, _vp]
+lib.w3d_backward_raw_rows.restype = ctypes.c_int
 lib.w3d_apply_gradient_rows.argtypes = [_i32, _vp, _vp, ctypes.c_uint32, _vp, ctypes.POINTER(W3DRawGrads), _vp, _vp]
 lib.w3d_apply_gradient_rows.restype = ctypes.c_int
 lib.w3d_index_gradient_rows.argtypes = [_i32, _i32, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp]
@@ -385,6 +388,27 @@ def backward_raw_lowrank(model, handle, dL_dimage, want_norm=True):
                                            ctypes.byref(g), ptr(dcol), ctypes.byref(st), ptr(scratch), stream_ptr(dev)))
         scratch_done(view, model)
     return gnorm, dcol
+
+
+def backward_raw_rows(model, handle, dL_dimage, norm_scale=1.0):
+    """Backward of the view-parallel step in its sparse form (include/w3d.h w3d_backward_raw_rows): blend backward, then the
+    per-Gaussian backward appends the non-zero 64-B gradient rows {index, ||dL/dmean2D|| * norm_scale, dL/dRGB, 11 geometry
+    gradients} itself — backward_raw_lowrank + pack_gradient_rows without the dense arrays in between.  model.flat_grad is not
+    touched.  Returns (rows (P, 16) float32 of which the first `count` are filled, count (1,) int32 on the device)."""
+    dev = model.flat.device
+    P, view = handle["P"], handle["view"]
+    if P != model.num_points:
+        raise RuntimeError("model was resized between forward and backward")
+    prm = _raw_params(model)
+    rows = torch.empty(max(P, 1), ROW_FLOATS, dtype=torch.float32, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        scratch = backward_scratch(view, P, handle["point_list"], dev, owner=model)
+        check(lib.w3d_backward_raw_rows(ctypes.byref(view.c), P, ctypes.byref(prm), ptr(handle["state"]), ptr(handle["point_list"]),
+                                        ptr(dL_dimage.contiguous()), None, None, float(norm_scale), ptr(rows), rows.shape[0],
+                                        ptr(count), ptr(scratch), stream_ptr(dev)))
+        scratch_done(view, model)
+    return rows, count
 
 
 def sh_adam_lowrank(model, dcolor_all, campos_all, skip=(), rows=None):

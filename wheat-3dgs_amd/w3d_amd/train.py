@@ -269,7 +269,7 @@ class Trainer:
             frac = min(1.0, 0.9 * (12.0 + 88.0 / max(self.world, 1)) / 64.0)
         return int(frac * P)
 
-    def exchange_rows(self, dcolor, grad2d_norm, visible, radii, tracking=True):
+    def exchange_rows(self, dcolor, grad2d_norm, visible, radii, tracking=True, packed=None):
         """Sparse exchange of the view-parallel step.  Contract as exchange_lowrank().  A view gives a gradient only to the
         Gaussians its pixels blended — every other row of dcolor and of the geometry gradients is exactly zero — so the
         ranks all-gather their NON-ZERO rows (64 B: index, ||dL/dmean2D||, dL/dRGB, 11 geometry gradients; packed by
@@ -293,14 +293,18 @@ class Trainer:
         from .fused_step import ROW_FLOATS, GatheredRows, apply_gradient_rows, pack_gradient_rows
         m = self.model
         P = m.num_points
-        dev = dcolor.device
+        dev = visible.device
+        if packed is not None:
+            # (rows, count) straight from the per-Gaussian backward (fused_step.backward_raw_rows): dcolor / grad2d_norm are None;
+            # a step that turns out too dense for this form rebuilds the dense arrays from its own rows (too_dense below)
+            assert self._rows_skip == 0 and dcolor is None
         if self._rows_skip > 0:
             # a recent step was too dense for this form: the next ROWS_RETRY steps take the low-rank form without counting
             # their rows first (same state on every rank: it derives from the gathered counts)
             self._rows_skip -= 1
             self.exchange_used["lowrank"] += 1
             return self.exchange_lowrank(dcolor, grad2d_norm, visible, radii, tracking=tracking)
-        rows, count = pack_gradient_rows(m, dcolor, grad2d_norm if tracking else None)
+        rows, count = packed if packed is not None else pack_gradient_rows(m, dcolor, grad2d_norm if tracking else None)
         counts = torch.empty(self.world, dtype=torch.int32, device=dev)
         dist.all_gather_into_tensor(counts, count)
         pinned = ev = None
@@ -323,7 +327,7 @@ class Trainer:
             ev.synchronize()
             return pinned.tolist()
         # everything that does not depend on the counts is enqueued BEFORE the host reads them
-        gpu = dcolor.is_cuda
+        gpu = visible.is_cuda
         vcount = rmax = nsum = None
         self._stat_work = ()
         if tracking:
@@ -347,10 +351,17 @@ class Trainer:
             self._rows_cap = None
             self._rows_recent = []
             ns = None
+            dense_color = dcolor
+            if packed is not None:
+                # the dense arrays the low-rank form exchanges were never written: rebuild them from this view's own rows
+                dense_color = torch.zeros(P, 3, dtype=torch.float32, device=dev)
+                m.flat_grad[a:b].zero_()
+                own_norm = torch.zeros(P, dtype=torch.float32, device=dev) if tracking else None
+                apply_gradient_rows(m, rows, count, rows.shape[0], dense_color, own_norm)
             if tracking:
-                ns = grad2d_norm * visible
+                ns = own_norm if packed is not None else grad2d_norm * visible
                 self._stat_work = self._stat_work + (dist.all_reduce(ns, op=dist.ReduceOp.SUM, async_op=True),)
-            self.exchange_lowrank(dcolor, None, None, None, tracking=False)
+            self.exchange_lowrank(dense_color, None, None, None, tracking=False)
             return ns, vcount, rmax
 
         cap = self._rows_cap
@@ -560,8 +571,8 @@ class Trainer:
         densify / reset opacity write the gradient bucket and step separately.  Several ranks: low-rank or dense
         exchange (exchange_lowrank / exchange).  No autograd graph is built."""
         from .fused import l1_ssim_fwd_bwd
-        from .fused_step import (backward_blend_dcolor, backward_raw, backward_raw_adam, backward_raw_lowrank, finish,
-                                 render_raw)
+        from .fused_step import (backward_blend_dcolor, backward_raw, backward_raw_adam, backward_raw_lowrank, backward_raw_rows,
+                                 finish, render_raw)
         m, opt = self.model, self.opt
         m.update_learning_rate(iteration)
         if iteration % 1000 == 0:
@@ -573,7 +584,7 @@ class Trainer:
             single = self.world == 1 and not self.force_exchange
             lowrank = (not single) and self.exchange_mode in ("lowrank", "rows") and m.max_sh_degree == 3
             rows_form = lowrank and self.exchange_mode == "rows"
-            dcol = None
+            dcol = packed = None
             use_adam = (single and self.fused_adam and iteration < opt.iterations and
                         m.max_sh_degree == 3 and not self._structure_change_due(iteration))
             attempts = 0
@@ -596,6 +607,10 @@ class Trainer:
                     self.gather_colors(early)
                     gnorm, _ = backward_raw_lowrank(m, pkg["handle"], None, want_norm=True)
                     dcol = None
+                elif rows_form and self._rows_skip == 0:
+                    # sparse form: the per-Gaussian backward emits the non-zero rows itself — no dense 14-float arrays, no pack pass
+                    packed = backward_raw_rows(m, pkg["handle"], dimg, norm_scale=float(self.world) if tracking else 0.0)
+                    gnorm = dcol = None
                 elif lowrank:
                     gnorm, dcol = backward_raw_lowrank(m, pkg["handle"], dimg, want_norm=True)
                 else:
@@ -611,10 +626,12 @@ class Trainer:
                 m.max_radii2D = torch.max(m.max_radii2D, pkg["radii"].to(m.max_radii2D.dtype))
             if not single:
                 vis = pkg["radii"] > 0
-                if self.world > 1:
+                if self.world > 1 and gnorm is not None:
                     gnorm = gnorm * float(self.world)           # statistics use the unscaled per-view norm
                 stepped_early = False
-                if lowrank:
+                if packed is not None:
+                    nsum, vcount, rmax = self.exchange_rows(None, None, vis, pkg["radii"], tracking=tracking, packed=packed)
+                elif lowrank:
                     nsum, vcount, rmax = (self.exchange_rows if rows_form else self.exchange_lowrank)(
                         dcol, gnorm, vis, pkg["radii"], tracking=tracking)
                     if self._structure_change_due(iteration):
