@@ -59,8 +59,9 @@ def test_training_is_the_same_under_every_list_share_and_the_trainer_picks_one()
     tr, m = runs[None][4], runs[None][5]
     assert m.list_share is None and m._list_share_chosen in (0, 1, 2) and tr.share_rho is not None and 0.0 < tr.share_rho <= 1.0
     assert list_share_of(m) == m._list_share_chosen
-    want = 2 if tr.share_rho < tr.SHARE_RHO[0] - tr.SHARE_HYST else 1 if tr.SHARE_RHO[0] + tr.SHARE_HYST < tr.share_rho < tr.SHARE_RHO[1] - tr.SHARE_HYST \
-        else 0 if tr.share_rho > tr.SHARE_RHO[1] + tr.SHARE_HYST else None
+    from w3d_amd.rasterizer import SHARE_HYST, SHARE_RHO
+    want = 2 if tr.share_rho < SHARE_RHO[0] - SHARE_HYST else 1 if SHARE_RHO[0] + SHARE_HYST < tr.share_rho < SHARE_RHO[1] - SHARE_HYST \
+        else 0 if tr.share_rho > SHARE_RHO[1] + SHARE_HYST else None
     assert want is None or m._list_share_chosen == want, (tr.share_rho, m._list_share_chosen)
     # a caller's explicit setting is left alone
     assert runs[2][5].list_share == 2 and runs[2][5]._list_share_chosen is None and runs[2][4].share_rho is None

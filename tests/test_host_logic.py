@@ -502,8 +502,10 @@ def test_settings_carry_the_optional_switches_behind_the_reference_fields():
     list_capacity(a, 10, 20).observe(77)
     assert list_capacity(a, 10, 20).known == 77 and list_capacity(b, 10, 20).known == 0 and list_capacity(a, 20, 10).known == 0
     import w3d_amd.rasterizer as wr
-    # no module-level switches left (two constants: the brute-force / grid kNN crossover and the default of the settings' list_share)
-    assert not [n for n in vars(wr) if n.isupper() and n not in ("KNN_GRID_FROM", "LIST_SHARE_DEFAULT")]
+    # no module-level switches left (constants only: the brute-force / grid kNN crossover, the default of the settings' list_share
+    # and the thresholds of its automatic choice)
+    assert not [n for n in vars(wr) if n.isupper() and n not in ("KNN_GRID_FROM", "LIST_SHARE_DEFAULT", "SHARE_PROBE_EVERY", "SHARE_RHO",
+                                                                 "SHARE_HYST")]
 
 
 def test_inplace_collective_aliasing_is_checked():

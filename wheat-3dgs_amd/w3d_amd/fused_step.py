@@ -13,8 +13,8 @@ import math
 import torch
 
 from ._lib import W3DView, check, lib, ptr, stream_ptr
-from .rasterizer import (GaussianRasterizationSettings, list_share_of, _View, backward_scratch, list_capacity,
-                         scratch_done)
+from .rasterizer import (GaussianRasterizationSettings, adapt_list_share, list_share_of, _View, backward_scratch,
+                         list_capacity, scratch_done)
 
 _vp, _i32 = ctypes.c_void_p, ctypes.c_int32
 
@@ -241,6 +241,7 @@ class _RasterizeRawFn(torch.autograd.Function):
         pkg = render_raw(cam, model, bg, scaling_modifier, sync=False)
         if not finish(pkg["handle"]):                 # list buffer too small: repeat with the exact size
             pkg = render_raw(cam, model, bg, scaling_modifier, sync=True)
+        adapt_list_share(model, pkg["handle"])        # (speed only: which list grid the next renders of this model use)
         ctx.model, ctx.handle = model, pkg["handle"]
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(pkg["radii"])

@@ -40,6 +40,43 @@ def list_share_of(obj):
     return LIST_SHARE_DEFAULT if x is None else int(x)
 
 
+# list_share from what the scene does (results never depend on it): rho = (sum of the tiles' walk lengths) /
+# (sum of the lengths of the lists they read), measured on the view just rendered — one reduction of the camera's walk array —
+# every SHARE_PROBE_EVERY renders of an owner (a GaussianModel); below SHARE_RHO[0]: 32x32 cells, below [1]: 32x16, else one list
+# per tile, +- SHARE_HYST around a bound.  Same-box A/B on three scenes: profiles/r05/ab_list_share.txt.
+SHARE_PROBE_EVERY = 64
+SHARE_RHO = (0.30, 0.60)
+SHARE_HYST = 0.04
+
+
+def adapt_list_share(owner, handle, every=SHARE_PROBE_EVERY):
+    """Choose owner._list_share_chosen for the following renders from the walked fraction of this one (handle: a finished forward of
+    fused_step.render_raw).  A caller's explicit owner.list_share is left alone.  Returns the running rho (or None)."""
+    if getattr(owner, "list_share", None) is not None:
+        return None
+    st = getattr(owner, "_list_share_state", None)
+    if st is None:
+        st = owner._list_share_state = {"calls": 0, "rho": None}
+    st["calls"] += 1
+    if st["calls"] > 3 and st["calls"] % every:
+        return st["rho"]
+    view = handle["view"]
+    mode = int(view.c.list_share) if (view.c.tile_cull and not view.c.deterministic) else 0
+    lists_read = float(handle["num_rendered"]) * (1, 2, 4)[mode]
+    if lists_read <= 0:
+        return st["rho"]
+    rho = float(view.tile_walk_hint.sum()) / lists_read               # (host-synchronous: 7 500 integers)
+    r = st["rho"] = rho if st["rho"] is None else 0.5 * (st["rho"] + rho)
+    (lo, hi), h = SHARE_RHO, SHARE_HYST
+    want = 2 if r < lo else 1 if r < hi else 0
+    if want != mode:        # hysteresis: a bound only counts once it is crossed by SHARE_HYST in the direction of the change
+        edge = lo if {want, mode} == {1, 2} else hi if {want, mode} == {0, 1} else None
+        if edge is not None and abs(r - edge) < h:
+            want = mode
+    owner._list_share_chosen = want
+    return r
+
+
 class GaussianRasterizationSettings(NamedTuple):
     """Fields and order of the reference call site gaussian_renderer/__init__.py:40-53."""
     image_height: int

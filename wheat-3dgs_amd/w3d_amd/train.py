@@ -54,17 +54,8 @@ def nccl_inplace_shard(full, lo, hi, rank, world):
 class Trainer:
     ROWS_RETRY = 16          # exchange="rows": steps in the low-rank form after one that was too dense, before rows are counted again
     ROWS_WINDOW = 48         # ... and the speculative size of the row collective follows the largest count of this many steps
-    # w3d_view.list_share of the fused step, chosen from what the scene does (results never depend on it).  Sharing one list
-    # between the tiles of a cell shrinks the binning stage (31 % / 52 % fewer instances with 2 / 4 tiles per cell on a culled
-    # scene) and makes every blend wave stage its neighbours' entries too (+41 % / +100 %): it pays when the walks stop early —
-    # pixels saturate after a fraction of the list, so most staged entries are never reached — and costs when they run to the
-    # end.  rho = (sum of the tiles' walk lengths) / (sum of the lengths of the lists they read), measured every
-    # SHARE_PROBE_EVERY steps on the view just rendered (one reduction of the per-camera walk array).  Same-box A/B on the
-    # three benchmark scenes (profiles/r05/ab_list_share.txt): rho 0.15 -> 4 tiles per cell wins by 4.5 % of a step, 0.46 ->
-    # 2 per cell by 0-1 %, 0.87 -> unshared lists by 1.5 % (2 per cell) / 6 % (4 per cell).
+    # (w3d_view.list_share of the fused step is chosen from the walked fraction the trainer measures: rasterizer.adapt_list_share)
     SHARE_PROBE_EVERY = 64
-    SHARE_RHO = (0.30, 0.60)   # rho below [0]: 32x32 cells; below [1]: 32x16; else one list per tile (+- SHARE_HYST around a bound)
-    SHARE_HYST = 0.04
 
     def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
                  densify=True, loss_fn=photometric_loss, fused=None, force_exchange=False, fused_adam=True,
@@ -130,34 +121,17 @@ class Trainer:
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.perm = torch.randperm(len(cameras), generator=g).tolist()
         self.last = {}
-        # list_share: None on the model = chosen here from the measured walk fraction (adapt_list_share, kept on the model as
+        # list_share: None on the model = chosen from the measured walk fraction (adapt_list_share, kept on the model as
         # _list_share_chosen); a number = the caller's
-        self._share_steps = 0
         self.share_rho = None
 
     def adapt_list_share(self, handle):
-        """Every SHARE_PROBE_EVERY fused steps (and on the first three): the walked fraction of the view just rendered decides
-        model.list_share for the following steps (class comment).  One host-synchronous reduction of 7 500 integers."""
-        if getattr(self.model, "list_share", None) is not None:
-            return
-        self._share_steps += 1
-        if self._share_steps > 3 and self._share_steps % self.SHARE_PROBE_EVERY:
-            return
-        view = handle["view"]
-        mode = int(view.c.list_share) if (view.c.tile_cull and not view.c.deterministic) else 0
-        lists_read = float(handle["num_rendered"]) * (1, 2, 4)[mode]
-        if lists_read <= 0:
-            return
-        rho = float(view.tile_walk_hint.sum()) / lists_read
-        self.share_rho = rho if self.share_rho is None else 0.5 * (self.share_rho + rho)
-        r, (lo, hi), h = self.share_rho, self.SHARE_RHO, self.SHARE_HYST
-        # hysteresis: a bound only counts once it is crossed by SHARE_HYST in the direction of the change
-        want = 2 if r < lo else 1 if r < hi else 0
-        if want != mode:
-            edge = lo if {want, mode} == {1, 2} else hi if {want, mode} == {0, 1} else None
-            if edge is not None and abs(r - edge) < h:
-                want = mode
-        self.model._list_share_chosen = want
+        """Every SHARE_PROBE_EVERY fused steps (and on the first three): the walked fraction of the view just rendered decides the
+        list_share of the following steps (rasterizer.adapt_list_share; kept on the model)."""
+        from .rasterizer import adapt_list_share
+        rho = adapt_list_share(self.model, handle, every=self.SHARE_PROBE_EVERY)
+        if rho is not None:
+            self.share_rho = rho
 
     def camera_for(self, iteration):
         """rank r of N renders camera perm[(it*N + r) mod n] — N distinct views per step."""
