@@ -88,6 +88,9 @@ def parse(argv=None):
     ap.add_argument("--trained-only", action="store_true",
                     help="of the extra measurements keep only the trained-scene one (kernel A/B runs: profiles/ab_variants.sh)")
     ap.add_argument("--torch-restatement", default=None, help=argparse.SUPPRESS)      # child mode of the cpu_baseline leg
+    ap.add_argument("--no-spatial-order", action="store_true",
+                    help="keep the Gaussians in the order the scene was created in (default: Trainer(spatial_order=True), the "
+                         "model is stored in Morton order of the positions and re-sorted during densification)")
     ap.add_argument("--no-scale-model", action="store_true",
                     help="skip the N-GPU prediction from single-GPU measurements (per-camera step times, exchange machinery on a 1-rank group)")
     ap.add_argument("--force-dist", action="store_true", help="1-rank RCCL group: exercises the exchange path on one GPU")
@@ -587,7 +590,19 @@ def time_dropin(args, sc, cams, bg, dev, perm, n=None):
         n = args.steps if args.dropin_steps < 0 else args.dropin_steps
     if n <= 0:
         return None
-    out = time_standin(args, sc, cams, bg, dev, perm, True, n, max(3, min(args.warmup, 10)))
+    # (W3D_SPATIAL_ORDER: the documented switch of the redirect's GaussianModel, INTEGRATION.md section 1 — the model the script
+    #  restores from its checkpoint is put into Morton order, as Trainer(spatial_order=True) does for the fused step)
+    prev = os.environ.get("W3D_SPATIAL_ORDER")
+    if not args.no_spatial_order:
+        os.environ["W3D_SPATIAL_ORDER"] = "10"
+    try:
+        out = time_standin(args, sc, cams, bg, dev, perm, True, n, max(3, min(args.warmup, 10)))
+    finally:
+        if prev is None:
+            os.environ.pop("W3D_SPATIAL_ORDER", None)
+        else:
+            os.environ["W3D_SPATIAL_ORDER"] = prev
+    out["spatial_order"] = not args.no_spatial_order
     assert all(v.startswith("w3d_amd.") for v in out["resolved"].values()), out["resolved"]
     out["iter_time"] = "HIP events around render + loss + backward, the bracket of train_vanilla_3dgs.py:56,82 (no optimizer step)"
     return out
@@ -595,10 +610,15 @@ def time_dropin(args, sc, cams, bg, dev, perm, n=None):
 
 
 # ------------------------------------------------------------------------------------------------ roofline helpers
+SPATIAL_ORDER = True        # (main() clears it under --no-spatial-order)
+
+
 def kernel_bytes(P, V, R, Rw, HW, fused_adam):
     """Algorithmic HBM bytes per launch of every stage (what the stage must read and write once)."""
     return {
-        "preprocess_fwd": 236.0 * P + 64.0 * V,              # parameters read; packed per-visible records written
+        # parameters read; packed per-visible records written.  In Morton order the culled Gaussians come in runs and their
+        # 180-B SH rows are not requested at all: 56 B of geometry for everyone, the SH rows of the visible
+        "preprocess_fwd": (56.0 * P + 180.0 * V + 64.0 * V) if SPATIAL_ORDER else (236.0 * P + 64.0 * V),
         # first pass reads P (key, id) pairs, the others V; the last writes 24-B records from a 16-B rect/mask gather
         "depth_sort": 8.0 * P + 8.0 * V + 2 * 16.0 * V + (8.0 + 16.0 + 24.0) * V,
         "tile_count_scan": 24.0 * V,                           # the records, once
@@ -933,7 +953,7 @@ def grow_densified_model(args, dev, bg, iterations=None, log=None):
     m = GaussianModel(3, device=dev)
     m.create_from_pcd(PCD(pts.numpy(), col.numpy(), None), 1.0)
     m.training_setup(opt)
-    tr = Trainer(m, train, opt, bg, densify=True, cameras_extent=2.0)
+    tr = Trainer(m, train, opt, bg, densify=True, cameras_extent=2.0, spatial_order=not args.no_spatial_order)
 
     def quality(views):
         return sum(_psnr_db(i, v.original_image) for i, v in zip(render_views(m, views, bg), views)) / len(views)
@@ -970,7 +990,7 @@ def densified_scene(args, dev, bg, log, with_scale_model=False):
     iteration numbers continue after the schedule), with its own dominant-kernel roofline, stage table and workload."""
     from w3d_amd.train import Trainer
     m, opt, train, held, rep = grow_densified_model(args, dev, bg, log=log)
-    tr = Trainer(m, train, opt, bg, densify=False)
+    tr = Trainer(m, train, opt, bg, densify=False, spatial_order=not args.no_spatial_order)
     meter = StepMeter(tr, 1, dev)
     it = opt.iterations
     opt.iterations = 10 ** 9                       # (the step past `iterations` skips the optimizer: keep stepping)
@@ -1047,7 +1067,7 @@ def opaque_scene(args, dev, bg, log, with_scale_model=False, return_model=False)
     m = GaussianModel(3, device=dev)
     m.create_from_pcd(PCD(pts.numpy(), col.numpy(), None), 1.0)
     m.training_setup(opt)
-    tr = Trainer(m, train, opt, bg, densify=True, cameras_extent=2.0)
+    tr = Trainer(m, train, opt, bg, densify=True, cameras_extent=2.0, spatial_order=not args.no_spatial_order)
 
     def quality(views):
         return sum(_psnr_db(i, v.original_image) for i, v in zip(render_views(m, views, bg), views)) / len(views)
@@ -1078,7 +1098,7 @@ def opaque_scene(args, dev, bg, log, with_scale_model=False, return_model=False)
            "parameters_finite": bool(torch.isfinite(m.flat).all()), "trace_iteration_gaussians_seconds": trace}
 
     def measure(tag, it):
-        t = Trainer(m, train, opt, bg, densify=False)
+        t = Trainer(m, train, opt, bg, densify=False, spatial_order=not args.no_spatial_order)
         meter = StepMeter(t, 1, dev)
         for _ in range(max(5, args.warmup)):
             it += 1
@@ -1100,7 +1120,7 @@ def opaque_scene(args, dev, bg, log, with_scale_model=False, return_model=False)
     # ---- pad to --points with the reference's own clone / split rule
     target = args.points
     if m.num_points < 0.97 * target:
-        t = Trainer(m, train, opt, bg, densify=False)
+        t = Trainer(m, train, opt, bg, densify=False, spatial_order=not args.no_spatial_order)
         rounds = []
         for rnd in range(4):                       # (a Gaussian is cloned / split once per round: the gap may take several)
             if m.num_points >= 0.97 * target:
@@ -1209,6 +1229,8 @@ def main():
     args = parse()
     if args.torch_restatement:
         return torch_restatement_child(args.torch_restatement)
+    global SPATIAL_ORDER
+    SPATIAL_ORDER = not args.no_spatial_order
     world, rank, local = dist_env(args)
     if args.dry_run:
         return dry_run(args, world, rank)
@@ -1235,7 +1257,10 @@ def main():
         return
     loss_fn = photometric_loss_torch if args.torch_loss else photometric_loss
     trainer = Trainer(model, cams, opt, bg, densify=False, loss_fn=loss_fn, fused=False if args.autograd_path else None,
-                      force_exchange=force_dist, exchange="rows" if args.exchange == "auto" else args.exchange)
+                      force_exchange=force_dist, exchange="rows" if args.exchange == "auto" else args.exchange,
+                      spatial_order=not args.no_spatial_order)
+    # (the oracle legs read the scene tensors: the same rows in the order the model now stores them)
+    sc_model = sc if trainer.initial_perm is None else sc.take(trainer.initial_perm.cpu())
     meter = StepMeter(trainer, world, dev)
     sync = meter.sync
     # camera 0 with the INITIAL parameters, for "PSNR vs ref" (compared with the oracle's render in the cpu_baseline leg)
@@ -1254,7 +1279,7 @@ def main():
             own_grads0["densify_norm"] = gn0.cpu().numpy().astype(np.float64)
             own_grads0["radii"] = r0["radii"].cpu().numpy()
             model.flat_grad.zero_()
-        own_view0 = tuple(t.detach().cpu().numpy() for t in (r0["render"], r0["depth"], r0["alpha"], cams[0].original_image)) + (own_grads0, sc)
+        own_view0 = tuple(t.detach().cpu().numpy() for t in (r0["render"], r0["depth"], r0["alpha"], cams[0].original_image)) + (own_grads0, sc_model)
         del r0, gc0, gn0
 
     _progress("warm-up")
@@ -1562,6 +1587,8 @@ def main():
                        "mean_last_contributor_list_position": round(ws["mean_last"], 2),
                        "loss": "torch conv2d" if args.torch_loss else "fused HIP L1+SSIM",
                        "step": step_desc,
+                       "storage_order": "Morton order of the positions (Trainer(spatial_order=True))" if SPATIAL_ORDER
+                                        else "as created (random)",
                        "final_loss": round(final_loss, 6)},
             "roofline": roof,
             "roofline_valu_kernel": valu,

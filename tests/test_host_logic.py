@@ -563,3 +563,95 @@ def test_structure_change_schedule_follows_the_reference_loop():
     opt.random_background = True
     a, b = tr.background_for(1), tr.background_for(2)
     assert a.shape == (3,) and not torch.equal(a, b) and float(a.min()) >= 0.0 and float(a.max()) < 1.0
+
+
+def _is_morton_sorted(m):
+    return bool(torch.equal(m.spatial_permutation(), torch.arange(m.num_points)))
+
+
+def test_spatial_order_moves_every_per_gaussian_array_together(monkeypatch):
+    """GaussianModel.sort_spatially / reorder: one permutation for parameters, both Adam moments, labels and densification
+    statistics; step counters and learning rates kept; densify_and_prune and restore keep the order when asked to, and the
+    SET of Gaussians a densification produces does not depend on it."""
+    from w3d_amd.train import Trainer
+    P = 1003
+    sc = make_scene(P, seed=3, scale_mean=0.05)
+
+    def fresh(every=0):
+        m = GaussianModel(3, device="cpu")
+        m.spatial_order_every = every
+        m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+        m.training_setup(OptimizationParams())
+        g = torch.Generator().manual_seed(1)
+        m.optimizer.exp_avg.copy_(torch.randn(m.optimizer.exp_avg.shape, generator=g))
+        m.optimizer.exp_avg_sq.copy_(torch.rand(m.optimizer.exp_avg_sq.shape, generator=g))
+        m.optimizer._set_steps(7)
+        m.xyz_gradient_accum = torch.rand(P, 1, generator=g) * 1e-3
+        m.denom = torch.randint(1, 5, (P, 1), generator=g).float()
+        m.max_radii2D = torch.rand(P, generator=g)
+        m._which_object = torch.arange(P)
+        return m
+    m = fresh()
+    assert m.spatial_order_every == 0 and not _is_morton_sorted(m)
+    before = {k: v.detach().clone() for k, v in m._p.items()}
+    mom = {k: (a.clone(), b.clone()) for k, (a, b) in m.optimizer.moments().items()}
+    acc, den, rad = m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone()
+    lrs, steps = dict(m.optimizer.lrs), dict(m.optimizer.steps)
+    perm = m.sort_spatially()
+    assert sorted(perm.tolist()) == list(range(P)) and _is_morton_sorted(m)
+    for k in before:
+        assert torch.equal(m._p[k].detach(), before[k][perm]), k
+    for k, (a, b) in m.optimizer.moments().items():
+        assert torch.equal(a, mom[k][0][perm]) and torch.equal(b, mom[k][1][perm]), k
+    assert torch.equal(m.xyz_gradient_accum, acc[perm]) and torch.equal(m.denom, den[perm]) and torch.equal(m.max_radii2D, rad[perm])
+    assert torch.equal(m._which_object, perm) and m.optimizer.lrs == lrs and m.optimizer.steps == steps
+    # neighbours in the index are neighbours in space
+    step_sorted = (m.get_xyz[1:] - m.get_xyz[:-1]).norm(dim=1).mean()
+    step_random = (sc.xyz[1:] - sc.xyz[:-1]).norm(dim=1).mean()
+    assert float(step_sorted.detach()) < 0.4 * float(step_random)
+    with pytest.raises(ValueError):
+        m.reorder(torch.zeros(P, dtype=torch.int64))
+    inv = torch.argsort(perm)
+    m.reorder(inv)                                       # ... and back
+    for k in before:
+        assert torch.equal(m._p[k].detach(), before[k]), k
+
+    # a densification: same Gaussians with or without the ordering (as a multiset of rows), Morton order at the end
+    a, b = fresh(0), fresh(1)
+    for mm in (a, b):
+        torch.manual_seed(5)
+        mm.densify_and_prune(2e-4, 0.005, 2.0, None)
+    assert a.num_points == b.num_points != P and not _is_morton_sorted(a) and _is_morton_sorted(b)
+    # (the split children are sampled per parent in index order: same parents, same standard deviations, different draws — compare
+    #  what does not depend on the draw: opacities, rotations, features)
+    for k in ("opacity", "rotation", "f_dc"):
+        ra = a._p[k].detach().reshape(a.num_points, -1)
+        rb = b._p[k].detach().reshape(b.num_points, -1)
+        assert torch.equal(torch.sort(ra, 0).values, torch.sort(rb, 0).values), k
+    assert b._densify_calls == 1 and float(b.denom.abs().sum()) == 0.0      # (statistics reset by the densification, as without)
+
+    # a checkpoint restored into a model that keeps the order: sorted, moments with their rows
+    src = fresh(0)
+    tup = src.capture()
+    dst = GaussianModel(3, device="cpu")
+    dst.spatial_order_every = 10
+    dst.restore(tup, OptimizationParams())
+    pr = src.spatial_permutation()
+    assert _is_morton_sorted(dst) and torch.equal(dst._p["xyz"].detach(), src._p["xyz"].detach()[pr])
+    assert torch.equal(dst.optimizer.moments()["f_rest"][0], src.optimizer.moments()["f_rest"][0][pr])
+    assert torch.equal(dst.xyz_gradient_accum, src.xyz_gradient_accum[pr])
+
+    # the environment switch the import redirect documents
+    monkeypatch.setenv("W3D_SPATIAL_ORDER", "10")
+    assert GaussianModel(3, device="cpu").spatial_order_every == 10
+    monkeypatch.delenv("W3D_SPATIAL_ORDER")
+    assert GaussianModel(3, device="cpu").spatial_order_every == 0
+
+    # Trainer(spatial_order=True): sorts at construction, hands the permutation out, arms the periodic re-sort
+    t = fresh(0)
+    tr = Trainer(t, [0, 1, 2], OptimizationParams(), torch.zeros(3), densify=True, fused=False, spatial_order=True)
+    assert _is_morton_sorted(t) and t.spatial_order_every == Trainer.SPATIAL_ORDER_EVERY
+    assert torch.equal(t._p["xyz"].detach(), sc.xyz[tr.initial_perm])
+    u = fresh(0)
+    assert Trainer(u, [0, 1, 2], OptimizationParams(), torch.zeros(3), densify=True, fused=False).initial_perm is None
+    assert torch.equal(u._p["xyz"].detach(), sc.xyz)

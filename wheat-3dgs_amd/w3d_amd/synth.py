@@ -111,6 +111,12 @@ class SynthScene:
         return SynthScene(*(getattr(self, f).to(device) for f in
                             ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity")))
 
+    def take(self, rows):
+        """The scene with its Gaussians in another order (row r = old row rows[r])."""
+        rows = rows.to(self.xyz.device)
+        return SynthScene(*(getattr(self, f)[rows].contiguous() for f in
+                            ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity")))
+
     @property
     def P(self):
         return self.xyz.shape[0]

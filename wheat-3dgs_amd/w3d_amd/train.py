@@ -59,8 +59,13 @@ class Trainer:
 
     def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
                  densify=True, loss_fn=photometric_loss, fused=None, force_exchange=False, fused_adam=True,
-                 exchange="rows", early_gather=False, lowrank_chunks=None, rows_max_fraction=None, white_background=None):
-        """white_background: the dataset flag of reference train_vanilla_3dgs.py:44,109 — with it the opacities are ALSO reset once
+                 exchange="rows", early_gather=False, lowrank_chunks=None, rows_max_fraction=None, white_background=None,
+                 spatial_order=False):
+        """spatial_order: keep the Gaussians stored in Morton order of their positions (GaussianModel.sort_spatially: culled
+        Gaussians then come in runs and whole waves of the per-Gaussian forward skip their SH rows).  The model is sorted here,
+        at the first and then every SPATIAL_ORDER_EVERY-th densification, and once more when densification ends; the row order of the
+        model is then no longer the reference's (survivors, clones, children) — `initial_perm` is the permutation applied here.
+        white_background: the dataset flag of reference train_vanilla_3dgs.py:44,109 — with it the opacities are ALSO reset once
         at iteration == opt.densify_from_iter (besides every opacity_reset_interval).  The reference derives the background colour
         AND this extra reset from the one flag; None (default) does the same from the other end: a `background` of all ones is a
         white-background dataset.
@@ -121,9 +126,25 @@ class Trainer:
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.perm = torch.randperm(len(cameras), generator=g).tolist()
         self.last = {}
+        self.spatial_order = bool(spatial_order)
+        self.initial_perm = None
+        if self.spatial_order and model.num_points:
+            if model.spatial_order_every <= 0:
+                model.spatial_order_every = self.SPATIAL_ORDER_EVERY
+            self.initial_perm = model.sort_spatially()
         # list_share: None on the model = chosen from the measured walk fraction (adapt_list_share, kept on the model as
         # _list_share_chosen); a number = the caller's
         self.share_rho = None
+
+    SPATIAL_ORDER_EVERY = 10     # densifications between two full re-sorts (the new Gaussians of the rounds between are appended)
+
+    def _order_before_step(self, iteration):
+        """spatial_order: the last densification is over — the Gaussians appended since the last re-sort go into place (no
+        gradient is pending at the start of a step; moments and statistics move with their rows)."""
+        if self.spatial_order and self.densify and iteration == self.opt.densify_until_iter and self.model._densify_calls:
+            self.sync_stats()
+            self.gather_moments()
+            self.model.sort_spatially()
 
     def adapt_list_share(self, handle):
         """Every SHARE_PROBE_EVERY fused steps (and on the first three): the walked fraction of the view just rendered decides the
@@ -640,6 +661,7 @@ class Trainer:
         return loss
 
     def step(self, iteration):
+        self._order_before_step(iteration)
         if self.fused:
             return self.step_fused(iteration)
         m, opt = self.model, self.opt
