@@ -80,13 +80,13 @@ def main():
                 model.restore(pack["model"], OptimizationParams())
                 it = pack["it"]
             else:
-                tr0 = Trainer(model, cams, opt, bg, densify=False)
+                tr0 = Trainer(model, cams, opt, bg, densify=False, spatial_order=not args.no_spatial_order)
                 for _ in range(a.trained_steps):
                     it += 1
                     tr0.step(it)
                 if a.model_file:
                     torch.save({"model": model.capture(), "it": it}, a.model_file)
-    trainer = Trainer(model, cams, opt, bg, densify=False)
+    trainer = Trainer(model, cams, opt, bg, densify=False, spatial_order=not args.no_spatial_order)   # (bench.py's storage order)
     for _ in range(0 if (a.report and a.freeze) else a.warmup):      # (--freeze: the variant under test never trains the model)
         it += 1
         trainer.step(it)

@@ -101,9 +101,16 @@ def worker(rank, world, port, mode, outdir, backend="gloo_staged"):
     from w3d_amd.train import Trainer
     m, opt, cams = _scene_and_cams(dev)
     # "lowrank_early": the colour-gradient all-gather is issued between the two halves of the backward
+    # "<mode>_sorted": Trainer(spatial_order=True) — every replica puts its model into Morton order (at construction and at the
+    # first densification), computed on each rank from its own copy of the positions: the replicas must pick the same order
+    sorted_ = mode.endswith("_sorted")
+    ex = mode[:-len("_sorted")] if sorted_ else mode
     tr = Trainer(m, cams, opt, torch.zeros(3, device=dev), densify=True, cameras_extent=2.0,
-                 exchange="lowrank" if mode.startswith("lowrank") else mode, early_gather=mode == "lowrank_early",
-                 rows_max_fraction=1.0)   # (small dense test views: take the sparse form however many rows a view has)
+                 exchange="lowrank" if ex.startswith("lowrank") else ex, early_gather=ex == "lowrank_early",
+                 rows_max_fraction=1.0,   # (small dense test views: take the sparse form however many rows a view has)
+                 spatial_order=sorted_)
+    if sorted_:
+        tr.SPATIAL_ORDER_EVERY = m.spatial_order_every = 1
     assert tr.world == world and tr.rank == rank
     snaps = {}
     for it in range(1, 8):              # densifies at iteration 4, resets the opacities at iteration 6
@@ -153,7 +160,7 @@ def _check_replicas_and_mean_gradient_step(snaps, world, mode):
         for k in a.files:                # replicas bit-identical, before and after the densification and the opacity reset
             assert np.array_equal(a[k], b[k]), f"{mode}: rank {r} differs from rank 0 in {k}"
     assert int(a["P_7"]) != P            # the schedule really densified
-    if mode == "rows":                   # ... and every iteration went through the sparse form (none was too dense)
+    if mode in ("rows", "rows_sorted"):  # ... and every iteration went through the sparse form (none was too dense)
         assert a["used"].tolist() == [7, 0], a["used"]
 
     # single-process reference of step 1: Adam on the MEAN of the ranks' views' gradients, statistics summed / maxed
@@ -162,7 +169,7 @@ def _check_replicas_and_mean_gradient_step(snaps, world, mode):
     from w3d_amd.train import Trainer
     dev = torch.device("cuda:0")
     m, opt, cams = _scene_and_cams(dev)
-    tr = Trainer(m, cams, opt, torch.zeros(3, device=dev), densify=False)
+    tr = Trainer(m, cams, opt, torch.zeros(3, device=dev), densify=False, spatial_order=mode.endswith("_sorted"))
     m.update_learning_rate(1)
     n = len(cams)
     total = torch.zeros_like(m.flat_grad)
@@ -197,7 +204,7 @@ def _check_replicas_and_mean_gradient_step(snaps, world, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["rows", "lowrank", "lowrank_early", "dense"])
+@pytest.mark.parametrize("mode", ["rows", "lowrank", "lowrank_early", "dense", "rows_sorted", "dense_sorted"])
 def test_two_ranks_one_gpu_replicas_identical_and_equal_mean_gradient_step(mode, tmp_path):
     _check_replicas_and_mean_gradient_step(_run_ranks(2, mode, "gloo_staged", tmp_path), 2, mode)
 
@@ -208,7 +215,7 @@ def _gpus():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["rows", "lowrank", "lowrank_early", "dense"])
+@pytest.mark.parametrize("mode", ["rows", "lowrank", "lowrank_early", "dense", "rows_sorted"])
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_rccl_ranks_replicas_identical_and_equal_mean_gradient_step(world, mode, tmp_path):
     """Config C5's exchange on the real links: `world` ranks, one GPU each, backend nccl (= RCCL), no shims."""
