@@ -594,7 +594,7 @@ def time_dropin(args, sc, cams, bg, dev, perm, n=None):
     #  restores from its checkpoint is put into Morton order, as Trainer(spatial_order=True) does for the fused step)
     prev = os.environ.get("W3D_SPATIAL_ORDER")
     if not args.no_spatial_order:
-        os.environ["W3D_SPATIAL_ORDER"] = "10"
+        os.environ["W3D_SPATIAL_ORDER"] = "2"
     try:
         out = time_standin(args, sc, cams, bg, dev, perm, True, n, max(3, min(args.warmup, 10)))
     finally:

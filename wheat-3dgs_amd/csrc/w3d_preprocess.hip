@@ -602,14 +602,7 @@ preprocess_bwd_kernel(w3d_view v, int P, const float *means3D, const float *shs,
     constexpr bool STAGED = HAS_SH && FAST16 && !LOWRANK;       // SH gradient rows go through the LDS stage
     __shared__ uint32_t s_rowtot[MODE == 3 ? 5 : 1];
     __shared__ float sh_stage[STAGED ? 256 * W3D_SHROW : 1];
-#ifdef W3D_BWD_INTERLEAVE
-    // A/B: workgroup b takes block (b % K) * seg + b / K — K regions of the index range are swept side by side
-    const uint32_t n_blk = ((uint32_t)P + 255u) / 256u, seg_blk = (n_blk + W3D_BWD_INTERLEAVE - 1u) / W3D_BWD_INTERLEAVE;
-    const uint32_t blk = (blockIdx.x % W3D_BWD_INTERLEAVE) * seg_blk + blockIdx.x / W3D_BWD_INTERLEAVE;
-    if (blk >= n_blk || blockIdx.x / W3D_BWD_INTERLEAVE >= seg_blk) return;
-#else
     const uint32_t blk = blockIdx.x;
-#endif
     const int gid = blk * blockDim.x + threadIdx.x;
     const bool active = gid < P;
     if (!STAGED && MODE != 3 && !active) return;      // (MODE 3: every thread reaches the workgroup barrier of the row compaction)
@@ -1179,11 +1172,7 @@ int w3d_launch_preprocess_backward(const W3DLayout &L, const w3d_view &v, const 
                                    float *dL_dopacity, float *dL_dscales, float *dL_drots, float *dL_dcov3D,
                                    const W3DRawBwdArgs *rawargs, hipStream_t stream) {
     if (L.P == 0) return W3D_OK;
-#ifdef W3D_BWD_INTERLEAVE
-    const int block = 256, grid = (((L.P + block - 1) / block + W3D_BWD_INTERLEAVE - 1) / W3D_BWD_INTERLEAVE) * W3D_BWD_INTERLEAVE;
-#else
     const int block = 256, grid = (L.P + block - 1) / block;
-#endif
     const bool has_sh = (shs != nullptr), has_sr = (scales != nullptr);
     (void)colors_precomp;
     RawBwd raw = {};

@@ -402,15 +402,16 @@ class GaussianModel:
     # ------------------------------------------------------------------ storage order
     def spatial_permutation(self):
         """Row order that puts the Gaussians in Morton (Z-order) order of their positions: 21 bits per axis over the box of the
-        0.1 % .. 99.9 % quantiles (outliers clamp to its faces), stable in the current index — a function of the positions
+        0.1 % .. 99.9 % quantiles of a strided subsample (outliers clamp to its faces), stable in the current index — a function of the positions
         alone, so replicas holding identical positions get the identical order."""
         xyz = torch.nan_to_num(self._p["xyz"].detach().float(), nan=0.0, posinf=0.0, neginf=0.0)
         P = xyz.shape[0]
         if P < 2:
             return torch.arange(P, device=xyz.device)
-        k_lo, k_hi = max(1, int(0.001 * P)), min(P, P - int(0.001 * P))
-        lo = torch.stack([xyz[:, a].kthvalue(k_lo).values for a in range(3)])
-        hi = torch.stack([xyz[:, a].kthvalue(k_hi).values for a in range(3)])
+        # (the quantiles of every (P / 65536)-th row: a sort of <= 2^17 rows — torch.kthvalue over all P takes 12 ms per call)
+        sub = torch.sort(xyz[::max(1, P >> 16)], dim=0).values
+        n = sub.shape[0]
+        lo, hi = sub[int(0.001 * n)], sub[min(n - 1, n - 1 - int(0.001 * n))]
         q = ((xyz - lo) / (hi - lo).clamp_min(1e-12) * 2097151.0).clamp_(0.0, 2097151.0).to(torch.int64)
 
         def spread(v):                                   # 21 bits -> every third bit of 63
@@ -439,7 +440,8 @@ class GaussianModel:
         at 2 M Gaussians).  Nothing the rasterizer computes depends on the order except the
         tie-break of exactly equal depths."""
         perm = self.spatial_permutation()
-        self.reorder(perm)
+        if perm.numel():
+            self._compact(perm, n_keep=perm.numel(), reset_stats=False)        # (an argsort: a permutation by construction)
         return perm
 
     def __deepcopy__(self, memo):
