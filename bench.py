@@ -814,7 +814,7 @@ def scale_model(model, opt, cams, bg, dev, it, steps=30):
     from w3d_amd.train import Trainer
     P = model.num_points
     out = {"gaussians": P}
-    single = Trainer(model, cams, opt, bg, densify=False)
+    single = Trainer(model, cams, opt, bg, densify=False, spatial_order=SPATIAL_ORDER)
     for _ in range(8):
         it += 1
         single.step(it)
@@ -837,7 +837,7 @@ def scale_model(model, opt, cams, bg, dev, it, steps=30):
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
             dist.init_process_group("nccl", store=dist.HashStore(), rank=0, world_size=1, device_id=dev)
         for mode in ("rows", "lowrank"):
-            tr = Trainer(model, cams, opt, bg, densify=False, force_exchange=True, exchange=mode)
+            tr = Trainer(model, cams, opt, bg, densify=False, force_exchange=True, exchange=mode, spatial_order=SPATIAL_ORDER)
             for _ in range(10):
                 it += 1
                 tr.step(it)

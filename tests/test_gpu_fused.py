@@ -116,7 +116,9 @@ def test_fused_raw_step_equals_autograd_step(deg, W, H):
         m.active_sh_degree = deg
         opt = OptimizationParams()
         m.training_setup(opt)
-        tr = Trainer(m, cams, opt, bg, densify=False, fused=fused)
+        # (spatial_order=False: the spy below reads the gradient bucket before optimizer.step(); after a re-sort the parameters are
+        #  new nn.Parameters whose first autograd .grad is a fresh tensor that step() copies into the bucket — as after a densification)
+        tr = Trainer(m, cams, opt, bg, densify=False, fused=fused, spatial_order=False)
         tr.fused_adam = False            # the gradient bucket is compared below: keep the optimizer a separate sweep
         assert tr.fused == fused
         # peek at the gradient bucket of the first step before Adam consumes it
@@ -316,9 +318,9 @@ def test_fused_adam_backward_equals_separate_adam_sweep(P):
         m.active_sh_degree = 3
         opt = OptimizationParams()
         m.training_setup(opt)
-        m.flat_grad.fill_(123.0)
         tr = Trainer(m, cams, opt, bg, densify=False)
         tr.fused_adam = fused_adam
+        m.flat_grad.fill_(123.0)         # (after the Trainer: its spatial_order re-sort rebinds the model's buffers)
         p0 = m.flat.clone()
         tr.step(1)
         one = (m.flat.clone(), m.optimizer.exp_avg.clone(), m.optimizer.exp_avg_sq.clone(), m.xyz_gradient_accum.clone(),

@@ -653,5 +653,7 @@ def test_spatial_order_moves_every_per_gaussian_array_together(monkeypatch):
     assert _is_morton_sorted(t) and t.spatial_order_every == Trainer.SPATIAL_ORDER_EVERY
     assert torch.equal(t._p["xyz"].detach(), sc.xyz[tr.initial_perm])
     u = fresh(0)
-    assert Trainer(u, [0, 1, 2], OptimizationParams(), torch.zeros(3), densify=True, fused=False).initial_perm is None
-    assert torch.equal(u._p["xyz"].detach(), sc.xyz)
+    assert Trainer(u, [0, 1, 2], OptimizationParams(), torch.zeros(3), densify=True, fused=False, spatial_order=False).initial_perm is None
+    assert torch.equal(u._p["xyz"].detach(), sc.xyz) and u.spatial_order_every == 0
+    v = fresh(0)                                         # the default is on
+    assert Trainer(v, [0, 1, 2], OptimizationParams(), torch.zeros(3), densify=True, fused=False).initial_perm is not None

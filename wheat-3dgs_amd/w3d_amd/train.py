@@ -60,11 +60,13 @@ class Trainer:
     def __init__(self, model, cameras, opt, background, pipe=None, cameras_extent=1.0, seed=0,
                  densify=True, loss_fn=photometric_loss, fused=None, force_exchange=False, fused_adam=True,
                  exchange="rows", early_gather=False, lowrank_chunks=None, rows_max_fraction=None, white_background=None,
-                 spatial_order=False):
-        """spatial_order: keep the Gaussians stored in Morton order of their positions (GaussianModel.sort_spatially: culled
-        Gaussians then come in runs and whole waves of the per-Gaussian forward skip their SH rows).  The model is sorted here,
-        at the first and then every SPATIAL_ORDER_EVERY-th densification, and once more when densification ends; the row order of the
-        model is then no longer the reference's (survivors, clones, children) — `initial_perm` is the permutation applied here.
+                 spatial_order=True):
+        """spatial_order (default on): keep the Gaussians stored in Morton order of their positions (GaussianModel.sort_spatially:
+        culled Gaussians then come in runs and whole waves of the per-Gaussian forward skip their SH rows; +2-6 % per step).  The
+        model is sorted HERE — its buffers and nn.Parameters are rebound, as a densification rebinds them: take references to them
+        after constructing the Trainer — at the first and then every SPATIAL_ORDER_EVERY-th densification, and once more when
+        densification ends.  The row order is then no longer the point cloud's / the reference's (survivors, clones, children);
+        `initial_perm` is the permutation applied here.  False keeps the rows where they are.
         white_background: the dataset flag of reference train_vanilla_3dgs.py:44,109 — with it the opacities are ALSO reset once
         at iteration == opt.densify_from_iter (besides every opacity_reset_interval).  The reference derives the background colour
         AND this extra reset from the one flag; None (default) does the same from the other end: a `background` of all ones is a
