@@ -44,7 +44,9 @@ for case in range(cases):
         m.deterministic = True
         opt = OptimizationParams()
         m.training_setup(opt)
-        tr = Trainer(m, cams, opt, bg, densify=False, fused=fused)
+        # (spatial_order=False: the spy reads the gradient bucket before optimizer.step(); after a re-sort the autograd path's first
+        #  .grad is a fresh tensor that step() copies into the bucket, as after a densification — the bucket would still be zero here)
+        tr = Trainer(m, cams, opt, bg, densify=False, fused=fused, spatial_order=False)
         tr.fused_adam = False
         grads = []
         orig = m.optimizer.step
