@@ -574,3 +574,39 @@ def test_trained_scene_full_size_against_oracle():
     attributed_gradient_check("C3-trained", m, cam, gc, ref, gref, want, final_T, o, "[trained C3 attribution] ",
                               residual_frac=2e-4, max_unexplained=2, probe_want=want_probe, scene=Snap)
     o.free()
+
+
+def test_flat_buffer_beyond_2_to_the_31_floats():
+    """Maximum sizes: 37 M Gaussians — a flat parameter buffer of 2.18e9 floats (> 2^31; 8.7 GB per array), 19 M visible — one view
+    against the oracle, then the Trainer's fused step, a re-sort through the compaction kernel and more steps
+    (profiles/big_scene_probe.py in a child process: ~45 GB of HBM and ~60 GB of host memory for a minute; skipped on a box
+    that does not have them).  40 M and 80 M (> 2^32 floats) by hand: profiles/r05/big_scene_{40m,80m}.json."""
+    import json
+    import subprocess
+    import sys
+    avail = 0.0
+    for ln in open("/proc/meminfo"):
+        if ln.startswith("MemAvailable"):
+            avail = int(ln.split()[1]) / 1e6
+    free_hbm = torch.cuda.mem_get_info()[0] / 1e9
+    if avail < 150 or free_hbm < 120:
+        pytest.skip(f"needs 150 GB of host memory and 120 GB of HBM (have {avail:.0f} / {free_hbm:.0f})")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    P = 37_000_000
+    r = subprocess.run([sys.executable, os.path.join(root, "profiles", "big_scene_probe.py"), str(P)], capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "skipped" not in out, out
+    assert out["P"] == P and out["beyond_2^31_floats"] and 0.3 * P < out["visible"] < P
+    assert out["radii"]["visibility_same"] and out["radii"]["differing"] <= 1e-5 * P and out["radii"]["max_abs"] <= 1
+    for k, st in out["images"].items():
+        assert st["frac_gt_2e-4"] <= 1e-4 and st["psnr_db"] >= 110.0, (k, st)
+    for k, st in out["grads"].items():
+        assert st["culled_zero"] and st["p99"] <= 1e-4 and st["n"] > 100_000, (k, st)
+    dn = out["densify_norm"]
+    assert dn["culled_zero"] and dn["p99"] <= 1e-4, dn
+    assert out["adam_moved_parameters"] and out["sort_moved_rows_consistently"] and out["finite_after"]
+    assert out["loss_first_last"][1] < out["loss_first_last"][0]
+    _report(test="flat_buffer_beyond_2^31_floats", **{k: out[k] for k in ("P", "flat_floats", "visible", "num_rendered", "radii", "images",
+                                                                             "densify_norm", "fused_step_ms", "hbm_peak_gb")})
