@@ -99,21 +99,35 @@ def test_bench_with_two_ranks_on_one_gpu(exchange):
 
 
 @pytest.mark.gpu
-def test_bench_default_legs_with_two_ranks():
-    """The flags the driver's SCALE run uses leave the extras on: forward-only render, FlashSplat views and the trained-scene
-    leg run on every rank (max-over-ranks clocks, rank 0 alone measures the workload statistics meanwhile); the single-GPU
-    legs (drop-in loop, densified / opaque scenes, scale_model) stay out of an N > 1 line."""
-    (out0, _), (out1, _) = _run(["--trained-steps", "12"])
+def test_bench_full_legs_with_two_ranks(tmp_path):
+    """--full at N = 2: forward-only render, FlashSplat views and the trained-scene leg run on every rank (max-over-ranks
+    clocks, rank 0 alone measures the workload statistics meanwhile); the single-GPU legs (drop-in loop, densified / opaque
+    scenes, scale_model) stay out of an N > 1 record.  The line stays compact; the legs' objects go to the detail file."""
+    detail = str(tmp_path / "detail.json")
+    (out0, _), (out1, _) = _run(["--full", "--trained-steps", "12", "--detail-file", detail])
     assert out1.strip() == ""
     lines = out0.splitlines()
-    assert len(lines) == 1, out0
+    assert len(lines) == 1 and len(lines[0]) < 4096, out0
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["exchange"]["selfcheck_ok"] is True
-    assert line["trained_value"] > 0 and line["trained_scene"]["after_steps"] >= 12
-    assert line["render_mpix_per_s"] > 0 and line["flashsplat_views_per_s"] > 0
+    assert line["trained_value"] > 0 and line["render_mpix_per_s"] > 0 and line["flashsplat_views_per_s"] > 0
+    assert line["roofline"]["kernel"] and line["roofline"]["frac"] > 0 and line["detail_file"] == detail
+    full = json.load(open(detail))
+    assert full["value"] == line["value"] and full["trained_scene"]["after_steps"] >= 12
     for k in ("dropin", "densified_scene", "opaque_scene", "scale_model", "cpu_baseline"):
-        assert line.get(k) is None, k
-    assert line["roofline"]["kernel"] and line["roofline"]["frac"] > 0
+        assert full.get(k) is None, k
+
+
+@pytest.mark.gpu
+def test_bench_default_run_has_no_legs_with_two_ranks(tmp_path):
+    """the flags the driver's SCALE run uses: the headline step, the render rate, the exchange object — and nothing else"""
+    detail = str(tmp_path / "detail.json")
+    (out0, _), (out1, _) = _run(["--detail-file", detail])
+    line = json.loads(out0.splitlines()[-1])
+    assert out1.strip() == "" and line["n_gpus"] == 2 and line["exchange"]["selfcheck_ok"] is True and line["render_mpix_per_s"] > 0
+    full = json.load(open(detail))
+    for k in ("trained_scene", "flashsplat_views_per_s", "dropin", "densified_scene", "opaque_scene", "scale_model"):
+        assert full.get(k) is None, k
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--rank":
