@@ -119,7 +119,7 @@ typedef struct w3d_view {
 
 /* Version of this ABI: major * 100 + minor.  The major number changes whenever a struct of this header changes its layout or
  * an entry point its signature; a binding must refuse a library whose major number differs from the header it mirrors. */
-#define W3D_ABI_VERSION 301
+#define W3D_ABI_VERSION 302
 int w3d_version(void);
 const char *w3d_last_error(void);
 
@@ -387,6 +387,10 @@ int w3d_debug_tile_ranges(int32_t H, int32_t W, int32_t P, const void *state, ui
 /* Debug/inspection: the per-Gaussian 16-B rect / tile-mask records of the forward (P,4) uint32 {rect lo, rect hi, mask lo, mask hi}
  * (tile units: lo = minx | miny << 16, hi = maxx | maxy << 16; written only when view->tile_cull was set). */
 int w3d_debug_tile_rects(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *rects_out, w3d_stream_t stream);
+/* Debug/inspection: the 64-B per-Gaussian records the blend kernels gather, (P,16) f32: {x, y, rect lo bits, rect hi bits |
+ * conic.x, conic.y, conic.z, opacity | r, g, b, depth | the conic scaled into the log2 domain, opacity}.  Records of culled
+ * Gaussians (radii == 0) are NOT written: they hold whatever the buffer held before — gate on radii. */
+int w3d_debug_gaussian_records(int32_t H, int32_t W, int32_t P, const void *state, float *records_out, w3d_stream_t stream);
 /* Debug/inspection of the per-pixel state kept for backward: final_T (H,W) f32, n_contrib (H,W) u32. */
 int w3d_debug_pixel_state(int32_t H, int32_t W, int32_t P, const void *state, float *final_T_out,
                           uint32_t *n_contrib_out, w3d_stream_t stream);

@@ -31,7 +31,7 @@ def _model(sc, dev):
 
 
 def _subset_inputs(sc, cam, sel):
-    d = view_inputs(sc, cam)
+    d = view_inputs(sc, cam, device="cuda:0")      # (torch's device activations: the raw-parameter kernels reproduce their bits)
     return {k: (None if v is None else v[sel].contiguous()) for k, v in d.items()}
 
 

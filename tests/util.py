@@ -7,14 +7,17 @@ import torch
 from w3d_amd.synth import small_test_scene, make_scene, make_cameras
 
 
-def view_inputs(sc, cam, sh_degree=3, precomp_color=False, precomp_cov=False, scale_modifier=1.0):
+def view_inputs(sc, cam, sh_degree=3, precomp_color=False, precomp_cov=False, scale_modifier=1.0, device=None):
     """Activated rasterizer inputs exactly as reference render() marshals them
-    (gaussian_renderer/__init__.py:57-84)."""
+    (gaussian_renderer/__init__.py:57-84).  device: where the activations of scene/gaussian_model.py:33-41 are evaluated — the
+    reference evaluates them with torch ON THE GPU and hands the results to the rasterizer, so the tests of the raw-parameter
+    kernels (which must reproduce those bits) feed the oracle torch's device results; None: the host's."""
     from oracle.oracle import torch_cov3d, torch_sh_to_rgb
     means = sc.xyz.float().contiguous()
-    opac = torch.sigmoid(sc.opacity).float().contiguous()
-    scales = torch.exp(sc.scaling).float().contiguous()
-    rots = torch.nn.functional.normalize(sc.rotation).float().contiguous()
+    act = (lambda f, t: f(t.float().to(device)).cpu()) if device is not None else (lambda f, t: f(t))  # noqa: E731
+    opac = act(torch.sigmoid, sc.opacity).float().contiguous()
+    scales = act(torch.exp, sc.scaling).float().contiguous()
+    rots = act(torch.nn.functional.normalize, sc.rotation).float().contiguous()
     shs = torch.cat([sc.features_dc, sc.features_rest], 1).float().contiguous()
     d = dict(means3D=means, opacities=opac, shs=shs, colors_precomp=None, scales=scales, rotations=rots,
              cov3D_precomp=None)

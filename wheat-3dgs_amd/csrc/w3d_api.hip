@@ -522,6 +522,16 @@ int w3d_debug_tile_rects(int32_t H, int32_t W, int32_t P, const void *state, uin
     return W3D_OK;
 }
 
+int w3d_debug_gaussian_records(int32_t H, int32_t W, int32_t P, const void *state, float *records_out, w3d_stream_t stream_) {
+    W3DLayout L;
+    int rc = w3d_make_layout(P, H, W, &L);
+    if (rc || !state || (P > 0 && !records_out)) { w3d_set_error("bad arguments"); return W3D_ERR_INVALID; }
+    if (P > 0)
+        W3D_HIP_CHECK(hipMemcpyAsync(records_out, static_cast<const char *>(state) + L.o_grec, (size_t)P * 64, hipMemcpyDeviceToDevice,
+                                     reinterpret_cast<hipStream_t>(stream_)));
+    return W3D_OK;
+}
+
 int w3d_debug_pixel_state(int32_t H, int32_t W, int32_t P, const void *state, float *final_T_out,
                           uint32_t *n_contrib_out, w3d_stream_t stream_) {
     W3DLayout L;

@@ -243,12 +243,34 @@ __device__ __forceinline__ uint64_t footprint_tile_mask(float mx, float my, floa
 }
 
 // Activations of the raw (pre-activation) parameter path — what GaussianModel's getters apply
-// (reference scene/gaussian_model.py:33-41,101-121): exp, sigmoid, F.normalize.
+// (reference scene/gaussian_model.py:33-41,101-121): torch.exp, torch.sigmoid, F.normalize ON THE DEVICE.  The fused path must hand
+// the rasterizer the very bits those torch kernels produce (radii, tile ranges and lists are integer work and compared
+// bit for bit with the activated API fed torch's activations, tests/test_gpu_raw_bitexact.py):
+//   exp      torch's kernel calls ::exp(float) = this expf (ROCm device library, no fast-math on either side);
+//   sigmoid  1 / (1 + exp(-x)) with an IEEE division (aten UnarySpecialOpsKernel.cu);
+//   normalize  x / max(sqrt(sum of squares), 1e-12) — one IEEE division PER COMPONENT (not one reciprocal), the sum of squares in
+//            the order torch's reduction of a contiguous row of four takes on this device: correctly rounded squares added
+//            pairwise, (s0 + s1) + (s2 + s3) — found empirically (profiles/activation_probe.py, profiles/r06/activation_probe.json:
+//            0 of 4 M rows over 60 binades differ from F.normalize with this order and a per-component division; left-to-right
+//            order 469 k, an fma chain 669 k, one reciprocal 2.5 M).
+#ifndef W3D_NORM_ORDER
+#define W3D_NORM_ORDER 1       // 1: (s0+s1)+(s2+s3)   0: ((s0+s1)+s2)+s3   2: fma chain  (0, 2: probe builds only)
+#endif
 __device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ void act_normalize(const float *r, float *q, float &inv_norm) {
-    const float n = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
-    inv_norm = 1.0f / fmaxf(n, 1e-12f);
-    q[0] = r[0] * inv_norm; q[1] = r[1] * inv_norm; q[2] = r[2] * inv_norm; q[3] = r[3] * inv_norm;
+#pragma clang fp contract(off)
+    const float s0 = r[0] * r[0], s1 = r[1] * r[1], s2 = r[2] * r[2], s3 = r[3] * r[3];
+#if W3D_NORM_ORDER == 0
+    const float ss = ((s0 + s1) + s2) + s3;
+#elif W3D_NORM_ORDER == 1
+    const float ss = (s0 + s1) + (s2 + s3);
+#else
+    const float ss = __builtin_fmaf(r[3], r[3], __builtin_fmaf(r[2], r[2], __builtin_fmaf(r[1], r[1], s0)));
+    (void)s1; (void)s2; (void)s3;
+#endif
+    const float d = fmaxf(sqrtf(ss), 1e-12f);
+    inv_norm = 1.0f / d;              // (the backward's chain rule through the normalisation; not on the integer path)
+    q[0] = r[0] / d; q[1] = r[1] / d; q[2] = r[2] / d; q[3] = r[3] / d;
 }
 
 // RAW: `shs` is f_dc (P,1,3), `f_rest` is (P,M-1,3), opacities are logits, scales are log-scales,

@@ -510,6 +510,18 @@ def debug_tile_rects(saved):
     return out
 
 
+def debug_gaussian_records(saved):
+    """(P,16) float32: the 64-B per-Gaussian records of a forward (include/w3d.h w3d_debug_gaussian_records); rows of culled
+    Gaussians (radii == 0) are not written by the forward."""
+    v = saved["view"].c
+    dev = saved["state"].device
+    out = torch.empty(saved["P"], 16, dtype=torch.float32, device=dev)
+    lib.w3d_debug_gaussian_records.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_void_p] * 3
+    lib.w3d_debug_gaussian_records.restype = ctypes.c_int
+    check(lib.w3d_debug_gaussian_records(v.image_height, v.image_width, saved["P"], ptr(saved["state"]), ptr(out), stream_ptr(dev)))
+    return out
+
+
 def debug_pixel_state(saved):
     v = saved["view"].c
     dev = saved["state"].device
