@@ -346,19 +346,28 @@ def test_culls_are_exact_on_needles(seed):
             o.free()
 
 
-@pytest.mark.parametrize("depth_span,P", [("narrow", 150_000), ("wide", 150_000), ("wide", 9_000)])
+@pytest.mark.parametrize("depth_span,P", [("narrow", 150_000), ("wide", 150_000), ("wide", 9_000), ("clustered", 120_000),
+                                          ("two_depths", 30_000)])
 def test_depth_sort_paths_and_tie_order_at_size(depth_span, P):
-    """The depth sort (w3d_binning.hip: 8-bit digits; three passes when the upper halves of the view's depth keys take at
-    most 256 consecutive values, else four) on enough Gaussians that every wave of the sort holds keys, for both digit rules:
-    `narrow` — the benchmark's overhead cameras, depths within one octave; `wide` — the slab stretched 30 units away from the
-    cameras, depths 2 ... 33 (four octaves: the fourth pass runs).  A quarter of the Gaussians are exact duplicates of earlier
-    ones (densify_and_clone's output), so equal keys must keep ascending index order.  Per-tile ranges and lists: bit-identical
-    to the oracle's (stable order by (depth bits, index))."""
+    """The depth sort (w3d_binning.hip: 1024 buckets over the view's depth interval, every bucket sorted in LDS by its low bits) on
+    enough Gaussians that every wave of the split holds keys: `narrow` — the benchmark's overhead cameras, depths within one octave
+    (bucket shift 12-13: two in-bucket passes); `wide` — the slab stretched 30 units away from the cameras, depths 2 ... 33 (four
+    octaves: shift 16, the bucket populations follow the depth distribution); `clustered` — all Gaussians at 24 positions, 5 000
+    EQUAL keys each: buckets beyond the LDS arrays, sorted through their slice of the global buffers, nothing but ties;
+    `two_depths` — two positions (a span below 1024 key values would need no in-bucket pass at all: shift 0).  A quarter of the
+    Gaussians are exact duplicates of earlier ones (densify_and_clone's output), so equal keys must keep ascending index order.
+    Per-tile ranges and lists: bit-identical to the oracle's (stable order by (depth bits, index))."""
     from w3d_amd.synth import make_scene, make_cameras
     W, H = 320, 240
     sc = make_scene(P, seed=23, scale_mean=0.004)
+    g5 = torch.Generator().manual_seed(5)
     if depth_span == "wide":
-        sc.xyz[:, 2] = 0.6 - 30.0 * torch.rand(P, generator=torch.Generator().manual_seed(5))
+        sc.xyz[:, 2] = 0.6 - 30.0 * torch.rand(P, generator=g5)
+    elif depth_span in ("clustered", "two_depths"):
+        k = 24 if depth_span == "clustered" else 2
+        anchors = sc.xyz[:k].clone()
+        sc.xyz[:] = anchors[torch.randint(0, k, (P,), generator=g5)]
+        sc.opacity[:] = -4.0                      # (faint: thousands of them lie on top of each other)
     cam, bg = make_cameras(6, W, H)[2], (0.0, 0.0, 0.0)
     d = view_inputs(sc, cam)
     d = {k: (None if v is None else torch.cat([v, v[: P // 3]], 0).contiguous()) for k, v in d.items()}
@@ -366,7 +375,10 @@ def test_depth_sort_paths_and_tie_order_at_size(depth_span, P):
     ref = o.forward(**np_inputs(d))
     depth = o.geom()["depth"][ref["radii"] > 0]
     octaves = float(np.log2(depth.max() / depth.min()))
-    assert (octaves > 2.5) if depth_span == "wide" else (octaves < 1.0), octaves
+    if depth_span in ("wide", "narrow"):
+        assert (octaves > 2.5) if depth_span == "wide" else (octaves < 1.0), octaves
+    else:
+        assert len(np.unique(depth)) <= 24 and (ref["radii"] > 0).sum() > 0.5 * P
     out, _ = run_hip(d, cam, bg, tile_cull=False)
     check_integers(out, o, ref)
     check_images(out, ref, f"[sort {depth_span}] ")

@@ -5,8 +5,9 @@
 // MI355X-first formulation.  Instead of materialising R = sum(tiles touched) 64-bit
 // (tile|depth) keys and radix-sorting all of them through HBM, the order contract
 // "within a tile ascending depth bits, ties by ascending Gaussian index" is met in two steps:
-//   1. ONE stable LSD radix sort of the (depth bits, index) pairs — P << R, 16 B per Gaussian; its first pass drops the
-//      culled Gaussians and publishes V, the later passes sort the V survivors;
+//   1. ONE stable sort of the (depth bits, index) pairs — P << R, 16 B per Gaussian — as a 1024-way bucket split over the view's
+//      depth interval + an in-LDS sort of every bucket (four launches, "depth sort" below); the split drops the culled
+//      Gaussians and publishes V;
 //   2. a single-pass stable counting sort of the tile instances by tile id: the depth order is cut into C chunks and the
 //      image into bands of tile rows; one wave per (chunk, band) keeps the band's per-tile counters (count pass) or
 //      cursors + 64-bit rank bitmaps (fill pass) in LDS and bins its records 64 at a time, one record per lane —
@@ -23,64 +24,80 @@ namespace {
 
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
-// ------------------------------------------------------------------------------ radix sort
-// One pass = histogram, row scan, scatter.  A "run" is the contiguous slice of keys one wave owns.
+// ------------------------------------------------------------------------------ depth sort
+// Stable sort of the visible Gaussians by (depth bits, index) in FOUR launches (rounds 1-5: an LSD radix sort, 3-4 passes x
+// {histogram, row scan, scatter} = 12 launches, 0.162 ms for 1.2 M keys — a chain of short latency-bound kernels, at the level of
+// rocPRIM's one-sweep sort, 139 us, on this part).
 //
-// The keys are the bit patterns of positive floats (view depths), and a view's depths rarely span more than two octaves
-// (the wheat-plot cameras hover 2-2.5 units above the canopy: depths 1.7-3.2), so their upper 16 bits take at most 256
-// consecutive values.  The first pass's histogram kernel therefore also finds min / max of the visible keys, and when
-// (kmax >> 16) - (kmin >> 16) <= 255 the third pass sorts by (key >> 16) - (kmin >> 16) — ALL the remaining bits in one
-// 8-bit digit — and the fourth pass does not run: 3 passes instead of 4, same order (the digit is a monotone function of the
-// upper half).  Wider depth ranges take the four plain 8-bit passes.  The decision lives on the device (counters[4..5]):
-// kernels of a pass that is not needed exit at once, and the consumers pick the buffer the last executed pass wrote.
-#define W3D_CTL_KMIN_HI 4       // counters[4] = kmin >> 16
-#define W3D_CTL_THREE 5         // counters[5] = 1: three passes suffice
-__device__ __forceinline__ uint32_t radix_digit(uint32_t key, int pass, const uint32_t *__restrict__ ctl) {
-    if (pass < 2) return (key >> (W3D_RADIX_BITS * pass)) & (W3D_RADIX_BINS - 1u);
-    if (ctl[W3D_CTL_THREE]) return (key >> 16) - ctl[W3D_CTL_KMIN_HI];
-    return (key >> (W3D_RADIX_BITS * pass)) & (W3D_RADIX_BINS - 1u);
+// The keys are the bit patterns of positive floats (view depths > 0.2), monotone in the depth, and ONE view's depths are a narrow
+// interval of them.  Every workgroup of the preprocess kernel leaves {min, max} of its visible keys (a block reduction and one 8-B
+// store, nothing to initialise); the histogram kernel reduces them to the view's interval [kmin, kmax].  Then
+//   1. depth_bucket_hist      the interval is cut into W3D_DB_BINS = 1024 equal buckets, bucket(key) = (key - kmin) >> shift with the
+//                             smallest shift that fits; one histogram per run (= the slice of the Gaussian order one wave owns);
+//   2. depth_bucket_scan      per bucket: exclusive scan of the run counts + bucket total;
+//   3. depth_bucket_scatter   stable multi-split of the (key, index) pairs into the buckets (culled Gaussians dropped, V published);
+//   4. depth_bucket_sort      one workgroup per bucket: the bucket (1 200 pairs on the benchmark view) is sorted IN LDS by the low
+//                             `shift` bits — ceil(shift / 8) stable 8-bit passes, 2 for the benchmark cameras — and written out as
+//                             the depth-ordered packed records {id, rect lo, rect hi, depth} + tile mask the (chunk, band) walkers
+//                             stream.  A bucket that does not fit the LDS arrays (everything at one depth, 40 M Gaussians ...) takes
+//                             the same passes through its own slice of the two global (key, id) buffers — slower, same result.
+// Bucket b holds exactly the keys of [kmin + (b << shift), kmin + ((b + 1) << shift)), the scatter keeps index order inside a
+// bucket and the in-bucket passes are stable, so the result is THE stable order by (depth bits, index), whatever the depth
+// distribution (tests/test_gpu_parity.py::test_depth_sort_paths_and_tie_order_at_size: lists bit-identical to the oracle's).
+#define W3D_CTL_KMIN 4          // counters[4] = smallest visible depth key
+#define W3D_CTL_SHIFT 5         // counters[5] = bucket(key) = (key - kmin) >> shift
+#define W3D_DB_CAP 4096         // (key, id) pairs a bucket may hold to be sorted in LDS (2 x 32 KB of ping-pong arrays)
+
+// the bucket grid of this view from the per-workgroup intervals the preprocess left (nb = ceil(P / W3D_PRE_BLOCK) pairs {min, max};
+// every workgroup of the histogram kernel reduces all of them: 62 KB of L2 hits at 2 M Gaussians)
+struct DepthGrid { uint32_t kmin, shift; };
+__device__ __forceinline__ DepthGrid depth_grid(const uint2 *__restrict__ minmax, uint32_t nb, uint32_t *red /* LDS [8] */) {
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (uint32_t i = threadIdx.x; i < nb; i += 256) { const uint2 m = minmax[i]; kmin = min(kmin, m.x); kmax = max(kmax, m.y); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = kmin; red[4 + (threadIdx.x >> 6)] = kmax; }
+    __syncthreads();
+    kmin = min(min(red[0], red[1]), min(red[2], red[3]));
+    kmax = max(max(red[4], red[5]), max(red[6], red[7]));
+    DepthGrid g;
+    g.kmin = kmin;
+    if (kmin > kmax) { g.kmin = 0u; g.shift = 0u; return g; }     // nothing visible
+    const uint32_t span = kmax - kmin;
+    const uint32_t bits = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;
+    g.shift = bits > W3D_DB_BITS ? bits - W3D_DB_BITS : 0u;          // span >> shift < W3D_DB_BINS
+    return g;
 }
 
+// one run per wave, four runs per workgroup; hist[bucket][run] (row pitch = runs rounded up to 4: the four counts of a workgroup
+// leave as one 16-B store per bucket)
 __global__ void __launch_bounds__(256)
-radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items, uint32_t n_runs, int pass,
-                  uint32_t *__restrict__ hist /* [256][n_runs] */, const uint32_t *__restrict__ n_dev, int drop_invalid,
-                  const uint32_t *__restrict__ ctl, uint32_t *__restrict__ minmax /* pass 0: [n_runs][2] */) {
-    __shared__ uint32_t h_all[4][W3D_RADIX_BINS];
+depth_bucket_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items, uint32_t n_runs, uint32_t pitch,
+                         uint32_t *__restrict__ hist, uint32_t *__restrict__ counters, const uint2 *__restrict__ minmax, uint32_t nb) {
+    __shared__ __align__(16) uint32_t h_all[4][W3D_DB_BINS];
+    __shared__ uint32_t red[8];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
-    if (pass == 3 && ctl[W3D_CTL_THREE]) return;
-    uint32_t *h = h_all[wv];
-    for (int i = lane; i < W3D_RADIX_BINS; i += 64) h[i] = 0;
+    const DepthGrid dg = depth_grid(minmax, nb, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { counters[W3D_CTL_KMIN] = dg.kmin; counters[W3D_CTL_SHIFT] = dg.shift; }
+    uint4 *hz = reinterpret_cast<uint4 *>(h_all[wv]);
+#pragma unroll
+    for (int i = 0; i < W3D_DB_BINS / 256; i++) hz[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
     __builtin_amdgcn_wave_barrier();
-    // passes after the first sort only the visible Gaussians (the first pass dropped the culled ones and counted the
-    // rest): n comes from the device and the runs re-partition it evenly
-    if (n_dev) { n = *n_dev; items = max(64u, ((n + n_runs - 1u) / n_runs + 63u) & ~63u); }
     if (run < n_runs) {
         const uint32_t beg = min(n, run * items), end = min(n, beg + items);
-        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-        // (the digit rule of passes 2 / 3 is wave-uniform and loop-invariant: read once)
-        const uint32_t three = pass >= 2 ? ctl[W3D_CTL_THREE] : 0u, kmin_hi = pass >= 2 ? ctl[W3D_CTL_KMIN_HI] : 0u;
-        const int shift = W3D_RADIX_BITS * pass;
 #pragma unroll 8
         for (uint32_t i = beg + lane; i < end; i += 64) {
             const uint32_t key = keys[i];
-            const uint32_t d = three ? (key >> 16) - kmin_hi : (key >> shift) & (W3D_RADIX_BINS - 1u);
-            if (!drop_invalid || key != W3D_INVALID_KEY) {
-                atomicAdd(const_cast<uint32_t *>(&h_all[wv][d & (W3D_RADIX_BINS - 1u)]), 1u);
-                kmin = min(kmin, key); kmax = max(kmax, key);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < W3D_RADIX_BINS; i += 64) hist[(size_t)i * n_runs + run] = h[i];
-        if (minmax) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
-                kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
-            }
-            if (lane == 0) { minmax[2 * run] = kmin; minmax[2 * run + 1] = kmax; }
+            if (key != W3D_INVALID_KEY) atomicAdd(&h_all[wv][(key - dg.kmin) >> dg.shift], 1u);
         }
     }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < W3D_DB_BINS; b += 256)
+        *reinterpret_cast<uint4 *>(&hist[(size_t)b * pitch + 4u * blockIdx.x]) = make_uint4(h_all[0][b], h_all[1][b], h_all[2][b], h_all[3][b]);
 }
 
 // inclusive scan across the 64 lanes of a wave
@@ -113,124 +130,70 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
     return res;
 }
 
-// one block per digit: exclusive scan of that digit's row of per-run counts (in place) + row total
+// one workgroup per bucket: exclusive scan of its row of run counts (in place, four runs per thread) + the bucket's total
 __global__ void __launch_bounds__(256)
-radix_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t n_runs, uint32_t *__restrict__ rowtot, int pass,
-                     uint32_t *__restrict__ ctl, const uint32_t *__restrict__ minmax) {
+depth_bucket_scan_kernel(uint32_t *__restrict__ hist, uint32_t pitch, uint32_t *__restrict__ rowtot) {
     __shared__ uint32_t wave_tot[17];
-    if (pass == 3 && ctl[W3D_CTL_THREE]) return;
-    if (pass == 0 && blockIdx.x == 0) {
-        // depth range of the visible Gaussians -> how many passes the sort needs (see radix_digit)
-        __shared__ uint32_t red[8];
-        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-        for (uint32_t i = threadIdx.x; i < n_runs; i += 256) { kmin = min(kmin, minmax[2 * i]); kmax = max(kmax, minmax[2 * i + 1]); }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
-            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
-        }
-        if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = kmin; red[2 * (threadIdx.x >> 6) + 1] = kmax; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < 4; w++) { kmin = min(kmin, red[2 * w]); kmax = max(kmax, red[2 * w + 1]); }
-            const bool none = kmin > kmax;                       // nothing visible
-            ctl[W3D_CTL_KMIN_HI] = none ? 0u : (kmin >> 16);
-            ctl[W3D_CTL_THREE] = (none || ((kmax >> 16) - (kmin >> 16)) < (uint32_t)W3D_RADIX_BINS) ? 1u : 0u;
-        }
-        __syncthreads();
-    }
-    uint32_t *row = hist + (size_t)blockIdx.x * n_runs;
+    uint4 *row = reinterpret_cast<uint4 *>(hist + (size_t)blockIdx.x * pitch);
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < n_runs; base += 256) {
+    for (uint32_t base = 0; base < pitch / 4u; base += 256) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < n_runs ? row[i] : 0u;
+        const uint4 v = i < pitch / 4u ? row[i] : make_uint4(0u, 0u, 0u, 0u);
         uint32_t tot;
-        const uint32_t ex = block_exclusive_scan(v, wave_tot, tot);
-        if (i < n_runs) row[i] = carry + ex;
+        const uint32_t ex = carry + block_exclusive_scan(v.x + v.y + v.z + v.w, wave_tot, tot);
+        if (i < pitch / 4u) row[i] = make_uint4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
         carry += tot;
     }
     if (threadIdx.x == 0) rowtot[blockIdx.x] = carry;
 }
 
-// CAN_FINAL (passes 2 and 3): the pass that turns out to be the LAST one — the third when three suffice, else the fourth —
-// does not write (key, id) pairs any more but the depth-ordered packed records {id, rect lo, rect hi, depth} + tile mask the
-// (chunk, band) walkers stream (they re-read their chunk once per band and per pass: coalesced records instead of gathers).
-// The 16-B rect / mask line of every Gaussian is gathered one batch ahead of the ranking, the (key, id) pairs two ahead.
-template <bool CAN_FINAL>
+// stable multi-split of the (key, index) pairs into the buckets; the value of key i IS i (the preprocess writes the keys in
+// Gaussian order and no id array); culled Gaussians (key 0xFFFFFFFF) are dropped; V and the bucket boundaries are published
 __global__ void __launch_bounds__(256)
-radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, uint32_t items,
-                     uint32_t n_runs, int pass, const uint32_t *__restrict__ offs /* row-scanned [256][n_runs] */,
-                     const uint32_t *__restrict__ rowtot /* [BINS] */, uint32_t *__restrict__ num_visible,
-                     const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ ctl,
-                     const uint2 *__restrict__ rect, const uint4 *__restrict__ rect_mask, uint4 *__restrict__ rec,
-                     uint2 *__restrict__ rec_mask, int cull) {
-    __shared__ uint32_t cur_all[4][W3D_RADIX_BINS];
+depth_bucket_scatter_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                            uint32_t n, uint32_t items, uint32_t n_runs, uint32_t pitch, const uint32_t *__restrict__ offs,
+                            const uint32_t *__restrict__ rowtot, uint32_t *__restrict__ counters, uint32_t *__restrict__ bstart) {
+    __shared__ uint32_t cur_all[4][W3D_DB_BINS];
+    __shared__ uint32_t wave_tot[17];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
-    if (run >= n_runs) return;
-    if (pass == 3 && ctl[W3D_CTL_THREE]) return;
-    const uint32_t three = pass >= 2 ? ctl[W3D_CTL_THREE] : 0u, kmin_hi = pass >= 2 ? ctl[W3D_CTL_KMIN_HI] : 0u;
-    const bool fin = CAN_FINAL && (pass == 3 || three != 0u);
-    const int shift = W3D_RADIX_BITS * pass;
-    // num_visible != NULL: FIRST pass — culled Gaussians (key 0xFFFFFFFF) are dropped and the number of survivors is
-    // published; n_dev != NULL: later pass over those survivors only (same re-partition as radix_hist_kernel)
-    const bool drop_invalid = num_visible != nullptr;
-    if (n_dev) { n = *n_dev; items = max(64u, ((n + n_runs - 1u) / n_runs + 63u) & ~63u); }
-    uint32_t *cur = cur_all[wv];
+    const uint32_t kmin = counters[W3D_CTL_KMIN], shift = counters[W3D_CTL_SHIFT];
     {
-        // digit bases = exclusive scan of the row totals, BINS/64 consecutive digits per lane
-        constexpr int PER = W3D_RADIX_BINS / 64;
-        uint32_t tot[PER];
-        uint32_t lsum = 0;
+        // bucket bases = exclusive scan of the bucket totals (four consecutive buckets per thread); cursor of run r in bucket b =
+        // base[b] + (counts of the runs before r in b)
+        const uint4 t4 = reinterpret_cast<const uint4 *>(rowtot)[threadIdx.x];
+        uint32_t total;
+        uint32_t base = block_exclusive_scan(t4.x + t4.y + t4.z + t4.w, wave_tot, total);
+        const uint32_t tot[4] = {t4.x, t4.y, t4.z, t4.w};
+        if (blockIdx.x == 0 && threadIdx.x == 0) { counters[0] = total; bstart[W3D_DB_BINS] = total; }   // all counted keys = the visible Gaussians
 #pragma unroll
-        for (int i = 0; i < PER; i += 4) {
-            const uint4 t4 = reinterpret_cast<const uint4 *>(rowtot)[(lane * PER + i) / 4];
-            tot[i] = t4.x; tot[i + 1] = t4.y; tot[i + 2] = t4.z; tot[i + 3] = t4.w;
-            lsum += t4.x + t4.y + t4.z + t4.w;
-        }
-        const uint32_t incl = wave_inclusive_scan(lsum);
-        uint32_t base = incl - lsum;
-        if (num_visible && run == 0 && lane == 63) *num_visible = incl;      // all counted keys = the visible Gaussians
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            const uint32_t d = lane * PER + i;
-            cur[d] = base + offs[(size_t)d * n_runs + run];
+        for (int i = 0; i < 4; i++) {
+            const uint32_t b = threadIdx.x * 4u + i;
+            const uint4 o4 = *reinterpret_cast<const uint4 *>(&offs[(size_t)b * pitch + 4u * blockIdx.x]);
+            cur_all[0][b] = base + o4.x; cur_all[1][b] = base + o4.y; cur_all[2][b] = base + o4.z; cur_all[3][b] = base + o4.w;
+            if (blockIdx.x == 0) bstart[b] = base;
             base += tot[i];
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (run >= n_runs) return;
+    uint32_t *cur = cur_all[wv];
     const uint32_t beg = min(n, run * items), end = min(n, beg + items);
     const uint64_t lt = lanemask_lt();
-    auto gather = [&](uint32_t g) -> uint4 {
-        if (cull) return rect_mask[g];                   // one 16-B record per Gaussian: a single random line
-        const uint2 rc = rect[g];
-        return make_uint4(rc.x, rc.y, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    };
-    // software pipeline: the (key, id) pairs of the next two batches and the rect line of the next batch are in flight while
-    // the current batch is ranked
-    // (first pass: the value of key i is i — the preprocess writes the Gaussians in index order — so no value array is read)
-    // pass 0 (drop_invalid) reads keys in Gaussian order: the value of key i IS i — the preprocess writes no id array, and
-    // vals_in must not be read in that pass
-    auto val_at = [&](uint32_t i) -> uint32_t { return drop_invalid ? i : vals_in[i]; };
-    uint32_t k1 = (beg + lane < end) ? keys_in[beg + lane] : 0u, v1 = (beg + lane < end) ? val_at(beg + lane) : 0u;
-    uint32_t k2 = (beg + 64 + lane < end) ? keys_in[beg + 64 + lane] : 0u, v2 = (beg + 64 + lane < end) ? val_at(beg + 64 + lane) : 0u;
-    uint4 g1 = make_uint4(0u, 0u, 0u, 0u);
-    if (CAN_FINAL && fin && beg + lane < end) g1 = gather(v1);
+    // software pipeline: the keys of the next two batches are in flight while the current batch is ranked
+    uint32_t k1 = (beg + lane < end) ? keys_in[beg + lane] : W3D_INVALID_KEY;
+    uint32_t k2 = (beg + 64 + lane < end) ? keys_in[beg + 64 + lane] : W3D_INVALID_KEY;
     for (uint32_t base = beg; base < end; base += 64) {
         const uint32_t i = base + lane;
-        const uint32_t key = k1, val = v1;
-        const uint4 gg = g1;
-        const bool valid = i < end && !(drop_invalid && key == W3D_INVALID_KEY);
-        k1 = k2; v1 = v2;
-        k2 = 0u; v2 = 0u;
-        if (i + 128 < end) { k2 = keys_in[i + 128]; v2 = val_at(i + 128); }
-        if (CAN_FINAL && fin && i + 64 < end) g1 = gather(v1);
-        const uint32_t d = (three ? (key >> 16) - kmin_hi : (key >> shift)) & (W3D_RADIX_BINS - 1u);
-        // lanes holding the same digit (stable rank = number of such lanes below me)
+        const uint32_t key = k1;
+        const bool valid = key != W3D_INVALID_KEY;
+        k1 = k2;
+        k2 = (i + 128 < end) ? keys_in[i + 128] : W3D_INVALID_KEY;
+        const uint32_t d = valid ? (key - kmin) >> shift : 0u;
+        // lanes holding the same bucket (stable rank = number of such lanes below me)
         uint64_t peers = w3d_ballot(valid);
 #pragma unroll
-        for (int b = 0; b < W3D_RADIX_BITS; b++) {
+        for (int b = 0; b < W3D_DB_BITS; b++) {
             const uint64_t m = w3d_ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
@@ -240,14 +203,94 @@ radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__res
         __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) cur[d] = pos + (uint32_t)__popcll(peers);   // group leader advances the cursor
         __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            if (CAN_FINAL && fin) {
-                rec[pos] = make_uint4(val, gg.x, gg.y, key);          // (the sort key IS the view depth)
-                rec_mask[pos] = make_uint2(gg.z, gg.w);
-            } else {
-                keys_out[pos] = key; vals_out[pos] = val;
-            }
+        if (valid) { keys_out[pos] = key; vals_out[pos] = i; }
+    }
+}
+
+// One stable 8-bit pass of a workgroup (256 threads) over the n (key, id) pairs of ITS bucket, src -> dst; the pairs are cut into
+// four contiguous quarters, one per wave.  src / dst are LDS arrays (bucket <= W3D_DB_CAP) or the bucket's slice of the global
+// buffers; the address space is resolved after inlining.
+__device__ __forceinline__ void bucket_pass(const uint32_t *ksrc, const uint32_t *vsrc, uint32_t *kdst, uint32_t *vdst, uint32_t n,
+                                            uint32_t kmin, uint32_t dshift, uint32_t (*hw)[256], uint32_t *wave_tot) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t per = ((n + 3u) / 4u + 63u) & ~63u;
+    const uint32_t beg = min(n, (uint32_t)wv * per), end = min(n, beg + per);
+#pragma unroll
+    for (int i = 0; i < 4; i++) hw[wv][lane + 64 * i] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = beg + lane; i < end; i += 64) atomicAdd(&hw[wv][((ksrc[i] - kmin) >> dshift) & 255u], 1u);
+    __syncthreads();
+    {
+        // thread <-> digit: digit bases, then the cursor of every wave
+        const uint32_t d = threadIdx.x;
+        const uint32_t c0 = hw[0][d], c1 = hw[1][d], c2 = hw[2][d], c3 = hw[3][d];
+        uint32_t total;
+        const uint32_t base = block_exclusive_scan(c0 + c1 + c2 + c3, wave_tot, total);
+        hw[0][d] = base; hw[1][d] = base + c0; hw[2][d] = base + c0 + c1; hw[3][d] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+    const uint64_t lt = lanemask_lt();
+    uint32_t *cur = hw[wv];
+    for (uint32_t base = beg; base < end; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < end;
+        const uint32_t key = valid ? ksrc[i] : 0u, val = valid ? vsrc[i] : 0u;
+        const uint32_t d = ((key - kmin) >> dshift) & 255u;
+        uint64_t peers = w3d_ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t m = w3d_ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
         }
+        const uint32_t rank = __popcll(peers & lt);
+        uint32_t pos = 0;
+        if (valid) pos = cur[d] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) cur[d] = pos + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        if (valid) { kdst[pos] = key; vdst[pos] = val; }
+    }
+    __syncthreads();
+}
+
+// one workgroup per bucket: sort by the low `shift` bits, write the depth-ordered packed records
+__global__ void __launch_bounds__(256)
+depth_bucket_sort_kernel(uint32_t *__restrict__ keys_a, uint32_t *__restrict__ vals_a, uint32_t *__restrict__ keys_b,
+                         uint32_t *__restrict__ vals_b, const uint32_t *__restrict__ counters, const uint32_t *__restrict__ bstart,
+                         const uint2 *__restrict__ rect, const uint4 *__restrict__ rect_mask, uint4 *__restrict__ rec,
+                         uint2 *__restrict__ rec_mask, int cull) {
+    __shared__ uint32_t lk[2][W3D_DB_CAP], lv[2][W3D_DB_CAP];
+    __shared__ uint32_t hw[4][256];
+    __shared__ uint32_t wave_tot[17];
+    const uint32_t beg = bstart[blockIdx.x], n = bstart[blockIdx.x + 1] - beg;
+    if (n == 0) return;
+    const uint32_t kmin = counters[W3D_CTL_KMIN], shift = counters[W3D_CTL_SHIFT];
+    const uint32_t npass = (shift + 7u) / 8u;
+    auto gather = [&](uint32_t g) -> uint4 {
+        if (cull) return rect_mask[g];                   // one 16-B record per Gaussian: a single random line
+        const uint2 rc = rect[g];
+        return make_uint4(rc.x, rc.y, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    };
+    auto emit = [&](uint32_t i, uint32_t key, uint32_t val) {
+        const uint4 gg = gather(val);
+        rec[beg + i] = make_uint4(val, gg.x, gg.y, key);          // (the sort key IS the view depth)
+        rec_mask[beg + i] = make_uint2(gg.z, gg.w);
+    };
+    if (n <= W3D_DB_CAP) {
+        for (uint32_t i = threadIdx.x; i < n; i += 256) { lk[0][i] = keys_a[beg + i]; lv[0][i] = vals_a[beg + i]; }
+        __syncthreads();
+        uint32_t s = 0;
+        for (uint32_t p = 0; p < npass; p++, s ^= 1u) bucket_pass(lk[s], lv[s], lk[s ^ 1u], lv[s ^ 1u], n, kmin, 8u * p, hw, wave_tot);
+        for (uint32_t i = threadIdx.x; i < n; i += 256) emit(i, lk[s][i], lv[s][i]);
+    } else {
+        // a bucket beyond the LDS arrays: the same passes through its slice of the two global (key, id) buffers
+        uint32_t *ks = keys_a + beg, *vs = vals_a + beg, *kd = keys_b + beg, *vd = vals_b + beg;
+        for (uint32_t p = 0; p < npass; p++) {
+            bucket_pass(ks, vs, kd, vd, n, kmin, 8u * p, hw, wave_tot);
+            uint32_t *t = ks; ks = kd; kd = t;
+            t = vs; vs = vd; vd = t;
+        }
+        for (uint32_t i = threadIdx.x; i < n; i += 256) emit(i, ks[i], vs[i]);
     }
 }
 
@@ -620,42 +663,29 @@ W3DBands w3d_pick_bands(const W3DLayout &L, int mode) {
 }
 }  // namespace
 
-// stable depth sort of the Gaussians + depth-ordered packed records
+// stable depth sort of the visible Gaussians + depth-ordered packed records: four launches (see "depth sort" above)
 int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream) {
     uint32_t *counters = reinterpret_cast<uint32_t *>(state + L.o_counters);
     uint32_t *keys[2] = {reinterpret_cast<uint32_t *>(scratch + L.s_keys0), reinterpret_cast<uint32_t *>(scratch + L.s_keys1)};
     uint32_t *vals[2] = {reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(scratch + L.s_vals1)};
     uint32_t *hist = reinterpret_cast<uint32_t *>(scratch + L.s_hist);
     uint32_t *rowtot = reinterpret_cast<uint32_t *>(scratch + L.s_rowtot);
+    uint32_t *bstart = reinterpret_cast<uint32_t *>(scratch + L.s_bstart);
     if (L.P == 0) return W3D_OK;
-    uint32_t *minmax = reinterpret_cast<uint32_t *>(scratch + L.s_minmax);
-    {
-        // ---- stable LSD radix sort of (depth bits, id): 3 or 4 passes of 8 bits (radix_digit); culled Gaussians carry key
-        // 0xFFFFFFFF and are dropped by the first pass
-        const uint32_t n = (uint32_t)L.P, runs = L.sort_waves, blocks = (runs + 3) / 4;
-        int src = 0;
-        W3D_PROF("depth_sort", stream);
-        for (int pass = 0; pass < W3D_RADIX_PASSES; pass++) {
-            // pass 0 reads all P keys, drops the culled ones and publishes V = counters[0]; passes 1.. sort V keys
-            const uint32_t *n_dev = pass == 0 ? (const uint32_t *)nullptr : counters;
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(blocks), dim3(256), 0, stream, keys[src], n, L.sort_items, runs, pass, hist,
-                               n_dev, pass == 0 ? 1 : 0, counters, pass == 0 ? minmax : (uint32_t *)nullptr);
-            W3D_LAUNCH_CHECK(v.debug, stream);
-            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(W3D_RADIX_BINS), dim3(256), 0, stream, hist, runs, rowtot, pass, counters,
-                               minmax);
-            W3D_LAUNCH_CHECK(v.debug, stream);
-#define SCATTER_ARGS                                                                                                          \
-    keys[src], vals[src], keys[src ^ 1], vals[src ^ 1], n, L.sort_items, runs, pass, hist, rowtot,                            \
-        pass == 0 ? counters : (uint32_t *)nullptr, n_dev, counters, reinterpret_cast<const uint2 *>(state + L.o_rect),       \
-        reinterpret_cast<const uint4 *>(state + L.o_tile_mask), reinterpret_cast<uint4 *>(scratch + L.s_rec),                 \
-        reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull
-            if (pass >= 2) hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(blocks), dim3(256), 0, stream, SCATTER_ARGS);
-            else hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(blocks), dim3(256), 0, stream, SCATTER_ARGS);
-#undef SCATTER_ARGS
-            W3D_LAUNCH_CHECK(v.debug, stream);
-            src ^= 1;
-        }
-    }
+    const uint32_t n = (uint32_t)L.P, runs = L.sort_waves, blocks = (runs + 3) / 4, pitch = blocks * 4;
+    W3D_PROF("depth_sort", stream);
+    hipLaunchKernelGGL(depth_bucket_hist_kernel, dim3(blocks), dim3(256), 0, stream, keys[0], n, L.sort_items, runs, pitch, hist, counters,
+                       reinterpret_cast<const uint2 *>(scratch + L.s_minmax), (n + W3D_PRE_BLOCK - 1) / W3D_PRE_BLOCK);
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    hipLaunchKernelGGL(depth_bucket_scan_kernel, dim3(W3D_DB_BINS), dim3(256), 0, stream, hist, pitch, rowtot);
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    hipLaunchKernelGGL(depth_bucket_scatter_kernel, dim3(blocks), dim3(256), 0, stream, keys[0], keys[1], vals[1], n, L.sort_items, runs,
+                       pitch, hist, rowtot, counters, bstart);
+    W3D_LAUNCH_CHECK(v.debug, stream);
+    // (keys[0] / vals[0] — the unsorted keys are not needed any more — serve as the second buffer of a bucket that is too large for LDS)
+    hipLaunchKernelGGL(depth_bucket_sort_kernel, dim3(W3D_DB_BINS), dim3(256), 0, stream, keys[1], vals[1], keys[0], vals[0], counters,
+                       bstart, reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint4 *>(state + L.o_tile_mask),
+                       reinterpret_cast<uint4 *>(scratch + L.s_rec), reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;
 }

@@ -19,9 +19,11 @@
 #endif
 #define W3D_CHUNK_MAX 65472       // per-chunk Gaussian count must fit a u16 counter (multiple of 64)
 #define W3D_SCAN_SEGS 16
-#define W3D_RADIX_BITS 8          // depth sort: 4 LSD passes of 8 bits (measured: 3 x 11 bits is slower — the
-#define W3D_RADIX_BINS (1 << W3D_RADIX_BITS)   // runs x bins histogram matrix grows 8x and dominates)
-#define W3D_RADIX_PASSES 4          // segments of the chunk axis in the offset scan
+// depth sort (w3d_binning.hip): the view's depth interval is cut into W3D_DB_BINS buckets; every workgroup of the preprocess kernel
+// (W3D_PRE_BLOCK Gaussians) leaves {min, max} of its visible depth keys in s_minmax — plain stores, nothing to initialise
+#define W3D_DB_BITS 10
+#define W3D_DB_BINS (1 << W3D_DB_BITS)
+#define W3D_PRE_BLOCK 256
 
 static inline uint64_t w3d_align_up(uint64_t x, uint64_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -36,7 +38,8 @@ struct W3DLayout {
     uint32_t seg;     // chunks per scan segment
     // ---- state buffer (kept until backward)
     uint64_t o_counters;   // u32[16]: [0]=num_visible [1]=num_rendered [3]=capacity of the list buffer given to stage 2
-                           //          [4]=(min depth key)>>16 [5]=1 if the depth sort needs three passes only (w3d_binning.hip)
+                           //          [4]=min visible depth key [5]=bucket shift of the depth sort (w3d_binning.hip)
+
     uint64_t o_grec;       // float4[4P]: ONE 64-B line per Gaussian, in the layout the blend kernels stage (w3d_render.hip StagedLDS):
                            //   [0] x, y, rect lo (minx | miny << 16), rect hi (maxx | maxy << 16) — the PUBLISHED tile rect: with shared
                            //       lists (w3d_view.list_share) a tile also sees entries of its neighbours and drops those whose rect it
@@ -58,9 +61,10 @@ struct W3DLayout {
     uint64_t state_bytes;
     // ---- scratch buffer (forward temporaries)
     uint64_t s_keys0, s_keys1, s_vals0, s_vals1; // u32[P] each (depth keys, Gaussian ids)
-    uint64_t s_hist;       // u32[BINS * sort_waves] radix digit histograms
-    uint64_t s_rowtot;     // u32[BINS] per-digit totals of the current radix pass
-    uint64_t s_minmax;     // u32[2 * sort_waves] per-run min / max of the visible depth keys (first pass)
+    uint64_t s_hist;       // u32[W3D_DB_BINS * pitch] per-run bucket histograms of the depth sort (pitch = sort_waves rounded up to 4)
+    uint64_t s_rowtot;     // u32[W3D_DB_BINS] bucket totals
+    uint64_t s_bstart;     // u32[W3D_DB_BINS + 1] bucket boundaries in the depth order
+    uint64_t s_minmax;     // uint2[ceil(P / W3D_PRE_BLOCK)] {min, max} of the visible depth keys of every preprocess workgroup
     uint64_t s_cnt;        // u16[C*T] per-chunk per-tile counts
     uint64_t s_off;        // u32[C*T] per-chunk per-tile list offsets
     uint64_t s_part;       // u32[SEGS*T]
@@ -100,7 +104,7 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->o_tile_walk = o;  o += w3d_align_up(T * 4);
     L->o_tile_order = o; o += w3d_align_up((T + 7) / 8 * 8 * 4);
     L->state_bytes = o;
-    // radix sort geometry: one wave per contiguous run of sort_items keys
+    // depth sort geometry: one wave per contiguous run of sort_items keys
     const uint64_t max_runs = 1024;              // one wave per SIMD (measured at P = 2 M: 512 runs 0.216 ms, 1024 0.161, 2048 0.177, 4096 0.214)
     uint64_t items = (Pp + max_runs - 1) / max_runs;
     items = (items + 63) / 64 * 64;
@@ -112,9 +116,10 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->s_keys1 = o; o += w3d_align_up(Pp * 4);
     L->s_vals0 = o; o += w3d_align_up(Pp * 4);
     L->s_vals1 = o; o += w3d_align_up(Pp * 4);
-    L->s_hist = o;  o += w3d_align_up((uint64_t)W3D_RADIX_BINS * L->sort_waves * 4);
-    L->s_rowtot = o; o += w3d_align_up(W3D_RADIX_BINS * 4);
-    L->s_minmax = o; o += w3d_align_up((uint64_t)L->sort_waves * 8);
+    L->s_hist = o;  o += w3d_align_up((uint64_t)W3D_DB_BINS * ((L->sort_waves + 3) / 4 * 4) * 4);
+    L->s_rowtot = o; o += w3d_align_up(W3D_DB_BINS * 4);
+    L->s_bstart = o; o += w3d_align_up((W3D_DB_BINS + 1) * 4);
+    L->s_minmax = o; o += w3d_align_up((Pp + W3D_PRE_BLOCK - 1) / W3D_PRE_BLOCK * 8);
     L->s_cnt = o;   o += w3d_align_up((uint64_t)L->C * T * 2);
     L->s_off = o;   o += w3d_align_up((uint64_t)L->C * T * 4);
     L->s_part = o;  o += w3d_align_up((uint64_t)W3D_SCAN_SEGS * T * 4);
