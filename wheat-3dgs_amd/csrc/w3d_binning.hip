@@ -32,25 +32,37 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x
 // The keys are the bit patterns of positive floats (view depths > 0.2), monotone in the depth, and ONE view's depths are a narrow
 // interval of them.  Every workgroup of the preprocess kernel leaves {min, max} of its visible keys (a block reduction and one 8-B
 // store, nothing to initialise); the histogram kernel reduces them to the view's interval [kmin, kmax].  Then
-//   1. depth_bucket_hist      the interval is cut into W3D_DB_BINS = 1024 equal buckets, bucket(key) = (key - kmin) >> shift with the
-//                             smallest shift that fits; one histogram per run (= the slice of the Gaussian order one wave owns);
+//   1. depth_bucket_hist      the interval is cut into W3D_DB_BINS = 1024 equal buckets, bucket(key) = ((key - kmin) * M) >> 32 with
+//                             M = floor(2^42 / (kmax - kmin + 1)) — monotone in the key, below 1024, and (unlike a power-of-two
+//                             shift, which left 25-45 % of the buckets empty and the others twice as full) using all of them;
+//                             one histogram per run (= the slice of the Gaussian order one wave owns);
 //   2. depth_bucket_scan      per bucket: exclusive scan of the run counts + bucket total;
 //   3. depth_bucket_scatter   stable multi-split of the (key, index) pairs into the buckets (culled Gaussians dropped, V published);
-//   4. depth_bucket_sort      one workgroup per bucket: the bucket (1 200 pairs on the benchmark view) is sorted IN LDS by the low
-//                             `shift` bits — ceil(shift / 8) stable 8-bit passes, 2 for the benchmark cameras — and written out as
+//   4. depth_bucket_sort      one workgroup per bucket: the bucket (1 200 pairs on the benchmark view) is sorted IN LDS by the key's
+//                             offset from the bucket's lower bound (`rbits` bits: the width of a bucket) — ceil(rbits / 8) stable
+//                             8-bit passes, 2 for the benchmark cameras — and written out as
 //                             the depth-ordered packed records {id, rect lo, rect hi, depth} + tile mask the (chunk, band) walkers
 //                             stream.  A bucket that does not fit the LDS arrays (everything at one depth, 40 M Gaussians ...) takes
 //                             the same passes through its own slice of the two global (key, id) buffers — slower, same result.
-// Bucket b holds exactly the keys of [kmin + (b << shift), kmin + ((b + 1) << shift)), the scatter keeps index order inside a
+// Bucket b holds exactly the keys of [kmin + lower(b), kmin + lower(b + 1)), lower(b) = ceil(b * 2^32 / M); the scatter keeps index order inside a
 // bucket and the in-bucket passes are stable, so the result is THE stable order by (depth bits, index), whatever the depth
 // distribution (tests/test_gpu_parity.py::test_depth_sort_paths_and_tie_order_at_size: lists bit-identical to the oracle's).
 #define W3D_CTL_KMIN 4          // counters[4] = smallest visible depth key
-#define W3D_CTL_SHIFT 5         // counters[5] = bucket(key) = (key - kmin) >> shift
+#define W3D_CTL_MUL 5           // counters[5] = M: bucket(key) = ((key - kmin) * M) >> 32 (0: the interval has fewer than 1024 keys, bucket = key - kmin)
+#define W3D_CTL_RBITS 7         // counters[7] = bits of a key's offset inside its bucket
 #define W3D_DB_CAP 4096         // (key, id) pairs a bucket may hold to be sorted in LDS (2 x 32 KB of ping-pong arrays)
 
 // the bucket grid of this view from the per-workgroup intervals the preprocess left (nb = ceil(P / W3D_PRE_BLOCK) pairs {min, max};
 // every workgroup of the histogram kernel reduces all of them: 62 KB of L2 hits at 2 M Gaussians)
-struct DepthGrid { uint32_t kmin, shift; };
+struct DepthGrid { uint32_t kmin, mul, rbits; };
+__device__ __forceinline__ uint32_t depth_bucket(uint32_t key, uint32_t kmin, uint32_t mul) {
+    const uint32_t x = key - kmin;
+    return mul ? __umulhi(x, mul) : x;
+}
+// smallest x with depth_bucket(x) == b
+__device__ __forceinline__ uint32_t depth_bucket_lower(uint32_t b, uint32_t mul) {
+    return mul ? (uint32_t)((((uint64_t)b << 32) + mul - 1u) / mul) : b;
+}
 __device__ __forceinline__ DepthGrid depth_grid(const uint2 *__restrict__ minmax, uint32_t nb, uint32_t *red /* LDS [8] */) {
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
     for (uint32_t i = threadIdx.x; i < nb; i += 256) { const uint2 m = minmax[i]; kmin = min(kmin, m.x); kmax = max(kmax, m.y); }
@@ -64,11 +76,13 @@ __device__ __forceinline__ DepthGrid depth_grid(const uint2 *__restrict__ minmax
     kmin = min(min(red[0], red[1]), min(red[2], red[3]));
     kmax = max(max(red[4], red[5]), max(red[6], red[7]));
     DepthGrid g;
-    g.kmin = kmin;
-    if (kmin > kmax) { g.kmin = 0u; g.shift = 0u; return g; }     // nothing visible
+    g.kmin = kmin; g.mul = 0u; g.rbits = 0u;
+    if (kmin > kmax) { g.kmin = 0u; return g; }                        // nothing visible
     const uint32_t span = kmax - kmin;
-    const uint32_t bits = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;
-    g.shift = bits > W3D_DB_BITS ? bits - W3D_DB_BITS : 0u;          // span >> shift < W3D_DB_BINS
+    if (span < W3D_DB_BINS) return g;                                  // one key value per bucket: nothing to sort inside
+    g.mul = (uint32_t)((1ull << (32 + W3D_DB_BITS)) / ((uint64_t)span + 1ull));      // < 2^32 since span + 1 > 1024; (span * mul) >> 32 < 1024
+    const uint32_t wmax = (uint32_t)(((1ull << 32) + g.mul - 1u) / g.mul) + 1u;      // lower(b + 1) - lower(b) <= ceil(2^32 / mul) + 1
+    g.rbits = 32u - (uint32_t)__builtin_clz(wmax);
     return g;
 }
 
@@ -82,17 +96,19 @@ depth_bucket_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
     const DepthGrid dg = depth_grid(minmax, nb, red);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { counters[W3D_CTL_KMIN] = dg.kmin; counters[W3D_CTL_SHIFT] = dg.shift; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { counters[W3D_CTL_KMIN] = dg.kmin; counters[W3D_CTL_MUL] = dg.mul; counters[W3D_CTL_RBITS] = dg.rbits; }
     uint4 *hz = reinterpret_cast<uint4 *>(h_all[wv]);
 #pragma unroll
     for (int i = 0; i < W3D_DB_BINS / 256; i++) hz[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
     __builtin_amdgcn_wave_barrier();
     if (run < n_runs) {
+        // (per-lane LDS atomics: finding the lanes of one bucket by ballots first — in Morton storage order a batch falls into a
+        //  handful of buckets — was measured and is slower, 25 -> 32 us)
         const uint32_t beg = min(n, run * items), end = min(n, beg + items);
 #pragma unroll 8
         for (uint32_t i = beg + lane; i < end; i += 64) {
             const uint32_t key = keys[i];
-            if (key != W3D_INVALID_KEY) atomicAdd(&h_all[wv][(key - dg.kmin) >> dg.shift], 1u);
+            if (key != W3D_INVALID_KEY) atomicAdd(&h_all[wv][depth_bucket(key, dg.kmin, dg.mul)], 1u);
         }
     }
     __syncthreads();
@@ -157,7 +173,7 @@ depth_bucket_scatter_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__re
     __shared__ uint32_t wave_tot[17];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
-    const uint32_t kmin = counters[W3D_CTL_KMIN], shift = counters[W3D_CTL_SHIFT];
+    const uint32_t kmin = counters[W3D_CTL_KMIN], mul = counters[W3D_CTL_MUL];
     {
         // bucket bases = exclusive scan of the bucket totals (four consecutive buckets per thread); cursor of run r in bucket b =
         // base[b] + (counts of the runs before r in b)
@@ -189,7 +205,7 @@ depth_bucket_scatter_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__re
         const bool valid = key != W3D_INVALID_KEY;
         k1 = k2;
         k2 = (i + 128 < end) ? keys_in[i + 128] : W3D_INVALID_KEY;
-        const uint32_t d = valid ? (key - kmin) >> shift : 0u;
+        const uint32_t d = valid ? depth_bucket(key, kmin, mul) : 0u;
         // lanes holding the same bucket (stable rank = number of such lanes below me)
         uint64_t peers = w3d_ballot(valid);
 #pragma unroll
@@ -207,18 +223,21 @@ depth_bucket_scatter_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__re
     }
 }
 
-// One stable 8-bit pass of a workgroup (256 threads) over the n (key, id) pairs of ITS bucket, src -> dst; the pairs are cut into
-// four contiguous quarters, one per wave.  src / dst are LDS arrays (bucket <= W3D_DB_CAP) or the bucket's slice of the global
-// buffers; the address space is resolved after inlining.
+// One stable 8-bit pass of a workgroup (256 threads) over n items of ITS bucket, src -> dst; the items are cut into four contiguous
+// quarters, one per wave.  PAIRS: (key, id) pairs in the bucket's slice of the global buffers, digit = ((key - kmin) >> dshift) & 255
+// (kmin: the bucket's smallest possible key).  !PAIRS: single words c = offset of the key in the bucket << 12 | position after the
+// split (n <= 4096) in LDS, digit = (c >> dshift) & 255.  (The address spaces are resolved after inlining.)
+template <bool PAIRS>
 __device__ __forceinline__ void bucket_pass(const uint32_t *ksrc, const uint32_t *vsrc, uint32_t *kdst, uint32_t *vdst, uint32_t n,
                                             uint32_t kmin, uint32_t dshift, uint32_t (*hw)[256], uint32_t *wave_tot) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t per = ((n + 3u) / 4u + 63u) & ~63u;
     const uint32_t beg = min(n, (uint32_t)wv * per), end = min(n, beg + per);
+    auto digit = [&](uint32_t k) -> uint32_t { return (((PAIRS ? k - kmin : k)) >> dshift) & 255u; };
 #pragma unroll
     for (int i = 0; i < 4; i++) hw[wv][lane + 64 * i] = 0u;
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = beg + lane; i < end; i += 64) atomicAdd(&hw[wv][((ksrc[i] - kmin) >> dshift) & 255u], 1u);
+    for (uint32_t i = beg + lane; i < end; i += 64) atomicAdd(&hw[wv][digit(ksrc[i])], 1u);
     __syncthreads();
     {
         // thread <-> digit: digit bases, then the cursor of every wave
@@ -234,8 +253,8 @@ __device__ __forceinline__ void bucket_pass(const uint32_t *ksrc, const uint32_t
     for (uint32_t base = beg; base < end; base += 64) {
         const uint32_t i = base + lane;
         const bool valid = i < end;
-        const uint32_t key = valid ? ksrc[i] : 0u, val = valid ? vsrc[i] : 0u;
-        const uint32_t d = ((key - kmin) >> dshift) & 255u;
+        const uint32_t key = valid ? ksrc[i] : 0u, val = (PAIRS && valid) ? vsrc[i] : 0u;
+        const uint32_t d = digit(key);
         uint64_t peers = w3d_ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -248,49 +267,78 @@ __device__ __forceinline__ void bucket_pass(const uint32_t *ksrc, const uint32_t
         __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) cur[d] = pos + (uint32_t)__popcll(peers);
         __builtin_amdgcn_wave_barrier();
-        if (valid) { kdst[pos] = key; vdst[pos] = val; }
+        if (valid) { kdst[pos] = key; if (PAIRS) vdst[pos] = val; }
     }
     __syncthreads();
 }
 
-// one workgroup per bucket: sort by the low `shift` bits, write the depth-ordered packed records
+// one workgroup per bucket: sort by the offset from the bucket's lower bound, write the depth-ordered packed records
 __global__ void __launch_bounds__(256)
 depth_bucket_sort_kernel(uint32_t *__restrict__ keys_a, uint32_t *__restrict__ vals_a, uint32_t *__restrict__ keys_b,
                          uint32_t *__restrict__ vals_b, const uint32_t *__restrict__ counters, const uint32_t *__restrict__ bstart,
                          const uint2 *__restrict__ rect, const uint4 *__restrict__ rect_mask, uint4 *__restrict__ rec,
                          uint2 *__restrict__ rec_mask, int cull) {
-    __shared__ uint32_t lk[2][W3D_DB_CAP], lv[2][W3D_DB_CAP];
+    __shared__ uint32_t lc[2][W3D_DB_CAP];
     __shared__ uint32_t hw[4][256];
     __shared__ uint32_t wave_tot[17];
     const uint32_t beg = bstart[blockIdx.x], n = bstart[blockIdx.x + 1] - beg;
     if (n == 0) return;
-    const uint32_t kmin = counters[W3D_CTL_KMIN], shift = counters[W3D_CTL_SHIFT];
-    const uint32_t npass = (shift + 7u) / 8u;
+    const uint32_t rbits = counters[W3D_CTL_RBITS];
+    const uint32_t klo = counters[W3D_CTL_KMIN] + depth_bucket_lower(blockIdx.x, counters[W3D_CTL_MUL]);      // smallest key of this bucket
+    const uint32_t npass = (rbits + 7u) / 8u;
     auto gather = [&](uint32_t g) -> uint4 {
         if (cull) return rect_mask[g];                   // one 16-B record per Gaussian: a single random line
         const uint2 rc = rect[g];
         return make_uint4(rc.x, rc.y, 0xFFFFFFFFu, 0xFFFFFFFFu);
     };
-    auto emit = [&](uint32_t i, uint32_t key, uint32_t val) {
-        const uint4 gg = gather(val);
-        rec[beg + i] = make_uint4(val, gg.x, gg.y, key);          // (the sort key IS the view depth)
-        rec_mask[beg + i] = make_uint2(gg.z, gg.w);
+    // the records of the sorted bucket, four per thread at a time so that the four dependent chains (position -> id -> rect line)
+    // are in flight together; src(i) = position of the i-th smallest item in the split's output
+    auto emit_all = [&](const uint32_t *ks, const uint32_t *vs, auto src) {
+        for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 1024) {
+            uint32_t key[4], val[4];
+            uint4 gg[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + 256u * u;
+                if (i < n) { const uint32_t j = src(i); key[u] = ks[j]; val[u] = vs[j]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (i0 + 256u * u < n) gg[u] = gather(val[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + 256u * u;
+                if (i < n) {
+                    rec[beg + i] = make_uint4(val[u], gg[u].x, gg[u].y, key[u]);          // (the sort key IS the view depth)
+                    rec_mask[beg + i] = make_uint2(gg[u].z, gg[u].w);
+                }
+            }
+        }
     };
-    if (n <= W3D_DB_CAP) {
-        for (uint32_t i = threadIdx.x; i < n; i += 256) { lk[0][i] = keys_a[beg + i]; lv[0][i] = vals_a[beg + i]; }
+    if (npass == 0) {
+        emit_all(keys_a + beg, vals_a + beg, [](uint32_t i) { return i; });
+    } else if (n <= W3D_DB_CAP && rbits <= 20u) {
+        // in LDS, one word per item: (offset of the key in the bucket) << 12 | position after the split
+        for (uint32_t i = threadIdx.x; i < n; i += 256) lc[0][i] = ((keys_a[beg + i] - klo) << 12) | i;
         __syncthreads();
         uint32_t s = 0;
-        for (uint32_t p = 0; p < npass; p++, s ^= 1u) bucket_pass(lk[s], lv[s], lk[s ^ 1u], lv[s ^ 1u], n, kmin, 8u * p, hw, wave_tot);
-        for (uint32_t i = threadIdx.x; i < n; i += 256) emit(i, lk[s][i], lv[s][i]);
+#ifndef W3D_SORT_NOPASS
+        for (uint32_t p = 0; p < npass; p++, s ^= 1u) bucket_pass<false>(lc[s], nullptr, lc[s ^ 1u], nullptr, n, 0u, 12u + 8u * p, hw, wave_tot);
+#endif
+        const uint32_t *fin = lc[s];
+#ifndef W3D_SORT_NOEMIT
+        emit_all(keys_a + beg, vals_a + beg, [&](uint32_t i) { return fin[i] & 4095u; });
+#else
+        if (fin[threadIdx.x] == 0xdeadbeef) rec[0] = make_uint4(0, 0, 0, 0);
+#endif
     } else {
-        // a bucket beyond the LDS arrays: the same passes through its slice of the two global (key, id) buffers
+        // a bucket beyond the LDS array (or offsets of 21+ bits): the same passes on (key, id) pairs through its slice of the two global buffers
         uint32_t *ks = keys_a + beg, *vs = vals_a + beg, *kd = keys_b + beg, *vd = vals_b + beg;
         for (uint32_t p = 0; p < npass; p++) {
-            bucket_pass(ks, vs, kd, vd, n, kmin, 8u * p, hw, wave_tot);
+            bucket_pass<true>(ks, vs, kd, vd, n, klo, 8u * p, hw, wave_tot);
             uint32_t *t = ks; ks = kd; kd = t;
             t = vs; vs = vd; vd = t;
         }
-        for (uint32_t i = threadIdx.x; i < n; i += 256) emit(i, ks[i], vs[i]);
+        emit_all(ks, vs, [](uint32_t i) { return i; });
     }
 }
 
