@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(LNT)
 ssim_pass_b(int H, int W, const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ d_mu1,
             const float *__restrict__ d_ex2, const float *__restrict__ d_exy, float c_l1, float c_ssim,
             const float *__restrict__ w_l1, const float *__restrict__ w_ssim, int weighted,
-            float *__restrict__ grad, GW11 gw) {
+            float *__restrict__ grad, GW11 gw, const float *__restrict__ sums, uint32_t nblocks, float lambda, float inv_n,
+            float *__restrict__ loss) {
     // grad = c_l1 * sign(x - y) - c_ssim * d(sum of the ssim map)/dx.  Classic call: c_l1 = (1 - lambda) / n, c_ssim = lambda / n.
     // Weighted call (w3d_l1_ssim_grad): the upstream gradients dL/dL1 and dL/dSSIM are device scalars (NULL = 0) and scale
     // 1/n and -1/n.
@@ -229,6 +230,19 @@ ssim_pass_b(int H, int W, const float *__restrict__ img, const float *__restrict
             grad[pix] = c_l1 * sgn - c_ssim * (acc[0][o] + 2.f * x * acc[1][o] + y * acc[2][o]);
         }
     }
+    // the loss value (w3d_l1_ssim_fwd_bwd: `loss` non-NULL): pass A's per-block partials are complete — it is the previous kernel on
+    // the stream — and the first workgroup adds them up in a fixed order after its own tile (rounds 1-5: a loss_finalize launch
+    // between the two passes)
+    if (loss && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        __shared__ float red[LNT / 64];
+        float a = 0.f, b = 0.f;
+        const float2 *s2 = reinterpret_cast<const float2 *>(sums);
+#pragma unroll 4
+        for (uint32_t i = tid; i < nblocks; i += LNT) { const float2 v = s2[i]; a += v.x; b += v.y; }
+        const float l1 = block_sum(a, red);
+        const float sv = block_sum(b, red);
+        if (tid == 0) loss[0] = (1.f - lambda) * (l1 * inv_n) + lambda * (1.f - sv * inv_n);
+    }
 }
 
 __global__ void __launch_bounds__(1024)
@@ -288,11 +302,9 @@ extern "C" int w3d_l1_ssim_fwd_bwd(int32_t C, int32_t H, int32_t W, const float 
     W3D_PROF("loss", stream);
     hipLaunchKernelGGL(ssim_pass_a, b.grid, dim3(LNT), 0, stream, H, W, image, gt, b.d_mu1, b.d_ex2, b.d_exy, b.sums, b.gw);
     W3D_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(1024), 0, stream, b.sums, (uint32_t)(b.grid.x * b.grid.y * b.grid.z), lambda_dssim,
-                       b.inv_n, loss_out, (float *)nullptr, (float *)nullptr);
     hipLaunchKernelGGL(ssim_pass_b, b.grid, dim3(LNT), 0, stream, H, W, image, gt, b.d_mu1, b.d_ex2, b.d_exy,
                        (1.f - lambda_dssim) * b.inv_n, lambda_dssim * b.inv_n, (const float *)nullptr, (const float *)nullptr, 0,
-                       dL_dimage, b.gw);
+                       dL_dimage, b.gw, (const float *)b.sums, (uint32_t)(b.grid.x * b.grid.y * b.grid.z), lambda_dssim, b.inv_n, loss_out);
     W3D_HIP_CHECK(hipGetLastError());
     return W3D_OK;
 }
@@ -323,7 +335,7 @@ extern "C" int w3d_l1_ssim_grad(int32_t C, int32_t H, int32_t W, const float *im
     const LossBufs b = loss_bufs(C, H, W, scratch);
     // dSSIM/dx = +1/n * d(sum of the map)/dx: the classic call's c_ssim carries lambda/n with a minus sign in the formula
     hipLaunchKernelGGL(ssim_pass_b, b.grid, dim3(LNT), 0, stream, H, W, image, gt, b.d_mu1, b.d_ex2, b.d_exy, b.inv_n, -b.inv_n,
-                       w_l1, w_ssim, 1, dL_dimage, b.gw);
+                       w_l1, w_ssim, 1, dL_dimage, b.gw, (const float *)nullptr, 0u, 0.f, 0.f, (float *)nullptr);
     W3D_HIP_CHECK(hipGetLastError());
     return W3D_OK;
 }

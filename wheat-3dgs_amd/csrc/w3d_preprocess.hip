@@ -124,6 +124,15 @@ __device__ __forceinline__ void xform4x4(const float *m, const float *p, float *
 // 4-byte-aligned 16-byte vector (gfx950 handles unaligned dwordx4 global accesses)
 struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
 #define W3D_SH_CHUNKS 720   // 16-B chunks in 64 f_rest rows of 45 floats
+#ifndef W3D_SH_ROUNDS
+#define W3D_SH_ROUNDS 2     // preprocess forward: the 64 rows of a wave staged through LDS in this many rounds (2: 32 rows at a time)
+#endif
+#ifndef W3D_PRE_OCC
+#define W3D_PRE_OCC 4       // ... and the waves per SIMD it is compiled for.  One round needs 46 KB of LDS per workgroup AND 129 VGPRs
+                            // (twelve 16-B chunks in flight per lane): 3 waves per SIMD either way — round 5 halved only the LDS and
+                            // measured nothing.  Two rounds: 23 KB, 101 VGPRs, 4 waves: 120.8 -> 112.5 us (same-box A/B,
+                            // profiles/r06/ab_preprocess_fwd.txt; 5 waves spill 50 registers: 117 us, 6 waves 242: 183 us)
+#endif
 
 // Loads the active SH coefficients of one Gaussian into c[3k + ch].
 //   interleaved layout: sh -> this Gaussian's (M,3) block (reference get_features layout);
@@ -276,7 +285,7 @@ __device__ __forceinline__ void act_normalize(const float *r, float *q, float &i
 // RAW: `shs` is f_dc (P,1,3), `f_rest` is (P,M-1,3), opacities are logits, scales are log-scales,
 // rotations are un-normalised quaternions; the activations are applied here.
 template <bool RAW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, W3D_PRE_OCC)
 preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, int lsx, int lsy, const float *__restrict__ means3D,
                       const float *__restrict__ shs, const float *__restrict__ f_rest, const float *__restrict__ colors_precomp,
                       const float *__restrict__ opacities, const float *__restrict__ scales,
@@ -287,7 +296,7 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, int lsx, int lsy, const
                       uint4 *__restrict__ tile_mask, const uint8_t *__restrict__ used_mask, uint2 *__restrict__ minmax) {
 #pragma clang fp contract(off)
     // f_rest rows of one wave's 64 Gaussians (64 x 180 B, contiguous in memory) on their way to the lanes
-    __shared__ float4 s_sh[RAW ? 4 : 1][RAW ? W3D_SH_CHUNKS : 1];
+    __shared__ float4 s_sh[RAW ? 4 : 1][RAW ? W3D_SH_CHUNKS / W3D_SH_ROUNDS : 1];
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = g < P;
     Cam cam;
@@ -383,6 +392,7 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, int lsx, int lsy, const
             const int rows = (int)min((size_t)64, (size_t)P - g0);          // > 0 whenever a lane is visible
             const int nfl = rows * 45, nch = nfl >> 2;
             const float4 *src = reinterpret_cast<const float4 *>(f_rest + g0 * 45);
+#if W3D_SH_ROUNDS == 1
             float4 t[W3D_SH_CHUNKS / 64 + 1];
 #pragma unroll
             for (int i = 0; i < W3D_SH_CHUNKS / 64 + 1; i++) {
@@ -408,6 +418,42 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, int lsx, int lsy, const
 #pragma unroll
                 for (int i = 0; i < 45; i++) c[3 + i] = row[i];
             }
+#else
+            // two rounds of 32 rows (row 32 starts on a chunk boundary: 32 * 45 floats = 360 chunks): half the LDS, half the
+            // chunks in flight per lane; the lanes of the round's half of the wave pick up their rows
+            constexpr int HC = W3D_SH_CHUNKS / 2;                  // 360 chunks per round
+            if (vis) { c[0] = dc[0]; c[1] = dc[1]; c[2] = dc[2]; }
+#pragma unroll
+            for (int rnd = 0; rnd < 2; rnd++) {
+                if (((vm >> (32 * rnd)) & 0xFFFFFFFFull) == 0ull) continue;     // nobody of this half is visible
+                float4 t[HC / 64 + 1];
+#pragma unroll
+                for (int i = 0; i < HC / 64 + 1; i++) {
+                    const int lc = lane + 64 * i, ch = HC * rnd + lc;
+                    const int r0 = (4 * ch) / 45, r1 = (4 * ch + 3) / 45;
+                    const bool need = lc < HC && ch < nch && (((vm >> r0) | (vm >> min(r1, 63))) & 1ull);
+                    t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (need) t[i] = src[ch];
+                }
+#pragma unroll
+                for (int i = 0; i < HC / 64 + 1; i++) {
+                    const int lc = lane + 64 * i;
+                    if (lc < HC) s_sh[wv][lc] = t[i];
+                }
+                // (a ragged last wave: the 1-3 floats behind its last whole chunk)
+                if ((nfl & 3) && lane < (nfl & 3) && nch >= HC * rnd && nch < HC * (rnd + 1))
+                    reinterpret_cast<float *>(s_sh[wv])[4 * (nch - HC * rnd) + lane] = f_rest[g0 * 45 + 4 * nch + lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (vis && (lane >> 5) == rnd) {
+                    const float *row = reinterpret_cast<const float *>(s_sh[wv]) + 45 * (lane & 31);
+#pragma unroll
+                    for (int i = 0; i < 45; i++) c[3 + i] = row[i];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+#endif
         }
     }
     if (vis) {
