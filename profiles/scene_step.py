@@ -31,6 +31,11 @@ def main():
     ap.add_argument("--freeze", action="store_true",
                     help="with --report: the parameters do NOT change — every iteration is forward + loss + gradient-writing backward "
                          "(no optimizer step), so variants that alter results are still timed on identical work")
+    ap.add_argument("--walk-stats", action="store_true",
+                    help="print the distribution of the tiles' walk lengths (the blend backward's work per wave) per camera and what "
+                         "the one-wave-per-tile schedule loses to its longest tiles: list-scheduling makespan of the 8 XCD ranges on "
+                         "512 wave slots each, tiles longest first, against the perfectly divisible bound; the same with every tile "
+                         "above `split` x the bound cut into two half-tile waves costing 0.6 of the tile each")
     ap.add_argument("--report", action="store_true",
                     help="instead of the marker window: time --steps steps (bench.StepMeter: probe, timed, per-stage events) and print "
                          "one JSON line {scene, iters_per_s, ms_per_step, stage_ms} — the A/B harness of profiles/ab_scenes.sh")
@@ -90,6 +95,38 @@ def main():
     for _ in range(0 if (a.report and a.freeze) else a.warmup):      # (--freeze: the variant under test never trains the model)
         it += 1
         trainer.step(it)
+    if a.walk_stats:
+        import heapq
+        import json
+
+        def makespan(jobs, slots):
+            h = [0.0] * slots
+            heapq.heapify(h)
+            for j in sorted(jobs, reverse=True):
+                heapq.heappush(h, heapq.heappop(h) + j)
+            return max(h)
+        out = []
+        for ci in (0, 7, 14, 21, 28, 35):
+            cam = cams[ci % len(cams)]
+            w = cam.world_view_transform._w3d_tile_walk.cpu().numpy().astype(float) + 12.0     # (+ a wave's fixed cost in entries)
+            T = len(w)
+            per = (T + 7) // 8
+            res = {"camera": ci, "tiles": T, "walk_sum": int(w.sum()), "mean": round(w.mean(), 1), "p99": int(sorted(w)[int(0.99 * T)]), "max": int(w.max())}
+            bound = max(w.sum() / 4096.0, 1.0)
+            for name, split in (("one_wave_per_tile", None), ("split_2.0", 2.0), ("split_1.5", 1.5), ("split_1.0", 1.0)):
+                ms = 0.0
+                for x in range(8):
+                    jobs = []
+                    for t in w[x * per:(x + 1) * per]:
+                        if split is not None and t > split * bound:
+                            jobs += [0.6 * t, 0.6 * t]
+                        else:
+                            jobs.append(t)
+                    ms = max(ms, makespan(jobs, 512))
+                res[name] = round(ms / bound, 3)
+            out.append(res)
+        print(json.dumps({"scene": a.scene, "gaussians": model.num_points, "schedule_over_divisible_bound": out}))
+        return
     if a.report and a.freeze:
         import ctypes
         import json

@@ -611,7 +611,9 @@ seg_sum_kernel(const uint16_t *__restrict__ cnt, uint32_t C, uint32_t T, uint32_
 // eight block scans with their barriers took 15 us to move 0.5 MB).
 __global__ void __launch_bounds__(1024)
 tile_scan_kernel(const uint32_t *__restrict__ part, uint32_t T, uint32_t nseg, uint32_t *__restrict__ tile_start,
-                 uint32_t *__restrict__ counters, uint32_t share_code) {
+                 uint32_t *__restrict__ counters, uint32_t share_code, uint32_t *__restrict__ tile_walk, uint32_t n_tiles) {
+    // (the blend forward's walk lengths: the part-waves of a split tile report theirs with atomicMax, w3d_render.hip)
+    for (uint32_t t = threadIdx.x; t < n_tiles; t += 1024u) tile_walk[t] = 0u;
     constexpr uint32_t PER = 8, SPAN = 1024u * PER;
     __shared__ uint32_t wave_tot[17];
     __shared__ uint32_t tot_s[SPAN];
@@ -773,7 +775,7 @@ int w3d_launch_tile_count(const W3DLayout &L, const w3d_view &v, char *state, ch
     hipLaunchKernelGGL(seg_sum_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, L.C, T, L.seg, part);
     W3D_LAUNCH_CHECK(v.debug, stream);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, part, T, (uint32_t)W3D_SCAN_SEGS, tile_start, counters,
-                       (uint32_t)L.lsx | ((uint32_t)L.lsy << 8));
+                       (uint32_t)L.lsx | ((uint32_t)L.lsy << 8), reinterpret_cast<uint32_t *>(state + L.o_tile_walk), (uint32_t)L.T);
     W3D_LAUNCH_CHECK(v.debug, stream);
     hipLaunchKernelGGL(chunk_off_kernel, dim3(tb, W3D_SCAN_SEGS), dim3(256), 0, stream, cnt, part, tile_start, L.C, T, L.seg, off);
     W3D_LAUNCH_CHECK(v.debug, stream);

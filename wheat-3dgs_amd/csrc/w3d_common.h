@@ -57,7 +57,7 @@ struct W3DLayout {
     uint64_t o_final_T;    // float[HW]
     uint64_t o_n_contrib;  // u32[HW]
     uint64_t o_tile_walk;  // u32[T]: entries of the tile's list the forward blended at all (max n_contrib of its pixels)
-    uint64_t o_tile_order; // u32[8 * ceil(T / 8)]: the blend backward's block -> tile map (longest walks first within each XCD)
+    uint64_t o_tile_order; // u32[8 * order_cap]: the blend kernels' block -> (tile, part) map (w3d_render.hip tile_schedule_kernel)
     uint64_t state_bytes;
     // ---- scratch buffer (forward temporaries)
     uint64_t s_keys0, s_keys1, s_vals0, s_vals1; // u32[P] each (depth keys, Gaussian ids)
@@ -70,9 +70,15 @@ struct W3DLayout {
     uint64_t s_part;       // u32[SEGS*T]
     uint64_t s_rec, s_rec_mask; // uint4[P], uint2[P]: depth-ordered {id, rect} records and tile masks
     uint64_t scratch_bytes;
+    uint32_t order_cap;    // block -> tile map: entries per XCD
     uint32_t sort_waves;   // waves used by the radix passes
     uint32_t sort_items;   // keys per wave per pass (multiple of 64)
 };
+
+// entries per XCD of the blend kernels' block -> (tile, part) map: frames of up to W3D_SCHED_MAX_TILES tiles get 1.5x their share of the
+// tiles (work-balanced XCD ranges are uneven in tile count, and long tiles are cut into 2 or 4 part-waves); larger frames the share
+#define W3D_SCHED_MAX_TILES 8192u
+static inline uint32_t w3d_order_cap(uint32_t T) { return T <= W3D_SCHED_MAX_TILES ? (T + T / 2u + 7u) / 8u + 1u : (T + 7u) / 8u; }
 
 static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L) {
     if (P < 0 || H <= 0 || W <= 0) return W3D_ERR_INVALID;
@@ -102,7 +108,8 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->o_final_T = o;    o += w3d_align_up(HW * 4);
     L->o_n_contrib = o;  o += w3d_align_up(HW * 4);
     L->o_tile_walk = o;  o += w3d_align_up(T * 4);
-    L->o_tile_order = o; o += w3d_align_up((T + 7) / 8 * 8 * 4);
+    L->order_cap = w3d_order_cap((uint32_t)T);
+    L->o_tile_order = o; o += w3d_align_up((uint64_t)8 * L->order_cap * 4);
     L->state_bytes = o;
     // depth sort geometry: one wave per contiguous run of sort_items keys
     const uint64_t max_runs = 1024;              // one wave per SIMD (measured at P = 2 M: 512 runs 0.216 ms, 1024 0.161, 2048 0.177, 4096 0.214)

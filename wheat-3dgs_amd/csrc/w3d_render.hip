@@ -105,17 +105,26 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return v;
 }
 
-// wave index -> tile index, keeping each XCD's tiles contiguous (blocks are dealt round-robin
-// over the 8 XCDs; speed only, never correctness).
-__device__ __forceinline__ uint32_t wave_to_tile(uint32_t T, uint32_t &tile, const uint32_t *__restrict__ order = nullptr) {
-    const uint32_t nblocks = gridDim.x;
+// wave -> (tile, part of the tile).  Without a schedule: tile = wave index with each XCD's tiles contiguous (blocks are dealt round-robin
+// over the 8 XCDs; speed only, never correctness), the whole tile.  With one (tile_schedule_kernel): block b runs entry
+// order[(b % 8) * cap + b / 8] = tile | part << 29, 0xFFFFFFFF = nothing.  part: 0 the whole tile, 1 / 2 its upper / lower two
+// 8x8 quadrants, 3..6 one quadrant — `qmask` is the set of quadrants (bit k = quadrant k) this wave owns.
+__device__ __forceinline__ uint32_t wave_to_tile(uint32_t T, uint32_t &tile, uint32_t &qmask, const uint32_t *__restrict__ order = nullptr,
+                                                 uint32_t cap = 0) {
     const uint32_t b = blockIdx.x;
-    const uint32_t per_xcd = (nblocks + 7) / 8;
+    qmask = 0xFu;
+    if (order) {
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)order[(b & 7u) * cap + (b >> 3)]);
+        if (e == 0xFFFFFFFFu) return 0u;
+        tile = e & 0x1FFFFFFFu;
+        const uint32_t part = e >> 29;
+        qmask = part == 0u ? 0xFu : part == 1u ? 0x3u : part == 2u ? 0xCu : (1u << (part - 3u));
+        return tile < T;
+    }
+    const uint32_t per_xcd = (gridDim.x + 7) / 8;
     const uint32_t logical_block = (b & 7u) * per_xcd + (b >> 3);
     // (an SGPR: the per-tile loads become scalar loads and every loop bound derived from them stays scalar)
     tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(logical_block * W3D_RW + (threadIdx.x >> 6)));
-    // `order` (blend backward): a permutation of each XCD's own tile range, longest walks first (tile_order_kernel)
-    if (order) tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)order[tile]);
     return tile < T;
 }
 
@@ -216,14 +225,14 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                   const float *__restrict__ gt_mask, int num_obj, int P, float *__restrict__ used_count,
                   int32_t *__restrict__ contrib_num, uint32_t list_cap, uint32_t *__restrict__ counters,
-                  uint32_t *__restrict__ tile_walk, const uint32_t *__restrict__ tile_order, uint32_t *__restrict__ walk_hint,
-                  uint32_t lshift, uint32_t lgx) {
+                  uint32_t *__restrict__ tile_walk, const uint32_t *__restrict__ tile_order, uint32_t order_cap,
+                  uint32_t *__restrict__ walk_hint, uint32_t lshift, uint32_t lgx) {
     __shared__ StagedLDS lds[W3D_RW];
     __shared__ int s_labels[W3D_RW][FLASH ? 256 : 1];
     // FlashSplat: row sums of the per-entry, per-label weights of the current batch: [label slot][entry][16-lane row]
     __shared__ __align__(16) float s_facc[W3D_RW][FLASH ? W3D_FLASH_LABELS * 64 * 4 : 4];
-    uint32_t tile;
-    if (!wave_to_tile(T, tile, tile_order)) return;
+    uint32_t tile, qmask;
+    if (!wave_to_tile(T, tile, qmask, tile_order, order_cap)) return;
     // the list buffer may be smaller than the lists (speculative sizing, see w3d_forward_stage2): never read
     // past it; the capacity is published for the backward pass
     if (tile == 0 && (threadIdx.x & 63) == 0) counters[3] = list_cap;
@@ -245,7 +254,7 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     for (int k = 0; k < 4; k++) {
         const uint32_t px = tx0 + (k & 1) * 8 + lx, py = ty0 + (k >> 1) * 8 + ly;
         pxf[k] = (float)px; pyf[k] = (float)py;
-        inside[k] = (px < (uint32_t)W) && (py < (uint32_t)H);
+        inside[k] = (px < (uint32_t)W) && (py < (uint32_t)H) && ((qmask >> k) & 1u);       // (a part-wave owns some quadrants only)
         hi[k] = inside[k] ? 0.f : -INFINITY;
         Tr[k] = 1.f; C0[k] = C1[k] = C2[k] = D[k] = A[k] = 0.f;
         last[k] = 0; napplied[k] = 0;
@@ -398,9 +407,12 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     {
         // how far into its list this tile blended anything: the length of the backward's reverse walk (its work)
         const uint32_t m = wave_max_u32(max(max(last[0], last[1]), max(last[2], last[3])));
+        // (the part-waves of a split tile each report their own quadrants: the tile's length is the maximum — tile_walk is zeroed by
+        //  the tile scan of this forward; the per-camera hint for the NEXT render of this view is not, and takes whichever part's
+        //  length is stored last: a lower bound of the tile's, good enough for a hint)
         if (lane == 0) {
-            tile_walk[tile] = m;
-            if (walk_hint) walk_hint[tile] = m;      // (the caller's per-camera hint for the NEXT render of this view)
+            if (qmask == 0xFu) tile_walk[tile] = m; else atomicMax(&tile_walk[tile], m);
+            if (walk_hint) walk_hint[tile] = m;
         }
     }
 #pragma unroll
@@ -471,15 +483,15 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
                   const float *__restrict__ dL_dcolor, const float *__restrict__ dL_ddepth,
                   const float *__restrict__ dL_dalpha_px, float *__restrict__ grad2d,
                   const uint32_t *__restrict__ counters, float *__restrict__ inst, uint32_t inst_cap,
-                  const uint32_t *__restrict__ tile_order, uint32_t lshift, uint32_t lgx) {
+                  const uint32_t *__restrict__ tile_order, uint32_t order_cap, uint32_t lshift, uint32_t lgx) {
     constexpr int NV = HAS_DA ? 10 : 9;
     __shared__ StagedLDS lds[W3D_RW];
     // row sums of the current half batch: acc[value][entry * 4 + row].  Every (entry, row) slot is written exactly once
     // per half batch by that row's leader lane — plain stores, no LDS atomics (measured on gfx950: a ds_add_f32 of four lanes
     // on one address occupies the CU's LDS for ~15 cycles, nine of them per entry cost more than the entry's arithmetic)
     __shared__ __align__(16) float acc_all[W3D_RW][NV * W3D_ACC_PITCH];
-    uint32_t tile;
-    if (!wave_to_tile(T, tile, tile_order)) return;
+    uint32_t tile, qmask;
+    if (!wave_to_tile(T, tile, qmask, tile_order, order_cap)) return;
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     StagedLDS &s = lds[wv];
     float *acc = acc_all[wv];
@@ -508,7 +520,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t px = tx0 + (k & 1) * 8 + lx, py = ty0 + (k >> 1) * 8 + ly;
-        const bool in = (px < (uint32_t)W) && (py < (uint32_t)H);
+        const bool in = (px < (uint32_t)W) && (py < (uint32_t)H) && ((qmask >> k) & 1u);    // (a part-wave walks for its own quadrants only)
         const size_t pix = (size_t)py * W + px;
         Tfin[k] = in ? final_T[pix] : 0.f;
         Tr[k] = Tfin[k];
@@ -576,7 +588,7 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
         // and skips entries without any quadrant on a scalar bit scan
         uint32_t myq = 0u;
         if (lane < n && tile_in_rect(nxt.a.z, nxt.a.w, tx0 / W3D_TILE, ty0 / W3D_TILE)) {
-            myq = quadrant_mask(nxt.a.x, nxt.a.y, nxt.b.x, nxt.b.y, nxt.b.z, pmin, (float)tx0, (float)ty0);
+            myq = quadrant_mask(nxt.a.x, nxt.a.y, nxt.b.x, nxt.b.y, nxt.b.z, pmin, (float)tx0, (float)ty0) & qmask;
         }
         const uint64_t todo_all = w3d_ballot(myq != 0u);
 #ifdef W3D_BWD_STATS
@@ -875,6 +887,191 @@ tile_order_kernel(const uint32_t *__restrict__ tile_walk, uint32_t T, uint32_t p
     if (i < per_xcd) order[t0 + base_s[wv][q] + rank] = t0 + i;
 }
 
+// The block -> (tile, part) schedule of a blend kernel for frames of up to W3D_SCHED_MAX_TILES tiles (one workgroup; the kernel above
+// serves larger frames).  The one-wave-per-tile schedule loses twice (profiles/r06/walk_schedule.jsonl: makespan over the perfectly
+// divisible bound 1.08-1.34 on the translucent scenes, 1.5-2.3 on the opaque one):
+//   * every XCD gets the same NUMBER of tiles, not the same work: here the 8 contiguous tile ranges are cut at equal cumulated cost
+//     (cost of a tile = its walk length + W3D_SCHED_C0 for the wave's fixed part), so they differ in tile count — the grid has
+//     `cap` = 1.5x the even share of blocks per XCD and the blocks past a range's entries exit at once;
+//   * a tile whose wave alone takes longer than the whole chip needs per wave slot (cost > total / slots) finishes last whatever
+//     the order: such a tile is cut into two waves (upper / lower pair of 8x8 quadrants, each ~0.6 of the cost: the staging is paid
+//     twice) or, beyond 2.2x, four (one quadrant each, ~0.35).  Part-waves add into the same Gaussian records (atomic backward
+//     only: allow_split = 0 for the deterministic one) and write disjoint pixels.
+// Inside a range: longest entry first (counting sort by a 6-bit quantised cost).  If a range would need more than `cap` entries
+// (a pathological cost profile) the even ranges without splitting are used.
+#define W3D_SCHED_C0 16u
+#ifndef W3D_SPLIT_X10
+#define W3D_SPLIT_X10 15u      // a tile is cut in two when its cost exceeds this / 10 x (total cost / wave slots), in four beyond 2.2x that
+#endif
+// cost of a tile's wave, its part code (0 whole, 1 two halves, 3 four quadrants) and the cost of one of its entries
+__device__ __forceinline__ uint32_t sched_cost(uint32_t walk) { return walk ? walk + W3D_SCHED_C0 : 2u; }
+__device__ __forceinline__ uint32_t sched_code(uint32_t c, uint32_t bound, int allow_split, uint32_t &ce) {
+    ce = c;
+    if (!allow_split || 10u * c <= W3D_SPLIT_X10 * bound) return 0u;
+    if (100u * c > 22u * W3D_SPLIT_X10 * bound) { ce = (35u * c) / 100u; return 3u; }
+    ce = (6u * c) / 10u;
+    return 1u;
+}
+// Eight workgroups, one per range.  Every one of them reads ALL walk lengths (30 KB) and scans cost and entry count in tile order —
+// so that all eight agree on the cuts and on whether the balanced ranges fit `cap` — then orders the entries of its own range.
+__global__ void __launch_bounds__(1024)
+tile_schedule_kernel(const uint32_t *__restrict__ walk, uint32_t T, uint32_t cap, uint32_t slots, int allow_split,
+                     uint32_t *__restrict__ order) {
+    constexpr uint32_t PER = W3D_SCHED_MAX_TILES / 1024u;
+    __shared__ uint32_t wave_c[16], wave_e[16], last_x[1025];
+    __shared__ uint32_t cut_t[9], cut_e[9];          // first tile of range k and the entries in front of it (k = 8: T, all entries)
+    __shared__ uint32_t cnt[64], base[64], s_cmax[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, x = blockIdx.x;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t w[PER];
+    {
+        const uint4 *w4 = reinterpret_cast<const uint4 *>(walk);
+        const uint32_t t0 = tid * PER;
+        if (t0 + PER <= T) {
+            const uint4 a = w4[2 * tid], b4 = w4[2 * tid + 1];
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b4.x; w[5] = b4.y; w[6] = b4.z; w[7] = b4.w;
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < PER; i++) w[i] = t0 + i < T ? walk[t0 + i] : 0u;
+        }
+    }
+    if (tid < 9) { cut_t[tid] = T; cut_e[tid] = 0u; }
+    // ---- pass 1: total cost -> the bound a single wave should stay under -> part codes
+    uint32_t c[PER], csum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < PER; i++) { const uint32_t t = tid * PER + i; c[i] = t < T ? sched_cost(w[i]) : 0u; csum += c[i]; }
+    uint32_t cinc = csum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)cinc, off, 64); if ((int)lane >= off) cinc += u; }
+    if (lane == 63) wave_c[wv] = cinc;
+    __syncthreads();
+    uint32_t cpre = cinc - csum, Wtot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) { const uint32_t v = wave_c[k]; cpre += k < wv ? v : 0u; Wtot += v; }
+    const uint32_t bound = max(Wtot / max(slots, 1u), 1u);
+    const float range_scale = 8.0f / (float)max(Wtot, 1u);
+    // ---- pass 2: entries in tile order, range of every tile (monotone in the cumulated cost), the cuts
+    uint32_t esum = 0, xl = 0, run = cpre;
+    uint32_t xr[PER], ne[PER];
+#pragma unroll
+    for (uint32_t i = 0; i < PER; i++) {
+        const uint32_t t = tid * PER + i;
+        uint32_t ce;
+        const uint32_t code = sched_code(c[i], bound, allow_split, ce);
+        ne[i] = t < T ? (code == 0u ? 1u : (code == 1u ? 2u : 4u)) : 0u;
+        esum += ne[i];
+        xr[i] = min(7u, (uint32_t)((float)(run + c[i] / 2u) * range_scale));
+        run += c[i];
+        if (t < T) xl = xr[i];
+    }
+    uint32_t einc = esum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)einc, off, 64); if ((int)lane >= off) einc += u; }
+    if (lane == 63) wave_e[wv] = einc;
+    last_x[tid + 1] = xl;               // (threads behind the last tile repeat the last range)
+    if (tid == 0) last_x[0] = 0u;
+    __syncthreads();
+    uint32_t epre = einc - esum, Etot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) { const uint32_t v = wave_e[k]; epre += k < wv ? v : 0u; Etot += v; }
+    {
+        uint32_t prev = last_x[tid], er = epre;
+#pragma unroll
+        for (uint32_t i = 0; i < PER; i++) {
+            const uint32_t t = tid * PER + i;
+            if (t < T) {
+                for (uint32_t k = prev + 1u; k <= xr[i]; k++) { cut_t[k] = t; cut_e[k] = er; }     // ranges (prev, xr] start at this tile
+                prev = xr[i];
+            }
+            er += ne[i];
+        }
+        if (tid == 0) { cut_t[0] = 0u; cut_e[0] = 0u; cut_e[8] = Etot; }
+    }
+    __syncthreads();
+    // (a range nobody starts keeps cut_t = T: empty — and every later one as well, since the ranges are monotone; its cut_e must
+    //  then be the total)
+    bool bad = false;
+    uint32_t my_s, my_e, my_n;
+    {
+        uint32_t ct[9], cee[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { ct[k] = cut_t[k]; cee[k] = cut_t[k] >= T ? Etot : cut_e[k]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) bad = bad || (cee[k + 1] - cee[k]) > cap;
+        my_s = ct[0]; my_e = ct[1]; my_n = cee[1] - cee[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) if (x == (uint32_t)k) { my_s = ct[k]; my_e = ct[k + 1]; my_n = cee[k + 1] - cee[k]; }
+    }
+    int split = allow_split;
+    if (bad) {                      // (the same decision in all eight workgroups) -> even ranges, whole tiles
+        const uint32_t even = (T + 7u) / 8u;
+        my_s = min(T, x * even); my_e = min(T, my_s + even); my_n = my_e - my_s;
+        split = 0;
+    }
+    // ---- pass 3: this range's entries, longest first
+    if (tid < 64) cnt[tid] = 0u;
+    uint32_t cm = 1u;
+    for (uint32_t t = my_s + tid; t < my_e; t += 1024u) { uint32_t ce; sched_code(sched_cost(walk[t]), bound, split, ce); cm = max(cm, ce); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cm = max(cm, (uint32_t)__shfl_xor((int)cm, off, 64));
+    if (lane == 0) s_cmax[wv] = cm;
+    __syncthreads();
+    uint32_t cmax = 1u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) cmax = max(cmax, s_cmax[k]);
+    const float q_scale = 64.0f / (float)(cmax + 1u);
+    // (at most two rounds: a range holds at most cap <= 1.5 x 1024 + 1 entries)  The entries of one bucket among the 64 tiles of a
+    // wave's round are found by ballots and ONE lane adds their number: neighbouring tiles mostly share a bucket, and 64 LDS atomics
+    // on one address serialise.
+    constexpr int ROUNDS = 2;
+    uint32_t rq[ROUNDS], rcode[ROUNDS], rbefore[ROUNDS], rtot[ROUNDS];
+    uint64_t rgrp[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const uint32_t t = my_s + (uint32_t)r * 1024u + tid;
+        const bool valid = t < my_e;
+        uint32_t ce = 0u;
+        rcode[r] = valid ? sched_code(sched_cost(walk[t]), bound, split, ce) : 0u;
+        rq[r] = 63u - min(63u, (uint32_t)((float)ce * q_scale));                 // bucket 0 = longest
+        uint64_t peers = w3d_ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            const uint64_t m = w3d_ballot((rq[r] >> b) & 1u);
+            peers &= ((rq[r] >> b) & 1u) ? m : ~m;
+        }
+        const uint64_t m2 = w3d_ballot(rcode[r] == 1u), m4 = w3d_ballot(rcode[r] == 3u);
+        auto entries = [&](uint64_t set) -> uint32_t { return (uint32_t)__popcll(set) + (uint32_t)__popcll(set & m2) + 3u * (uint32_t)__popcll(set & m4); };
+        rgrp[r] = valid ? peers : 0ull;
+        rbefore[r] = entries(peers & lt);
+        rtot[r] = entries(peers);
+        if (valid && (peers & lt) == 0ull) atomicAdd(&cnt[rq[r]], rtot[r]);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const uint32_t v = cnt[lane];
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)inc, off, 64); if ((int)lane >= off) inc += u; }
+        base[lane] = inc - v;
+        cnt[lane] = 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const uint32_t t = my_s + (uint32_t)r * 1024u + tid;
+        const uint64_t peers = rgrp[r];
+        uint32_t old = 0u;
+        if (peers && (peers & lt) == 0ull) old = atomicAdd(&cnt[rq[r]], rtot[r]);       // the group's leader claims its entries
+        old = (uint32_t)__shfl((int)old, peers ? (int)__builtin_ctzll(peers) : 0, 64);
+        if (peers) {
+            const uint32_t n = rcode[r] == 0u ? 1u : (rcode[r] == 1u ? 2u : 4u);
+            const uint32_t pos = base[rq[r]] + old + rbefore[r];
+            for (uint32_t e = 0; e < n; e++) order[x * cap + pos + e] = t | ((rcode[r] + e) << 29);
+        }
+    }
+    for (uint32_t j = my_n + tid; j < cap; j += 1024u) order[x * cap + j] = 0xFFFFFFFFu;
+}
+
 __global__ void copy_pixel_state_kernel(const float *__restrict__ fT, const uint32_t *__restrict__ nc, size_t n,
                                         float *__restrict__ fT_out, uint32_t *__restrict__ nc_out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -897,10 +1094,17 @@ int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const 
     // The forward does not know its walk lengths yet (list lengths are no stand-in: measured, no gain — most walks stop
     // early); a caller that renders the same camera repeatedly hands in the lengths of its previous render (w3d.h)
     uint32_t *order = nullptr;
+    const uint32_t cap = L.order_cap;
 #if W3D_TILE_ORDER
     if (W3D_RW == 1 && v.tile_walk_hint) {
         order = reinterpret_cast<uint32_t *>(state + L.o_tile_order);
-        hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, stream, (const uint32_t *)v.tile_walk_hint, T, blocks / 8, order);
+        // (slots: 1024 SIMDs x the waves per SIMD the kernel is compiled for)
+        if (T <= W3D_SCHED_MAX_TILES)
+            hipLaunchKernelGGL(tile_schedule_kernel, dim3(8), dim3(1024), 0, stream, (const uint32_t *)v.tile_walk_hint, T, cap,
+                               1024u * (flash ? 4u : (uint32_t)W3D_FWD_OCC), 1, order);
+        else
+            hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, stream, (const uint32_t *)v.tile_walk_hint, T, cap, order);
+        blocks = 8 * cap;
     }
 #endif
 #define ARGS                                                                                                          \
@@ -908,7 +1112,7 @@ int w3d_launch_render(const W3DLayout &L, const w3d_view &v, char *state, const 
         reinterpret_cast<const float4 *>(state + L.o_grec), v.bg, out_color, out_depth, out_alpha,                    \
         reinterpret_cast<float *>(state + L.o_final_T), reinterpret_cast<uint32_t *>(state + L.o_n_contrib), gt_mask, \
         num_obj, L.P, used_count, contrib_num, (uint32_t)(list_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : list_capacity),      \
-        reinterpret_cast<uint32_t *>(state + L.o_counters), reinterpret_cast<uint32_t *>(state + L.o_tile_walk), order,        \
+        reinterpret_cast<uint32_t *>(state + L.o_counters), reinterpret_cast<uint32_t *>(state + L.o_tile_walk), order, cap,   \
         v.tile_walk_hint, (uint32_t)L.lsx | ((uint32_t)L.lsy << 4), (uint32_t)L.lgx
     {
         W3D_PROF("render_fwd", stream);
@@ -928,13 +1132,20 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
     uint32_t blocks = (T + W3D_RW - 1) / W3D_RW;
     blocks = (blocks + 7) / 8 * 8;
     const bool det = v.deterministic != 0;
-    // block -> tile map: longest reverse walks first within every XCD's range (tile_order_kernel)
+    // block -> (tile, part) map from the walk lengths the forward of this view measured (tile_schedule_kernel)
     uint32_t *order = nullptr;
+    const uint32_t cap = L.order_cap;
 #if W3D_TILE_ORDER
     if (W3D_RW == 1) {
         order = reinterpret_cast<uint32_t *>(const_cast<char *>(state) + L.o_tile_order);
-        hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, stream,
-                           reinterpret_cast<const uint32_t *>(state + L.o_tile_walk), T, blocks / 8, order);
+        uint32_t *walk = reinterpret_cast<uint32_t *>(const_cast<char *>(state) + L.o_tile_walk);
+        const bool da_ = dL_ddepth || dL_dalpha;
+        if (T <= W3D_SCHED_MAX_TILES)
+            hipLaunchKernelGGL(tile_schedule_kernel, dim3(8), dim3(1024), 0, stream, (const uint32_t *)walk, T, cap,
+                               1024u * (da_ ? 3u : (uint32_t)W3D_BWD_OCC), det ? 0 : 1, order);
+        else
+            hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, stream, (const uint32_t *)walk, T, cap, order);
+        blocks = 8 * cap;
     }
 #endif
     // deterministic mode: [P records][det_list_capacity slots] in the scratch buffer (w3d_backward_det_sizes)
@@ -958,7 +1169,7 @@ int w3d_launch_render_backward(const W3DLayout &L, const w3d_view &v, const char
     T, (uint32_t)L.gx, L.W, L.H, reinterpret_cast<const uint32_t *>(state + L.o_tile_start), point_list,          \
         reinterpret_cast<const float4 *>(state + L.o_grec), v.bg,                                                 \
         reinterpret_cast<const float *>(state + L.o_final_T), reinterpret_cast<const uint32_t *>(state + L.o_n_contrib), \
-        dL_dcolor, dL_ddepth, dL_dalpha, grad2d, reinterpret_cast<const uint32_t *>(state + L.o_counters), inst, inst_cap, order, \
+        dL_dcolor, dL_ddepth, dL_dalpha, grad2d, reinterpret_cast<const uint32_t *>(state + L.o_counters), inst, inst_cap, order, cap, \
         (uint32_t)L.lsx | ((uint32_t)L.lsy << 4), (uint32_t)L.lgx
     {
         W3D_PROF("render_bwd", stream);
