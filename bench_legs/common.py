@@ -94,12 +94,14 @@ def _newest(pattern):
 # kernels of every stage of the step (names as rocprofv3 prints them, template arguments included where they matter)
 STAGE_KERNELS = {
     "preprocess_fwd": ("preprocess_fwd_kernel",),
-    "depth_sort": ("radix_hist_kernel", "radix_rowscan_kernel", "radix_scatter_kernel", "onesweep_", "depth_"),
+    "depth_sort": ("depth_bucket_",),
     "tile_count_scan": ("chunk_walk_kernel<0", "seg_sum_kernel", "tile_scan_kernel", "chunk_off_kernel", "tile_count_", "band_"),
     "fill_lists": ("chunk_walk_kernel<1", "fill_"),
-    "render_fwd": ("render_fwd_kernel", "tile_order_kernel"),
-    "loss": ("ssim_pass_a", "ssim_pass_b", "loss_finalize"),
+    "render_fwd": ("render_fwd_kernel",),
+    "loss": ("ssim_pass_a", "ssim_pass_b"),
     "render_bwd": ("render_bwd_kernel", "zero_visible_records_kernel", "det_gather_kernel"),
+    # (the blend kernels' block -> (tile, part) schedule: launched in front of both, outside their event brackets)
+    "tile_schedule": ("tile_schedule_kernel", "tile_order_kernel"),
     "preprocess_bwd": ("preprocess_bwd_kernel",),
 }
 
@@ -175,8 +177,8 @@ def kernel_bytes(P, V, R, Rw, HW, fused_adam):
         # parameters read; packed per-visible records written.  In Morton order the culled Gaussians come in runs and their
         # 180-B SH rows are not requested at all: 56 B of geometry for everyone, the SH rows of the visible
         "preprocess_fwd": (56.0 * P + 180.0 * V + 64.0 * V) if SPATIAL_ORDER else (236.0 * P + 64.0 * V),
-        # first pass reads P (key, id) pairs, the others V; the last writes 24-B records from a 16-B rect/mask gather
-        "depth_sort": 8.0 * P + 8.0 * V + 2 * 16.0 * V + (8.0 + 16.0 + 24.0) * V,
+        # P keys read twice (histogram, split), V (key, id) pairs written and read once, 24-B records written from a 16-B rect/mask gather
+        "depth_sort": 2 * 4.0 * P + 2 * 8.0 * V + (16.0 + 24.0) * V,
         "tile_count_scan": 24.0 * V,                           # the records, once
         "fill_lists": 24.0 * V + 4.0 * R,                      # the records once + the lists
         "render_fwd": 48.0 * Rw + 36.0 * HW,                   # 4-B id + 44-B gather per walked instance; image + aux

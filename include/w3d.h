@@ -119,7 +119,7 @@ typedef struct w3d_view {
 
 /* Version of this ABI: major * 100 + minor.  The major number changes whenever a struct of this header changes its layout or
  * an entry point its signature; a binding must refuse a library whose major number differs from the header it mirrors. */
-#define W3D_ABI_VERSION 302
+#define W3D_ABI_VERSION 303
 int w3d_version(void);
 const char *w3d_last_error(void);
 
@@ -313,6 +313,11 @@ int w3d_rows_adam(int32_t P, int32_t n_views, int32_t sh_degree, const float *ca
                   w3d_stream_t stream);
 
 /* mean squared distance to the 3 nearest other points; points (N,3) -> out (N,) */
+/* View-parallel bookkeeping between two densifications (per rank; reduced over the ranks when a densification or a checkpoint
+ * reads them): vis_count[g] += radii[g] > 0, radii_max[g] = max(radii_max[g], radii[g]) — the per-view halves of reference
+ * train_vanilla_3dgs.py:102 (max_radii2D) and scene/gaussian_model.py:463 (denom), all int32 (P,). */
+int w3d_track_visibility(int32_t P, const int32_t *radii, int32_t *vis_count, int32_t *radii_max, w3d_stream_t stream);
+
 int w3d_knn_dist2(int32_t N, const float *points, float *out, w3d_stream_t stream);
 /* The same result (bit for bit) through a uniform grid built on the device: O(N) instead of O(N^2) for the million-point
  * initialisations of the 2 M-Gaussian configurations.  scratch: w3d_knn_sizes(N) bytes. */

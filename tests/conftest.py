@@ -13,6 +13,8 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     import _poison                      # W3D_TEST_FILL=zeros|ff|nan|small|rand|unit: patterned torch.empty (tests/_poison.py)
     _poison.install_from_env()
+    import cpu_twins                    # torch stand-ins for the HIP-backed operations: the product has no CPU path (tests/cpu_twins.py)
+    cpu_twins.install()
 
 
 def pytest_collection_modifyitems(config, items):

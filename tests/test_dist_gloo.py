@@ -29,9 +29,11 @@ def _free_port():
 
 
 def _model(P=64):
-    for p in (ROOT, os.path.join(ROOT, "wheat-3dgs_amd")):
+    for p in (ROOT, os.path.join(ROOT, "wheat-3dgs_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
+    import cpu_twins                    # (spawned workers do not run conftest.py: the torch stand-ins of the kernels, tests/cpu_twins.py)
+    cpu_twins.install()
     from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
     from w3d_amd.synth import make_scene
     sc = make_scene(P, seed=0, scale_mean=0.05)

@@ -248,6 +248,8 @@ SIDE_BY_SIDE = textwrap.dedent('''
     sys.path[:0] = [REF, PKG, ROOT, os.path.join(ROOT, "tests")]
     import w3d_amd.dropin as d
     d.install()
+    import cpu_twins                # (our class on CPU tensors: the torch stand-ins of its kernels, tests/cpu_twins.py)
+    cpu_twins.install()
     G = imp("scene.gaussian_model")
     A = imp("arguments")
     from argparse import ArgumentParser

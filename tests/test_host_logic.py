@@ -657,3 +657,40 @@ def test_spatial_order_moves_every_per_gaussian_array_together(monkeypatch):
     assert torch.equal(u._p["xyz"].detach(), sc.xyz) and u.spatial_order_every == 0
     v = fresh(0)                                         # the default is on
     assert Trainer(v, [0, 1, 2], OptimizationParams(), torch.zeros(3), densify=True, fused=False).initial_perm is not None
+
+
+def test_product_has_no_cpu_path():
+    """Without tests/cpu_twins.py (a fresh interpreter: conftest.py has registered the stand-ins in this one) every HIP-backed
+    operation of the host classes refuses CPU tensors — Adam, the photometric loss, the densification statistics, the compaction —
+    like the rasterizer itself does: nothing in the product computes on the CPU."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path[:0] = [%r, %r]
+import torch
+from w3d_amd import _host_twins
+assert not _host_twins._TWINS
+from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+from w3d_amd.loss import photometric_loss
+from w3d_amd.synth import make_scene
+sc = make_scene(32, seed=0, scale_mean=0.05)
+m = GaussianModel(3, device="cpu")
+m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+m.training_setup(OptimizationParams())
+refused = []
+for name, call in (("adam", lambda: m.optimizer.step(respect_none_grads=False)),
+                   ("loss", lambda: photometric_loss(torch.rand(3, 16, 16), torch.rand(3, 16, 16))),
+                   ("stats", lambda: m.add_densification_stats(torch.rand(32, 3), torch.ones(32, dtype=torch.bool))),
+                   ("prune", lambda: m.prune_points(torch.arange(32) %% 2 == 0))):
+    try:
+        call()
+    except RuntimeError as e:
+        assert "no CPU path" in str(e), (name, e)
+        refused.append(name)
+print(",".join(refused))
+""" % (ROOT, os.path.join(ROOT, "wheat-3dgs_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip() == "adam,loss,stats,prune", r.stdout

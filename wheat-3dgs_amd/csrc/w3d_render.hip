@@ -128,11 +128,17 @@ __device__ __forceinline__ uint32_t wave_to_tile(uint32_t T, uint32_t &tile, uin
     return tile < T;
 }
 
-// tile -> list cell (w3d_view.list_share; lshift = lsx | lsy << 4, lgx = cells per row; lshift = 0: the tile itself)
-__device__ __forceinline__ uint32_t list_of_tile(uint32_t tile, uint32_t gx, uint32_t lshift, uint32_t lgx) {
-    if (lshift == 0u) return tile;
+// tile -> list cell (w3d_view.list_share).  The grid is the one the forward that wrote this state BUILT its lists on — counters[6] =
+// lsx | lsy << 8, left by the tile scan — not what the caller's view says now: a backward or a re-blend handed a different
+// list_share / deterministic flag than the forward would otherwise index tile_start on the wrong grid and silently return
+// garbage (the host-side values only size the launch).
+__device__ __forceinline__ uint32_t list_of_tile(uint32_t tile, uint32_t gx, const uint32_t *__restrict__ counters) {
+    const uint32_t code = counters[6];
+    if (code == 0u) return tile;
+    const uint32_t lsx = code & 0xFFu, lsy = (code >> 8) & 0xFFu;
+    const uint32_t lgx = (gx + (1u << lsx) - 1u) >> lsx;
     const uint32_t ty = tile / gx, tx = tile - ty * gx;
-    return (ty >> (lshift >> 4)) * lgx + (tx >> (lshift & 15u));
+    return (ty >> lsy) * lgx + (tx >> lsx);
 }
 
 struct StagedLDS {
@@ -291,7 +297,8 @@ render_fwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     }
     // the list this tile reads: its own, or (w3d_view.list_share) the one it shares with its neighbours in the list cell —
     // the entries that cannot touch THIS tile have an empty quadrant mask and are skipped on the scalar bit scan below
-    const uint32_t ltile = list_of_tile(tile, gx, lshift, lgx);
+    (void)lshift; (void)lgx;
+    const uint32_t ltile = list_of_tile(tile, gx, counters);
     const uint32_t start = min(tile_start[ltile], list_cap), end = min(tile_start[ltile + 1], list_cap);
     for (uint32_t base = start; base < end; base += 64) {
         if ((w3d_ballot(hi[0] == 0.f) | w3d_ballot(hi[1] == 0.f) | w3d_ballot(hi[2] == 0.f) | w3d_ballot(hi[3] == 0.f)) == 0ull) break;
@@ -540,7 +547,8 @@ render_bwd_kernel(uint32_t T, uint32_t gx, int W, int H, const uint32_t *__restr
     maxc = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(maxc));   // (an SGPR: everything derived from it stays scalar)
     if (maxc == 0) return;
     const uint32_t cap = counters[3];
-    const uint32_t start = min(tile_start[list_of_tile(tile, gx, lshift, lgx)], cap);     // (shared lists: see the forward)
+    (void)lshift; (void)lgx;
+    const uint32_t start = min(tile_start[list_of_tile(tile, gx, counters)], cap);     // (shared lists: see the forward)
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const bool has_bg = (bg0 != 0.f) || (bg1 != 0.f) || (bg2 != 0.f);     // wave-uniform: black background skips the term
     const int nb = (int)((maxc + 63) / 64);

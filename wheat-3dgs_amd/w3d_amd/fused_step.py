@@ -71,6 +71,8 @@ lib.w3d_index_gradient_rows.argtypes = [_i32, _i32, _vp, _vp, ctypes.c_uint32, _
 lib.w3d_index_gradient_rows.restype = ctypes.c_int
 lib.w3d_rows_norm_sum.argtypes = [_i32, _i32, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp]
 lib.w3d_rows_norm_sum.restype = ctypes.c_int
+lib.w3d_track_visibility.argtypes = [_i32, _vp, _vp, _vp, _vp]
+lib.w3d_track_visibility.restype = ctypes.c_int
 lib.w3d_rows_adam.argtypes = [_i32, _i32, _i32, _vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.POINTER(W3DRawGrads),
                               ctypes.POINTER(W3DAdamFused), _vp]
 lib.w3d_rows_adam.restype = ctypes.c_int
@@ -415,8 +417,8 @@ def backward_raw_rows(model, handle, dL_dimage, norm_scale=1.0):
 def sh_adam_lowrank(model, dcolor_all, campos_all, skip=(), rows=None):
     """Adam step of f_dc / f_rest from the colour gradients of ALL views of this iteration (dcolor_all (V,P,3), campos_all
     (V,3)): dL/dSH[k] = sum_v basis_k(normalize(xyz - campos_v)) * dcolor_v, summed in view order.  The optimizer's step
-    counter must already be advanced for this iteration.  GPU: csrc sh_adam_lowrank_kernel, in place; CPU (host-logic
-    tests): the same formula with torch ops through FlatAdam's CPU path."""
+    counter must already be advanced for this iteration.  csrc sh_adam_lowrank_kernel, in place (a model on the CPU is
+    refused: w3d_amd/_host_twins.py)."""
     opt = model.optimizer
     P, V = model.num_points, int(dcolor_all.shape[0])
     r0, r1 = (0, P) if rows is None else rows          # rows=(r0, r1): dcolor_all holds only these Gaussians
@@ -426,21 +428,8 @@ def sh_adam_lowrank(model, dcolor_all, campos_all, skip=(), rows=None):
     if model.max_sh_degree != 3:
         raise RuntimeError("the low-rank exchange is written for 16 SH coefficients")
     if not model.flat.is_cuda:
-        from .sh import sh_basis
-        if rows is not None:
-            raise RuntimeError("row chunks are a GPU-path feature")
-        xyz = model._p["xyz"].detach()
-        grad = torch.zeros(P, 16, 3, dtype=torch.float32)
-        for v in range(V):                                   # view order, as in the kernel
-            dirs = xyz - campos_all[v][None]
-            dirs = dirs / dirs.norm(dim=1, keepdim=True)
-            basis = sh_basis(deg, dirs)                      # (P, (deg+1)^2)
-            grad[:, :basis.shape[1]] += basis[:, :, None] * dcolor_all[v][:, None, :]
-        model.grad_view("f_dc").copy_(grad[:, :1])
-        model.grad_view("f_rest").copy_(grad[:, 1:])
-        # (the bucket was written directly just above: .grad is not consulted — after a densification every p.grad is None)
-        opt.step(only=SH_BLOCKS, skip=skip, advance=False, respect_none_grads=False)
-        return
+        from ._host_twins import twin
+        return twin("sh_adam_lowrank", "sh_adam_lowrank")(model, dcolor_all, campos_all, skip, rows)
     sl = model.block_slices()
     assert opt.steps["f_dc"] == opt.steps["f_rest"] or "f_dc" in skip or "f_rest" in skip
     bc1, bc2 = opt.bias_corrections("f_rest" if "f_dc" in skip else "f_dc")
@@ -470,20 +459,14 @@ def _geo_grads(model):
 def pack_gradient_rows(model, dcolor, grad2d_norm=None, norm_scale=1.0):
     """The non-zero rows of this view's gradient (include/w3d.h w3d_pack_gradient_rows): dcolor (P,3) and the geometry blocks
     of model.flat_grad as backward_raw_lowrank left them.  Returns (rows (P, 16) float32 of which the first `count` are
-    filled, count (1,) int32 on the device).  GPU: one kernel; CPU (host-logic tests): the same selection with torch ops."""
+    filled, count (1,) int32 on the device).  One kernel (a model on the CPU is refused: w3d_amd/_host_twins.py)."""
     P = model.num_points
     dev = model.flat.device
     rows = torch.empty(max(P, 1), ROW_FLOATS, dtype=torch.float32, device=dev)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
     if not model.flat.is_cuda:
-        gn = torch.zeros(P) if grad2d_norm is None else grad2d_norm.reshape(P).float() * norm_scale
-        full = torch.cat([gn[:, None], dcolor.reshape(P, 3)] + [model.grad_view(n).reshape(P, -1) for n in GEO_BLOCKS], 1)
-        idx = (full != 0).any(1).nonzero()[:, 0]
-        n = int(idx.numel())
-        rows[:n, 0] = idx.to(torch.int32).view(torch.float32)
-        rows[:n, 1:] = full[idx]
-        count[0] = n
-        return rows, count
+        from ._host_twins import twin
+        return twin("pack_gradient_rows", "pack_gradient_rows")(model, dcolor, grad2d_norm, norm_scale, rows, count)
     g = _geo_grads(model)
     with torch.cuda.device(dev):
         check(lib.w3d_pack_gradient_rows(P, ptr(dcolor.contiguous()), ctypes.byref(g), ptr(grad2d_norm), float(norm_scale),
@@ -497,18 +480,8 @@ def apply_gradient_rows(model, rows, count, max_rows, dcolor_view, norm_sum=None
     reads it, the host does not.  Call once per view in view order on zeroed buffers."""
     P = model.num_points
     if not model.flat.is_cuda:
-        n = min(int(count[0]), int(max_rows))
-        r = rows[:n]
-        idx = r[:, 0].contiguous().view(torch.int32).long()
-        if norm_sum is not None:
-            norm_sum[idx] += r[:, 1]
-        dcolor_view[idx] = r[:, 2:5]
-        col = 5
-        for name in GEO_BLOCKS:
-            blk = model.grad_view(name).view(P, -1)
-            blk[idx] += r[:, col:col + blk.shape[1]]
-            col += blk.shape[1]
-        return
+        from ._host_twins import twin
+        return twin("apply_gradient_rows", "apply_gradient_rows")(model, rows, count, max_rows, dcolor_view, norm_sum)
     dev = model.flat.device
     assert rows.is_contiguous() and dcolor_view.is_contiguous() and count.dtype == torch.int32
     g = _geo_grads(model)

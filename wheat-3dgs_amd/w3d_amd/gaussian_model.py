@@ -287,10 +287,14 @@ class GaussianModel:
             from .fused import add_densification_stats
             add_densification_stats(g, update_filter.reshape(-1).contiguous(), self.xyz_gradient_accum, self.denom)
             return
-        f = update_filter.reshape(-1, 1).to(self.xyz_gradient_accum.dtype)
-        norm = torch.norm(g[:, :2], dim=-1, keepdim=True)
-        self.xyz_gradient_accum += torch.where(update_filter.reshape(-1, 1), norm, torch.zeros_like(norm))
-        self.denom += f
+        if g.is_cuda and update_filter.is_cuda:
+            # (a strided / non-fp32 gradient on the device: the reference's own statement, as masked arithmetic)
+            norm = torch.norm(g[:, :2].float(), dim=-1, keepdim=True)
+            self.xyz_gradient_accum += torch.where(update_filter.reshape(-1, 1), norm, torch.zeros_like(norm))
+            self.denom += update_filter.reshape(-1, 1).to(self.denom.dtype)
+            return
+        from ._host_twins import twin
+        twin("add_densification_stats", "GaussianModel.add_densification_stats")(self, g, update_filter)
 
     def _bind_store(self, flat_store, flat_grad_store, P):
         """Adopt already-filled flat buffers (layout of _bind) without copying.  The new nn.Parameters start with
@@ -310,7 +314,7 @@ class GaussianModel:
         """The single resize path.  New row r = old row src[r]; rows >= n_keep are new points
         (zero Adam moments, reference cat_tensors_to_optimizer :356-374), rows >= n_child0 are split children whose
         xyz / scaling come from child_xyz / child_scaling.  Parameters and both moments move in ONE pass of
-        csrc/w3d_densify.hip on the GPU (torch index_select on the CPU, for the host-logic tests)."""
+        csrc/w3d_densify.hip (a model on the CPU is refused: w3d_amd/_host_twins.py)."""
         P_old, P_new = self.num_points, int(src.numel())
         n_child0 = P_new if n_child0 is None else int(n_child0)
         layout_old, layout_new = flat_layout(P_old)[0], flat_layout(P_new)[0]
@@ -357,23 +361,9 @@ class GaussianModel:
                             None if opt is None else opt.exp_avg, None if opt is None else opt.exp_avg_sq,
                             new_store, m_new, v_new, child_xyz, child_scaling)
         else:
-            src64 = src.to(torch.int64)
-            for name, d in zip(names, dims):
-                off_o, off_n = layout_old[name][0], layout_new[name][0]
-
-                def rows(buf):
-                    return buf[off_o:off_o + P_old * d].view(P_old, d).index_select(0, src64)
-                blk = rows(self.flat.detach())
-                if n_child0 < P_new and name == "xyz":
-                    blk[n_child0:] = child_xyz
-                if n_child0 < P_new and name == "scaling":
-                    blk[n_child0:] = child_scaling
-                new_store[off_n:off_n + P_new * d] = blk.reshape(-1)
-                if opt is not None:
-                    for old, new_ in ((opt.exp_avg, m_new), (opt.exp_avg_sq, v_new)):
-                        mb = rows(old)
-                        mb[n_keep:] = 0
-                        new_[off_n:off_n + P_new * d] = mb.reshape(-1)
+            from ._host_twins import twin
+            twin("densify_compact", "GaussianModel._compact")(self, names, dims, layout_old, layout_new, P_old, P_new, src, n_keep, n_child0,
+                                                              new_store, m_new, v_new, child_xyz, child_scaling)
         src64 = src.to(torch.int64)
         self._which_object = self._which_object.index_select(0, src64)
         stats = None if reset_stats else (self.xyz_gradient_accum.index_select(0, src64), self.denom.index_select(0, src64),

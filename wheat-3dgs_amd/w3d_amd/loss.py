@@ -1,11 +1,13 @@
 """Photometric loss of the training step: 0.8*L1 + 0.2*(1-SSIM) (reference
 train_vanilla_3dgs.py:77-79, utils/loss_utils.py:17-63; pinned by tests/golden/loss.npz).
 
-`l1_loss` / `ssim` / `psnr` restate the reference formulas with torch ops (host logic, CPU
-tests, and the parity check of the fused kernel).  `fused_l1_ssim` is the product path on the
-GPU: one hand-written HIP pass pair (csrc/w3d_loss.hip) that produces the scalar loss AND
-dL/dimage directly, replacing five grouped 11x11 convolutions forward plus their autograd
-backward.
+`photometric_loss` is the product path: one hand-written HIP pass pair (csrc/w3d_loss.hip) that produces the
+scalar loss AND dL/dimage directly, replacing five grouped 11x11 convolutions forward plus their autograd
+backward; it refuses CPU tensors.  `l1_loss` / `ssim` / `psnr` are the drop-in
+`utils.loss_utils` / `utils.image_utils` names: contiguous fp32 (3,H,W) images on the
+GPU go through the same kernels; any other input the reference's functions accept (4-D batches, other window sizes,
+half precision, `size_average=False`) is evaluated with the reference's own torch formulation, `ssim_torch` — the
+API contract of the module that is swapped in, and the formula the fused kernel is tested against.
 """
 import math
 import threading
@@ -147,7 +149,8 @@ class _FusedL1SSIM(torch.autograd.Function):
 
 
 def photometric_loss(image, gt, lambda_dssim=0.2):
-    """0.8*L1 + 0.2*(1-SSIM).  GPU: fused HIP kernel; CPU tensors: the torch restatement."""
+    """0.8*L1 + 0.2*(1-SSIM) through the fused HIP kernel pair.  CPU tensors are refused (w3d_amd/_host_twins.py)."""
     if image.is_cuda:
         return _FusedL1SSIM.apply(image, gt, lambda_dssim)
-    return photometric_loss_torch(image, gt, lambda_dssim)
+    from ._host_twins import twin
+    return twin("photometric_loss", "photometric_loss")(image, gt, lambda_dssim)

@@ -3,9 +3,8 @@
 Same update rule and hyper-parameters as the reference's optimizer — torch.optim.Adam with
 lr=0.0 default, eps=1e-15 and one lr per parameter group (scene/gaussian_model.py:172-182) —
 but the two moments live in flat buffers with the layout of GaussianModel.flat, so one sweep
-updates every block.  `step()` runs the hand-written HIP kernel (csrc/w3d_adam.hip) when the
-buffers are on the GPU; on the CPU (unit tests of the host logic) it uses the identical formula
-written with torch ops.
+updates every block.  `step()` runs the hand-written HIP kernel (csrc/w3d_adam.hip); buffers on
+the CPU are refused (w3d_amd/_host_twins.py: the host-logic tests register a torch stand-in).
 """
 import math
 
@@ -195,16 +194,6 @@ class FlatAdam:
                 bc1, bc2 = self.bias_corrections(name)
                 adam_step(p[a:b], g[a:b], m[a:b], v[a:b], self.lrs[name], b1, b2, self.eps, bc1, bc2, zero_grad)
             return
-        for name, (a, b, stepped) in slices.items():
-            gg = g[a:b]
-            if not stepped:
-                if zero_grad:
-                    gg.zero_()
-                continue
-            bc1, bc2 = self.bias_corrections(name)
-            m[a:b].mul_(b1).add_(gg, alpha=1 - b1)
-            v[a:b].mul_(b2).addcmul_(gg, gg, value=1 - b2)
-            denom = (v[a:b].sqrt() / math.sqrt(bc2)).add_(self.eps)
-            p[a:b].addcdiv_(m[a:b], denom, value=-self.lrs[name] / bc1)
-            if zero_grad:
-                gg.zero_()
+        # CPU tensors: no path of this package's own (w3d_amd/_host_twins.py)
+        from ._host_twins import twin
+        twin("adam_step", "FlatAdam.step")(self, p, g, m, v, slices, zero_grad)

@@ -49,9 +49,12 @@ SHARE_RHO = (0.30, 0.60)
 SHARE_HYST = 0.04
 
 
-def adapt_list_share(owner, handle, every=SHARE_PROBE_EVERY):
+def adapt_list_share(owner, handle, every=SHARE_PROBE_EVERY, combine=None):
     """Choose owner._list_share_chosen for the following renders from the walked fraction of this one (handle: a finished forward of
-    fused_step.render_raw).  A caller's explicit owner.list_share is left alone.  Returns the running rho (or None)."""
+    fused_step.render_raw).  A caller's explicit owner.list_share is left alone.  Returns the running rho (or None).
+    combine: rho -> rho, called on every probe — a view-parallel job passes the mean over its ranks (Trainer.adapt_list_share), so that
+    all ranks run the same mode: every rank probes its OWN camera, and per-rank choices made their timings, list lengths and buffer
+    capacities diverge."""
     if getattr(owner, "list_share", None) is not None:
         return None
     st = getattr(owner, "_list_share_state", None)
@@ -63,9 +66,12 @@ def adapt_list_share(owner, handle, every=SHARE_PROBE_EVERY):
     view = handle["view"]
     mode = int(view.c.list_share) if (view.c.tile_cull and not view.c.deterministic) else 0
     lists_read = float(handle["num_rendered"]) * (1, 2, 4)[mode]
-    if lists_read <= 0:
+    if lists_read <= 0 and combine is None:
         return st["rho"]
-    rho = float(view.tile_walk_hint.sum()) / lists_read               # (host-synchronous: 7 500 integers)
+    # (an upper estimate of the lists' total length as the tiles read them: clipped border cells and odd grid sizes read less)
+    rho = float(view.tile_walk_hint.sum()) / lists_read if lists_read > 0 else 1.0         # (host-synchronous: 7 500 integers)
+    if combine is not None:
+        rho = float(combine(rho))                        # (a collective: every rank reaches this line in the same call)
     r = st["rho"] = rho if st["rho"] is None else 0.5 * (st["rho"] + rho)
     (lo, hi), h = SHARE_RHO, SHARE_HYST
     want = 2 if r < lo else 1 if r < hi else 0
@@ -73,6 +79,11 @@ def adapt_list_share(owner, handle, every=SHARE_PROBE_EVERY):
         edge = lo if {want, mode} == {1, 2} else hi if {want, mode} == {0, 1} else None
         if edge is not None and abs(r - edge) < h:
             want = mode
+    if want != getattr(owner, "_list_share_chosen", None):
+        # (the list-capacity hints were learnt under the other grid: num_rendered differs up to 3x between the modes)
+        hints = getattr(owner, "_w3d_list_hints", None)
+        if hints:
+            hints.clear()
     owner._list_share_chosen = want
     return r
 

@@ -155,7 +155,14 @@ class Trainer:
         """Every SHARE_PROBE_EVERY fused steps (and on the first three): the walked fraction of the view just rendered decides the
         list_share of the following steps (rasterizer.adapt_list_share; kept on the model)."""
         from .rasterizer import adapt_list_share
-        rho = adapt_list_share(self.model, handle, every=self.SHARE_PROBE_EVERY)
+        combine = None
+        if self.world > 1:
+            # every rank probes in the same iterations (same call count): one scalar all-reduce per probe, the mean decides for all
+            def combine(rho):
+                t = torch.tensor([rho], dtype=torch.float64, device=self.model.flat.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                return float(t) / self.world
+        rho = adapt_list_share(self.model, handle, every=self.SHARE_PROBE_EVERY, combine=combine)
         if rho is not None:
             self.share_rho = rho
 
@@ -212,8 +219,14 @@ class Trainer:
         if getattr(self, "_vis_local", None) is None or self._vis_local.shape[0] != P or self._vis_local.device != visible.device:
             self._vis_local = torch.zeros(P, dtype=torch.int32, device=visible.device)
             self._rmax_local = torch.zeros(P, dtype=torch.int32, device=visible.device)
-        self._vis_local += visible.to(torch.int32)
-        torch.maximum(self._rmax_local, radii.to(torch.int32), out=self._rmax_local)
+        if radii.is_cuda and radii.dtype == torch.int32 and radii.is_contiguous():
+            from ._lib import check, ptr, stream_ptr
+            from .fused_step import lib             # (the module that declares the entry point's argument types)
+            with torch.cuda.device(radii.device):             # one launch instead of five torch kernels (`visible` IS radii > 0)
+                check(lib.w3d_track_visibility(P, ptr(radii), ptr(self._vis_local), ptr(self._rmax_local), stream_ptr(radii.device)))
+            return
+        from ._host_twins import twin
+        twin("track_visibility", "Trainer.track_local")(visible, radii, self._vis_local, self._rmax_local)
 
     def sync_stats(self):
         """Fold the locally tracked visibility counts and radii of all ranks into model.denom / model.max_radii2D (track_local).
@@ -629,11 +642,14 @@ class Trainer:
                 if self.world > 1 and gnorm is not None:
                     gnorm = gnorm * float(self.world)           # statistics use the unscaled per-view norm
                 stepped_early = False
-                if packed is not None:
-                    nsum, vcount, rmax = self.exchange_rows(None, None, vis, pkg["radii"], tracking=tracking, packed=packed)
-                elif lowrank:
-                    nsum, vcount, rmax = (self.exchange_rows if rows_form else self.exchange_lowrank)(
-                        dcol, gnorm, vis, pkg["radii"], tracking=tracking)
+                if packed is not None or lowrank:
+                    if packed is not None:
+                        nsum, vcount, rmax = self.exchange_rows(None, None, vis, pkg["radii"], tracking=tracking, packed=packed)
+                    else:
+                        nsum, vcount, rmax = (self.exchange_rows if rows_form else self.exchange_lowrank)(
+                            dcol, gnorm, vis, pkg["radii"], tracking=tracking)
+                    # (both forms: a too-dense rows step falls back to exchange_lowrank and leaves an asynchronous all-reduce on
+                    #  the gradient bucket, which a densification recycles — drain first)
                     if self._structure_change_due(iteration):
                         self._drain_lowrank()        # densification recycles the gradient bucket
                     elif iteration < opt.iterations:
