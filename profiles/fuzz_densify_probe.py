@@ -1,4 +1,4 @@
-"""Differential fuzzing of densify_and_prune (round 4): the same GaussianModel code on the CPU (torch gathers: the path pinned
+"""Differential fuzzing of densify_and_prune (round 4): the same GaussianModel code on the CPU (torch gathers: the stand-in pinned
 to the reference's own densify_and_prune by tests/golden/densify.npz) and on the GPU (csrc/w3d_densify.hip's one-pass
 compaction) with random parameters, moments, statistics (zero denominators included: the reference's NaN -> 0 rule), thresholds
 from "nothing is selected" to "everything is split / pruned", ragged P, with and without the screen-size test.  The split
@@ -12,6 +12,8 @@ for p in (ROOT, os.path.join(ROOT, "wheat-3dgs_amd"), os.path.join(ROOT, "tests"
 import numpy as np, torch
 from w3d_amd.synth import make_scene
 from w3d_amd.gaussian_model import GaussianModel, OptimizationParams
+import cpu_twins                 # the CPU side of this comparison is the torch stand-in of the compaction (tests/cpu_twins.py: the product
+cpu_twins.install()              # has no CPU path), pinned to the reference's own densify_and_prune by tests/golden/densify.npz
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
