@@ -119,7 +119,7 @@ typedef struct w3d_view {
 
 /* Version of this ABI: major * 100 + minor.  The major number changes whenever a struct of this header changes its layout or
  * an entry point its signature; a binding must refuse a library whose major number differs from the header it mirrors. */
-#define W3D_ABI_VERSION 303
+#define W3D_ABI_VERSION 304
 int w3d_version(void);
 const char *w3d_last_error(void);
 
@@ -308,6 +308,10 @@ int w3d_index_gradient_rows(int32_t P, int32_t n_views, const float *rows_all, c
                             uint32_t *viewmask, uint32_t *slots, w3d_stream_t stream);
 int w3d_rows_norm_sum(int32_t P, int32_t n_views, const float *rows_all, uint32_t cap_rows, const uint32_t *viewmask,
                       const uint32_t *slots, float *norm_sum, w3d_stream_t stream);
+/* ... and the same sum ADDED to accum[g] (P,) in one addition per Gaussian: xyz_gradient_accum += sum over the views of the rows'
+ * ||dL/dmean2D|| (reference scene/gaussian_model.py:462 once per view), without materialising the sum. */
+int w3d_rows_norm_accumulate(int32_t P, int32_t n_views, const float *rows_all, uint32_t cap_rows, const uint32_t *viewmask,
+                             const uint32_t *slots, float *accum, w3d_stream_t stream);
 int w3d_rows_adam(int32_t P, int32_t n_views, int32_t sh_degree, const float *campos_all, const float *rows_all, uint32_t cap_rows,
                   const uint32_t *viewmask, const uint32_t *slots, const w3d_raw_blocks *params, const w3d_adam_fused *adam,
                   w3d_stream_t stream);

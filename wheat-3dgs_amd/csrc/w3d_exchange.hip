@@ -107,7 +107,7 @@ index_rows_kernel(int P, const float4 *__restrict__ rows_all, const uint32_t *__
 // norm_sum[g] = sum over the views that hold a row of g, in view order, of the row's ||dL/dmean2D|| (0 where none does)
 __global__ void __launch_bounds__(256)
 rows_norm_sum_kernel(int P, const float4 *__restrict__ rows_all, uint32_t cap, const uint32_t *__restrict__ viewmask,
-                     const uint32_t *__restrict__ slots, float *__restrict__ norm_sum) {
+                     const uint32_t *__restrict__ slots, float *__restrict__ norm_sum, int accumulate) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= P) return;
     uint32_t mask = viewmask[g];
@@ -117,7 +117,9 @@ rows_norm_sum_kernel(int P, const float4 *__restrict__ rows_all, uint32_t cap, c
         mask &= mask - 1u;
         s += rows_all[4 * ((size_t)v * cap + slots[(size_t)v * P + g])].y;
     }
-    norm_sum[g] = s;
+    // accumulate: norm_sum IS the running statistic (xyz_gradient_accum += the views' sum: the same single addition torch's `+=`
+    // of the summed array performs, without the array)
+    norm_sum[g] = accumulate ? norm_sum[g] + s : s;
 }
 
 bool geo_ok(const w3d_raw_grads *g) {
@@ -187,7 +189,19 @@ extern "C" int w3d_rows_norm_sum(int32_t P, int32_t n_views, const float *rows_a
     if (P == 0) return W3D_OK;
     if (!viewmask || !slots || !norm_sum || !rows_all) { w3d_set_error("rows_norm_sum: NULL buffer"); return W3D_ERR_INVALID; }
     hipLaunchKernelGGL(rows_norm_sum_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, P,
-                       reinterpret_cast<const float4 *>(rows_all), cap_rows, viewmask, slots, norm_sum);
+                       reinterpret_cast<const float4 *>(rows_all), cap_rows, viewmask, slots, norm_sum, 0);
+    W3D_HIP_CHECK(hipGetLastError());
+    return W3D_OK;
+}
+
+extern "C" int w3d_rows_norm_accumulate(int32_t P, int32_t n_views, const float *rows_all, uint32_t cap_rows, const uint32_t *viewmask,
+                                        const uint32_t *slots, float *accum, w3d_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (P < 0 || n_views < 1 || n_views > 32) { w3d_set_error("rows_norm_accumulate: 1..32 views"); return W3D_ERR_INVALID; }
+    if (P == 0) return W3D_OK;
+    if (!viewmask || !slots || !accum || !rows_all) { w3d_set_error("rows_norm_accumulate: NULL buffer"); return W3D_ERR_INVALID; }
+    hipLaunchKernelGGL(rows_norm_sum_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, P,
+                       reinterpret_cast<const float4 *>(rows_all), cap_rows, viewmask, slots, accum, 1);
     W3D_HIP_CHECK(hipGetLastError());
     return W3D_OK;
 }

@@ -71,6 +71,8 @@ lib.w3d_index_gradient_rows.argtypes = [_i32, _i32, _vp, _vp, ctypes.c_uint32, _
 lib.w3d_index_gradient_rows.restype = ctypes.c_int
 lib.w3d_rows_norm_sum.argtypes = [_i32, _i32, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp]
 lib.w3d_rows_norm_sum.restype = ctypes.c_int
+lib.w3d_rows_norm_accumulate.argtypes = [_i32, _i32, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp]
+lib.w3d_rows_norm_accumulate.restype = ctypes.c_int
 lib.w3d_track_visibility.argtypes = [_i32, _vp, _vp, _vp, _vp]
 lib.w3d_track_visibility.restype = ctypes.c_int
 lib.w3d_rows_adam.argtypes = [_i32, _i32, _i32, _vp, _vp, ctypes.c_uint32, _vp, _vp, ctypes.POINTER(W3DRawGrads),
@@ -521,6 +523,14 @@ class GatheredRows:
             check(lib.w3d_rows_norm_sum(self.P, self.V, ptr(self.rows_all), self.cap, ptr(self.viewmask), ptr(self.slots), ptr(out),
                                         stream_ptr(dev)))
         return out[:self.P]
+
+    def norm_accumulate(self, accum):
+        """accum (P,) or (P,1) float32 += the views' sum of the rows' ||dL/dmean2D|| (one addition per Gaussian, view order)."""
+        dev = self.rows_all.device
+        assert accum.is_contiguous() and accum.numel() == self.P and accum.dtype == torch.float32 and accum.device == dev
+        with torch.cuda.device(dev):
+            check(lib.w3d_rows_norm_accumulate(self.P, self.V, ptr(self.rows_all), self.cap, ptr(self.viewmask), ptr(self.slots),
+                                               ptr(accum), stream_ptr(dev)))
 
 
 def rows_adam(model, gathered, campos_all, skip=()):

@@ -51,6 +51,24 @@ def nccl_inplace_shard(full, lo, hi, rank, world):
     return shard
 
 
+class _LazyVisible:
+    """`radii > 0`, evaluated only if somebody multiplies by it (the too-dense fallback of the sparse exchange)."""
+
+    def __init__(self, radii):
+        self._radii, self._v = radii, None
+
+    def _get(self):
+        if self._v is None:
+            self._v = self._radii > 0
+        return self._v
+
+    def __rmul__(self, other):
+        return other * self._get()
+
+    def __mul__(self, other):
+        return self._get() * other
+
+
 class Trainer:
     ROWS_RETRY = 16          # exchange="rows": steps in the low-rank form after one that was too dense, before rows are counted again
     ROWS_WINDOW = 48         # ... and the speculative size of the row collective follows the largest count of this many steps
@@ -215,10 +233,10 @@ class Trainer:
         exact in any order — integer-valued sums, maxima — so the ranks accumulate their own views locally and reduce ONCE,
         right before the consumer (sync_stats), instead of with two all-reduces of P-sized arrays in every step (rounds 1-4).
         The sum of the gradient norms still travels every step (in the rows, or as one all-reduce): a float sum is not."""
-        P = int(visible.shape[0])
-        if getattr(self, "_vis_local", None) is None or self._vis_local.shape[0] != P or self._vis_local.device != visible.device:
-            self._vis_local = torch.zeros(P, dtype=torch.int32, device=visible.device)
-            self._rmax_local = torch.zeros(P, dtype=torch.int32, device=visible.device)
+        P = int(radii.shape[0])
+        if getattr(self, "_vis_local", None) is None or self._vis_local.shape[0] != P or self._vis_local.device != radii.device:
+            self._vis_local = torch.zeros(P, dtype=torch.int32, device=radii.device)
+            self._rmax_local = torch.zeros(P, dtype=torch.int32, device=radii.device)
         if radii.is_cuda and radii.dtype == torch.int32 and radii.is_contiguous():
             from ._lib import check, ptr, stream_ptr
             from .fused_step import lib             # (the module that declares the entry point's argument types)
@@ -226,7 +244,8 @@ class Trainer:
                 check(lib.w3d_track_visibility(P, ptr(radii), ptr(self._vis_local), ptr(self._rmax_local), stream_ptr(radii.device)))
             return
         from ._host_twins import twin
-        twin("track_visibility", "Trainer.track_local")(visible, radii, self._vis_local, self._rmax_local)
+        twin("track_visibility", "Trainer.track_local")(radii > 0 if visible is None or isinstance(visible, _LazyVisible) else visible, radii,
+                                                        self._vis_local, self._rmax_local)
 
     def sync_stats(self):
         """Fold the locally tracked visibility counts and radii of all ranks into model.denom / model.max_radii2D (track_local).
@@ -244,8 +263,18 @@ class Trainer:
 
     def campos_of_all_ranks(self, iteration):
         """(world, 3) camera centres of the views all ranks render in this iteration (known locally: same camera list,
-        same permutation)."""
+        same permutation).  On the GPU a slice of a table kept on the device (the camera centres in permutation order, twice in a
+        row so that a step's `world` consecutive entries never wrap): no per-step stack + host-to-device copy in front of the
+        optimizer kernel."""
         n = len(self.cameras)
+        dev = self.model.flat.device
+        if dev.type == "cuda" and self.world <= n:
+            tab = getattr(self, "_campos_table", None)
+            if tab is None or tab.device != dev or tab.shape[0] != 2 * n:
+                c = torch.stack([self.cameras[i].camera_center.detach().reshape(3).float() for i in self.perm]).to(dev)
+                tab = self._campos_table = torch.cat([c, c]).contiguous()
+            s0 = ((iteration - 1) * self.world) % n
+            return tab[s0:s0 + self.world]
         cams = [self.cameras[self.perm[((iteration - 1) * self.world + r) % n]] for r in range(self.world)]
         return torch.stack([c.camera_center.detach().reshape(3).float() for c in cams])
 
@@ -306,7 +335,9 @@ class Trainer:
         from .fused_step import ROW_FLOATS, GatheredRows, apply_gradient_rows, pack_gradient_rows
         m = self.model
         P = m.num_points
-        dev = visible.device
+        if visible is None:
+            visible = _LazyVisible(radii)
+        dev = radii.device
         if packed is not None:
             # (rows, count) straight from the per-Gaussian backward (fused_step.backward_raw_rows): dcolor / grad2d_norm are None;
             # a step that turns out too dense for this form rebuilds the dense arrays from its own rows (too_dense below)
@@ -340,7 +371,7 @@ class Trainer:
             ev.synchronize()
             return pinned.tolist()
         # everything that does not depend on the counts is enqueued BEFORE the host reads them
-        gpu = visible.is_cuda
+        gpu = radii.is_cuda
         vcount = rmax = nsum = None
         self._stat_work = ()
         if tracking:
@@ -417,9 +448,11 @@ class Trainer:
             # the optimizer kernel reads the rows through the per-Gaussian index (optimizer_step_lowrank -> w3d_rows_adam):
             # no dense per-view array is zero-filled, scattered into or read
             if tracking:
-                nsum = gathered.norm_sum()
+                # (the norms go straight into the running statistic: _post_backward's `xyz_gradient_accum += nsum` without the array)
+                gathered.norm_accumulate(m.xyz_gradient_accum)
+                self._norms_accumulated = True
             self._rows, self._d_chunks, self._geo_work = gathered, [], []
-            return nsum, vcount, rmax
+            return None, vcount, rmax
         # host-logic path (CPU tensors, tests/test_dist_gloo.py): the same sums through dense arrays and the low-rank step
         if tracking:
             nsum = torch.zeros(P, dtype=torch.float32, device=dev)
@@ -558,7 +591,9 @@ class Trainer:
         # and torch's Adam skips them in that iteration's step; `skip` reproduces that.
         skip = set()
         if iteration < opt.densify_until_iter:
-            if not stats_done:
+            if not stats_done and getattr(self, "_norms_accumulated", False):
+                self._norms_accumulated = False           # (exchange_rows on the GPU added the rows' norms itself)
+            elif not stats_done:
                 m.xyz_gradient_accum += nsum[:, None]
                 if vcount is not None:              # (several ranks: tracked locally, reduced by sync_stats below when read)
                     m.max_radii2D = torch.max(m.max_radii2D, rmax.to(m.max_radii2D.dtype))
@@ -638,7 +673,8 @@ class Trainer:
                 m.denom += vis[:, None]
                 m.max_radii2D = torch.max(m.max_radii2D, pkg["radii"].to(m.max_radii2D.dtype))
             if not single:
-                vis = pkg["radii"] > 0
+                # (the sparse form on the GPU needs no visibility mask: the rows carry the norms and track_visibility reads the radii)
+                vis = None if packed is not None else pkg["radii"] > 0
                 if self.world > 1 and gnorm is not None:
                     gnorm = gnorm * float(self.world)           # statistics use the unscaled per-view norm
                 stepped_early = False
