@@ -94,11 +94,13 @@ typedef struct w3d_view {
                               * adds its slots in ascending tile order: bit-identical gradients run to run (the sanitizer
                               * mode of SURVEY.md section 5).  Needs scratch of w3d_backward_det_sizes() bytes. */
     uint64_t det_list_capacity; /* deterministic = 1: entries of point_list (= the capacity stage 2 was given) */
-    uint32_t *tile_walk_hint;   /* device, u32[tiles], nullable; speed only, never results.  The blend forward runs the tiles of
-                                 * every XCD longest first, and how long a tile takes — how far into its list it blends before
-                                 * its pixels saturate — is only known afterwards; a training loop renders the same camera again
-                                 * and again, so the caller may keep one such array per camera: stage 2 orders its tiles by the
-                                 * values it finds (zeros: image order) and overwrites them with this render's walk lengths. */
+    uint32_t *tile_walk_hint;   /* device, u32[tiles], nullable; speed only, never results.  How long a tile's wave takes — how far
+                                 * into its list it blends before its pixels saturate — is only known afterwards; a training loop
+                                 * renders the same camera again and again, so the caller may keep one such array per camera: stage 2
+                                 * builds its block -> (tile, part) schedule from the values it finds (work-balanced XCD ranges,
+                                 * longest first, tiles far longer than the chip's per-slot share cut into 2 or 4 part-waves; zeros:
+                                 * image order) and overwrites them with this render's walk lengths (for a tile that ran as
+                                 * part-waves: the length one of its parts reported — a lower bound).  Any contents are safe. */
     int32_t records_kept_clean; /* backward only, deterministic = 0.  The first P * 64 bytes of the backward scratch are the
                                  * per-Gaussian records the blend backward adds to; they must start at zero.  0: the backward
                                  * zeroes the visible Gaussians' records itself (a pass of its own).  1: the caller promises they
@@ -394,7 +396,9 @@ int w3d_profile_collect(char *out, uint64_t cap);
 /* Debug/inspection: copies of internal per-tile ranges (T,2) uint32 laid out as [start,end). */
 int w3d_debug_tile_ranges(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *ranges_out, w3d_stream_t stream);
 /* Debug/inspection: the per-Gaussian 16-B rect / tile-mask records of the forward (P,4) uint32 {rect lo, rect hi, mask lo, mask hi}
- * (tile units: lo = minx | miny << 16, hi = maxx | maxy << 16; written only when view->tile_cull was set). */
+ * (lo = minx | miny << 16, hi = maxx | maxy << 16; written only when view->tile_cull was set).  UNITS: cells of the LIST grid the
+ * forward ran on — 16x16 tiles with list_share = 0, 32x16 / 32x32 cells with list_share = 1 / 2 (a cell's mask bit is the OR of
+ * its tiles' bits).  Culled Gaussians hold an all-zero record. */
 int w3d_debug_tile_rects(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *rects_out, w3d_stream_t stream);
 /* Debug/inspection: the 64-B per-Gaussian records the blend kernels gather, (P,16) f32: {x, y, rect lo bits, rect hi bits |
  * conic.x, conic.y, conic.z, opacity | r, g, b, depth | the conic scaled into the log2 domain, opacity}.  Records of culled
