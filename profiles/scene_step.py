@@ -36,6 +36,9 @@ def main():
                          "the one-wave-per-tile schedule loses to its longest tiles: list-scheduling makespan of the 8 XCD ranges on "
                          "512 wave slots each, tiles longest first, against the perfectly divisible bound; the same with every tile "
                          "above `split` x the bound cut into two half-tile waves costing 0.6 of the tile each")
+    ap.add_argument("--bucket-stats", action="store_true",
+                    help="populations of the depth sort's 1024 buckets (w3d_binning.hip) on six cameras of the scene: max, p99, buckets "
+                         "beyond the LDS capacity of the in-bucket sort")
     ap.add_argument("--report", action="store_true",
                     help="instead of the marker window: time --steps steps (bench.StepMeter: probe, timed, per-stage events) and print "
                          "one JSON line {scene, iters_per_s, ms_per_step, stage_ms} — the A/B harness of profiles/ab_scenes.sh")
@@ -95,6 +98,25 @@ def main():
     for _ in range(0 if (a.report and a.freeze) else a.warmup):      # (--freeze: the variant under test never trains the model)
         it += 1
         trainer.step(it)
+    if a.bucket_stats:
+        import json
+        from w3d_amd.fused_step import render_raw
+        from w3d_amd.rasterizer import debug_gaussian_records
+        out = []
+        for ci in (0, 7, 14, 21, 28, 35):
+            cam = cams[ci % len(cams)]
+            with torch.no_grad():
+                pkg = render_raw(cam, model, bg, sync=True)
+            rec = debug_gaussian_records(pkg["handle"])
+            vis = pkg["radii"] > 0
+            keys = rec[vis][:, 11].contiguous().view(torch.int32).to(torch.int64)
+            kmin, kmax = int(keys.min()), int(keys.max())
+            M = (1 << 42) // (kmax - kmin + 1)
+            b = torch.bincount(((keys - kmin) * M) >> 32, minlength=1024)
+            out.append({"camera": ci, "visible": int(vis.sum()), "max": int(b.max()), "p99": int(b.float().quantile(0.99)), "mean": round(float(b.float().mean()), 1),
+                        "over_4096": int((b > 4096).sum()), "over_2048": int((b > 2048).sum()), "empty": int((b == 0).sum())})
+        print(json.dumps({"scene": a.scene, "gaussians": model.num_points, "depth_buckets": out}))
+        return
     if a.walk_stats:
         import heapq
         import json
