@@ -694,3 +694,22 @@ print(",".join(refused))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.strip() == "adam,loss,stats,prune", r.stdout
+
+
+def test_rows_moved_between_sync_points_is_an_error():
+    """per-rank visibility counters (Trainer.track_local) refer to rows; a direct model.reorder() / prune between two
+    sync_stats() calls used to leave them on the old rows silently — now the next step refuses."""
+    from w3d_amd.train import Trainer
+    sc = make_scene(40, seed=1, scale_mean=0.05)
+    m = GaussianModel(3, device="cpu")
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    opt = OptimizationParams()
+    m.training_setup(opt)
+    tr = Trainer(m, list(range(4)), opt, torch.zeros(3), densify=False, spatial_order=False)
+    radii = torch.arange(40, dtype=torch.int32) % 5
+    tr.track_local(radii > 0, radii)
+    tr.track_local(radii > 0, radii)
+    assert int(tr._vis_local.sum()) == 2 * int((radii > 0).sum())
+    m.reorder(torch.randperm(40, generator=torch.Generator().manual_seed(0)))
+    with pytest.raises(RuntimeError, match="rows were moved"):
+        tr.track_local(radii > 0, radii)

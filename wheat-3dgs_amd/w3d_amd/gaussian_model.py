@@ -316,6 +316,9 @@ class GaussianModel:
         xyz / scaling come from child_xyz / child_scaling.  Parameters and both moments move in ONE pass of
         csrc/w3d_densify.hip (a model on the CPU is refused: w3d_amd/_host_twins.py)."""
         P_old, P_new = self.num_points, int(src.numel())
+        # (the rows move: whoever keeps per-row data of its own between two calls — Trainer.track_local's per-rank visibility counters —
+        #  compares this counter to notice)
+        self._rows_version = getattr(self, "_rows_version", 0) + 1
         n_child0 = P_new if n_child0 is None else int(n_child0)
         layout_old, layout_new = flat_layout(P_old)[0], flat_layout(P_new)[0]
         n = flat_layout(P_new)[1]

@@ -234,9 +234,16 @@ class Trainer:
         right before the consumer (sync_stats), instead of with two all-reduces of P-sized arrays in every step (rounds 1-4).
         The sum of the gradient norms still travels every step (in the rows, or as one all-reduce): a float sum is not."""
         P = int(radii.shape[0])
-        if getattr(self, "_vis_local", None) is None or self._vis_local.shape[0] != P or self._vis_local.device != radii.device:
+        ver = getattr(self.model, "_rows_version", 0)
+        if getattr(self, "_vis_local", None) is not None and (self._vis_local_version != ver or self._vis_local.shape[0] != P):
+            # (ADVICE r05: model.reorder() / sort_spatially() / prune_points() called directly between two sync points used to leave
+            #  these counters on the old rows without any error)
+            raise RuntimeError("the model's rows were moved (reorder / sort_spatially / prune / densify called directly) while this rank "
+                               "held visibility counts of its own views: call Trainer.sync_stats() on every rank first")
+        if getattr(self, "_vis_local", None) is None or self._vis_local.device != radii.device:
             self._vis_local = torch.zeros(P, dtype=torch.int32, device=radii.device)
             self._rmax_local = torch.zeros(P, dtype=torch.int32, device=radii.device)
+            self._vis_local_version = ver
         if radii.is_cuda and radii.dtype == torch.int32 and radii.is_contiguous():
             from ._lib import check, ptr, stream_ptr
             from .fused_step import lib             # (the module that declares the entry point's argument types)
