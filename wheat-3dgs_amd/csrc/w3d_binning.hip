@@ -42,15 +42,18 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x
 //                             offset from the bucket's lower bound (`rbits` bits: the width of a bucket) — ceil(rbits / 8) stable
 //                             8-bit passes, 2 for the benchmark cameras — and written out as
 //                             the depth-ordered packed records {id, rect lo, rect hi, depth} + tile mask the (chunk, band) walkers
-//                             stream.  A bucket that does not fit the LDS arrays (everything at one depth, 40 M Gaussians ...) takes
-//                             the same passes through its own slice of the two global (key, id) buffers — slower, same result.
+//                             stream.  A bucket that does not fit the LDS arrays (everything at one depth, 40 M Gaussians, the piled
+//                             depths of some cameras of the densified benchmark scene: 140-230 buckets of 4 100-9 700 keys) takes
+//                             the same passes through its own slice of the two global (key, id) buffers — slower, same result
+//                             (depth sort 0.141 ms on that scene against 0.099; a second launch with 128 KB of LDS for those
+//                             buckets was measured and is slower still: its 1024 one-per-CU workgroups cost 12 us when idle).
 // Bucket b holds exactly the keys of [kmin + lower(b), kmin + lower(b + 1)), lower(b) = ceil(b * 2^32 / M); the scatter keeps index order inside a
 // bucket and the in-bucket passes are stable, so the result is THE stable order by (depth bits, index), whatever the depth
 // distribution (tests/test_gpu_parity.py::test_depth_sort_paths_and_tie_order_at_size: lists bit-identical to the oracle's).
 #define W3D_CTL_KMIN 4          // counters[4] = smallest visible depth key
 #define W3D_CTL_MUL 5           // counters[5] = M: bucket(key) = ((key - kmin) * M) >> 32 (0: the interval has fewer than 1024 keys, bucket = key - kmin)
 #define W3D_CTL_RBITS 7         // counters[7] = bits of a key's offset inside its bucket
-#define W3D_DB_CAP 4096         // (key, id) pairs a bucket may hold to be sorted in LDS (2 x 32 KB of ping-pong arrays)
+#define W3D_DB_CAP 4096         // items a bucket may hold to be sorted in LDS (one 32-bit word each, 2 x 16 KB of ping-pong arrays: 4 workgroups per CU)
 
 // the bucket grid of this view from the per-workgroup intervals the preprocess left (nb = ceil(P / W3D_PRE_BLOCK) pairs {min, max};
 // every workgroup of the histogram kernel reduces all of them: 62 KB of L2 hits at 2 M Gaussians)
@@ -321,15 +324,9 @@ depth_bucket_sort_kernel(uint32_t *__restrict__ keys_a, uint32_t *__restrict__ v
         for (uint32_t i = threadIdx.x; i < n; i += 256) lc[0][i] = ((keys_a[beg + i] - klo) << 12) | i;
         __syncthreads();
         uint32_t s = 0;
-#ifndef W3D_SORT_NOPASS
         for (uint32_t p = 0; p < npass; p++, s ^= 1u) bucket_pass<false>(lc[s], nullptr, lc[s ^ 1u], nullptr, n, 0u, 12u + 8u * p, hw, wave_tot);
-#endif
         const uint32_t *fin = lc[s];
-#ifndef W3D_SORT_NOEMIT
         emit_all(keys_a + beg, vals_a + beg, [&](uint32_t i) { return fin[i] & 4095u; });
-#else
-        if (fin[threadIdx.x] == 0xdeadbeef) rec[0] = make_uint4(0, 0, 0, 0);
-#endif
     } else {
         // a bucket beyond the LDS array (or offsets of 21+ bits): the same passes on (key, id) pairs through its slice of the two global buffers
         uint32_t *ks = keys_a + beg, *vs = vals_a + beg, *kd = keys_b + beg, *vd = vals_b + beg;
