@@ -230,17 +230,26 @@ depth_bucket_scatter_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__re
 // quarters, one per wave.  PAIRS: (key, id) pairs in the bucket's slice of the global buffers, digit = ((key - kmin) >> dshift) & 255
 // (kmin: the bucket's smallest possible key).  !PAIRS: single words c = offset of the key in the bucket << 12 | position after the
 // split (n <= 4096) in LDS, digit = (c >> dshift) & 255.  (The address spaces are resolved after inlining.)
-template <bool PAIRS>
+template <int MODE, uint32_t POSBITS = 12>
 __device__ __forceinline__ void bucket_pass(const uint32_t *ksrc, const uint32_t *vsrc, uint32_t *kdst, uint32_t *vdst, uint32_t n,
                                             uint32_t kmin, uint32_t dshift, uint32_t (*hw)[256], uint32_t *wave_tot) {
+    constexpr bool PAIRS = MODE == 1, MAKE = MODE == 2;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t per = ((n + 3u) / 4u + 63u) & ~63u;
     const uint32_t beg = min(n, (uint32_t)wv * per), end = min(n, beg + per);
-    auto digit = [&](uint32_t k) -> uint32_t { return (((PAIRS ? k - kmin : k)) >> dshift) & 255u; };
+    auto digit = [&](uint32_t k) -> uint32_t { return ((((PAIRS || MAKE) ? k - kmin : k)) >> dshift) & 255u; };
 #pragma unroll
     for (int i = 0; i < 4; i++) hw[wv][lane + 64 * i] = 0u;
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = beg + lane; i < end; i += 64) atomicAdd(&hw[wv][digit(ksrc[i])], 1u);
+    // (several loads in flight: a bucket that goes through global memory reads its keys from L2, a non-unrolled loop would pay
+    //  the latency once per 64 keys)
+    for (uint32_t i0 = beg + lane; i0 < end; i0 += 64u * 8u) {
+        uint32_t kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) kk[u] = i0 + 64u * u < end ? ksrc[i0 + 64u * u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (i0 + 64u * u < end) atomicAdd(&hw[wv][digit(kk[u])], 1u);
+    }
     __syncthreads();
     {
         // thread <-> digit: digit bases, then the cursor of every wave
@@ -253,10 +262,16 @@ __device__ __forceinline__ void bucket_pass(const uint32_t *ksrc, const uint32_t
     __syncthreads();
     const uint64_t lt = lanemask_lt();
     uint32_t *cur = hw[wv];
+    // software pipeline: the items of the next two batches are in flight while the current batch is ranked
+    uint32_t k1 = beg + lane < end ? ksrc[beg + lane] : 0u, v1 = (PAIRS && beg + lane < end) ? vsrc[beg + lane] : 0u;
+    uint32_t k2 = beg + 64 + lane < end ? ksrc[beg + 64 + lane] : 0u, v2 = (PAIRS && beg + 64 + lane < end) ? vsrc[beg + 64 + lane] : 0u;
     for (uint32_t base = beg; base < end; base += 64) {
         const uint32_t i = base + lane;
         const bool valid = i < end;
-        const uint32_t key = valid ? ksrc[i] : 0u, val = (PAIRS && valid) ? vsrc[i] : 0u;
+        const uint32_t key = k1, val = v1;
+        k1 = k2; v1 = v2;
+        k2 = i + 128 < end ? ksrc[i + 128] : 0u;
+        v2 = (PAIRS && i + 128 < end) ? vsrc[i + 128] : 0u;
         const uint32_t d = digit(key);
         uint64_t peers = w3d_ballot(valid);
 #pragma unroll
@@ -270,7 +285,7 @@ __device__ __forceinline__ void bucket_pass(const uint32_t *ksrc, const uint32_t
         __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) cur[d] = pos + (uint32_t)__popcll(peers);
         __builtin_amdgcn_wave_barrier();
-        if (valid) { kdst[pos] = key; if (PAIRS) vdst[pos] = val; }
+        if (valid) { kdst[pos] = MAKE ? (((key - kmin) << POSBITS) | i) : key; if (PAIRS) vdst[pos] = val; }
     }
     __syncthreads();
 }
@@ -324,14 +339,24 @@ depth_bucket_sort_kernel(uint32_t *__restrict__ keys_a, uint32_t *__restrict__ v
         for (uint32_t i = threadIdx.x; i < n; i += 256) lc[0][i] = ((keys_a[beg + i] - klo) << 12) | i;
         __syncthreads();
         uint32_t s = 0;
-        for (uint32_t p = 0; p < npass; p++, s ^= 1u) bucket_pass<false>(lc[s], nullptr, lc[s ^ 1u], nullptr, n, 0u, 12u + 8u * p, hw, wave_tot);
+        for (uint32_t p = 0; p < npass; p++, s ^= 1u) bucket_pass<0>(lc[s], nullptr, lc[s ^ 1u], nullptr, n, 0u, 12u + 8u * p, hw, wave_tot);
         const uint32_t *fin = lc[s];
         emit_all(keys_a + beg, vals_a + beg, [&](uint32_t i) { return fin[i] & 4095u; });
+    } else if (n <= 2u * W3D_DB_CAP && npass == 2u && rbits <= 19u) {
+        // up to twice the capacity, two passes: ONE LDS array holds the bucket.  Pass 0 reads the raw keys (global, twice: count and
+        // scatter) and leaves the words offset << 13 | position sorted by the low digit in LDS; pass 1 ranks them by the high digit
+        // and scatters the words into the bucket's slice of the second global buffer, from where the records are emitted — one
+        // L2 round trip instead of the three of the global path (the densified benchmark scene: 140-230 such buckets per view)
+        uint32_t *big = &lc[0][0];
+        bucket_pass<2, 13>(keys_a + beg, nullptr, big, nullptr, n, klo, 0u, hw, wave_tot);
+        bucket_pass<0>(big, nullptr, keys_b + beg, nullptr, n, 0u, 13u + 8u, hw, wave_tot);
+        const uint32_t *fin = keys_b + beg;
+        emit_all(keys_a + beg, vals_a + beg, [&](uint32_t i) { return fin[i] & 8191u; });
     } else {
         // a bucket beyond the LDS array (or offsets of 21+ bits): the same passes on (key, id) pairs through its slice of the two global buffers
         uint32_t *ks = keys_a + beg, *vs = vals_a + beg, *kd = keys_b + beg, *vd = vals_b + beg;
         for (uint32_t p = 0; p < npass; p++) {
-            bucket_pass<true>(ks, vs, kd, vd, n, klo, 8u * p, hw, wave_tot);
+            bucket_pass<1>(ks, vs, kd, vd, n, klo, 8u * p, hw, wave_tot);
             uint32_t *t = ks; ks = kd; kd = t;
             t = vs; vs = vd; vd = t;
         }
