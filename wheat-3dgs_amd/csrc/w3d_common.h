@@ -47,6 +47,10 @@ struct W3DLayout {
                            //       the staging lane replaces the two words by pmin * log2e and the Gaussian's index
                            //   [1] conic.x, conic.y, conic.z, opacity   [2] r, g, b, depth
                            //   [3] -0.5 log2e conic.x, -log2e conic.y, -0.5 log2e conic.z, opacity
+                           // READERS MUST GATE ON o_rect (or radii): a culled Gaussian's record is NOT written by the forward — the line
+                           // keeps whatever a recycled state buffer held; nothing reads the record of a Gaussian that is in no
+                           // list (the blend gathers through the lists; flash_extras, det_gather and w3d_debug_gaussian_records'
+                           // callers test the rect first)
                            // (rounds 1-4 kept xy / conic+opacity / rgb+depth in three arrays: three cache lines per gathered list
                            //  entry — 375 B through the fabric per walked entry of the blend backward, PMC — instead of one)
     uint64_t o_rect;       // ushort4[P] (minx,miny,maxx,maxy) tile units
