@@ -121,7 +121,7 @@ typedef struct w3d_view {
 
 /* Version of this ABI: major * 100 + minor.  The major number changes whenever a struct of this header changes its layout or
  * an entry point its signature; a binding must refuse a library whose major number differs from the header it mirrors. */
-#define W3D_ABI_VERSION 304
+#define W3D_ABI_VERSION 305
 int w3d_version(void);
 const char *w3d_last_error(void);
 
@@ -400,6 +400,12 @@ int w3d_debug_tile_ranges(int32_t H, int32_t W, int32_t P, const void *state, ui
  * forward ran on — 16x16 tiles with list_share = 0, 32x16 / 32x32 cells with list_share = 1 / 2 (a cell's mask bit is the OR of
  * its tiles' bits).  Culled Gaussians hold an all-zero record. */
 int w3d_debug_tile_rects(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *rects_out, w3d_stream_t stream);
+/* Debug/inspection: the block -> (tile, part) schedule the LAST blend kernel on this state ran (forward: built from the view's
+ * tile_walk_hint; backward: from the forward's walk lengths).  *cap_out = entries per XCD range; order_out (HOST memory, 8 * cap
+ * u32, may be NULL to query cap only; synchronous copy): entry = tile | part << 29 (part 0 the whole tile, 1 / 2 its upper /
+ * lower pair of 8x8 quadrants, 3..6 one quadrant), 0xFFFFFFFF = no work.  Meaningless when the kernel ran without a schedule
+ * (a forward without hint). */
+int w3d_debug_tile_schedule(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *order_out, uint32_t *cap_out);
 /* Debug/inspection: the 64-B per-Gaussian records the blend kernels gather, (P,16) f32: {x, y, rect lo bits, rect hi bits |
  * conic.x, conic.y, conic.z, opacity | r, g, b, depth | the conic scaled into the log2 domain, opacity}.  Records of culled
  * Gaussians (radii == 0) are NOT written: they hold whatever the buffer held before — gate on radii. */

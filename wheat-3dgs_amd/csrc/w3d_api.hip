@@ -522,6 +522,18 @@ int w3d_debug_tile_rects(int32_t H, int32_t W, int32_t P, const void *state, uin
     return W3D_OK;
 }
 
+int w3d_debug_tile_schedule(int32_t H, int32_t W, int32_t P, const void *state, uint32_t *order_out, uint32_t *cap_out) {
+    W3DLayout L;
+    int rc = w3d_make_layout(P, H, W, &L);
+    if (rc || !cap_out) { w3d_set_error("bad arguments"); return W3D_ERR_INVALID; }
+    *cap_out = L.order_cap;
+    if (order_out) {
+        if (!state) { w3d_set_error("bad arguments"); return W3D_ERR_INVALID; }
+        W3D_HIP_CHECK(hipMemcpy(order_out, static_cast<const char *>(state) + L.o_tile_order, (size_t)8 * L.order_cap * 4, hipMemcpyDeviceToHost));
+    }
+    return W3D_OK;
+}
+
 int w3d_debug_gaussian_records(int32_t H, int32_t W, int32_t P, const void *state, float *records_out, w3d_stream_t stream_) {
     W3DLayout L;
     int rc = w3d_make_layout(P, H, W, &L);

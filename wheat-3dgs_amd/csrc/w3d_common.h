@@ -80,9 +80,14 @@ struct W3DLayout {
 };
 
 // entries per XCD of the blend kernels' block -> (tile, part) map: frames of up to W3D_SCHED_MAX_TILES tiles get 1.5x their share of the
-// tiles (work-balanced XCD ranges are uneven in tile count, and long tiles are cut into 2 or 4 part-waves); larger frames the share
+// tiles (work-balanced XCD ranges are uneven in tile count, and long tiles are cut into 2 or 4 part-waves) — small frames, whose tiles
+// number fewer than a quarter of the chip's wave slots, 4x: every tile can run as four quadrant waves; larger frames the share
 #define W3D_SCHED_MAX_TILES 8192u
-static inline uint32_t w3d_order_cap(uint32_t T) { return T <= W3D_SCHED_MAX_TILES ? (T + T / 2u + 7u) / 8u + 1u : (T + 7u) / 8u; }
+static inline uint32_t w3d_order_cap(uint32_t T) {
+    if (T > W3D_SCHED_MAX_TILES) return (T + 7u) / 8u;
+    if (T <= 1024u) return 4u * ((T + 7u) / 8u) + 4u;        // (an even range of whole-frame quarters always fits)
+    return (T + T / 2u + 7u) / 8u + 1u;
+}
 
 static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L) {
     if (P < 0 || H <= 0 || W <= 0) return W3D_ERR_INVALID;

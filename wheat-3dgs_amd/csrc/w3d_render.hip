@@ -958,63 +958,71 @@ tile_schedule_kernel(const uint32_t *__restrict__ walk, uint32_t T, uint32_t cap
     for (uint32_t k = 0; k < 16; k++) { const uint32_t v = wave_c[k]; cpre += k < wv ? v : 0u; Wtot += v; }
     const uint32_t bound = max(Wtot / max(slots, 1u), 1u);
     const float range_scale = 8.0f / (float)max(Wtot, 1u);
-    // ---- pass 2: entries in tile order, range of every tile (monotone in the cumulated cost), the cuts
-    uint32_t esum = 0, xl = 0, run = cpre;
-    uint32_t xr[PER], ne[PER];
-#pragma unroll
-    for (uint32_t i = 0; i < PER; i++) {
-        const uint32_t t = tid * PER + i;
-        uint32_t ce;
-        const uint32_t code = sched_code(c[i], bound, allow_split, ce);
-        ne[i] = t < T ? (code == 0u ? 1u : (code == 1u ? 2u : 4u)) : 0u;
-        esum += ne[i];
-        xr[i] = min(7u, (uint32_t)((float)(run + c[i] / 2u) * range_scale));
-        run += c[i];
-        if (t < T) xl = xr[i];
-    }
-    uint32_t einc = esum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)einc, off, 64); if ((int)lane >= off) einc += u; }
-    if (lane == 63) wave_e[wv] = einc;
-    last_x[tid + 1] = xl;               // (threads behind the last tile repeat the last range)
-    if (tid == 0) last_x[0] = 0u;
-    __syncthreads();
-    uint32_t epre = einc - esum, Etot = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) { const uint32_t v = wave_e[k]; epre += k < wv ? v : 0u; Etot += v; }
-    {
-        uint32_t prev = last_x[tid], er = epre;
+    // ---- pass 2: entries in tile order, range of every tile (monotone in tile order), the cuts.  Up to three attempts, each decided
+    // identically by all eight workgroups: cost-balanced ranges with long tiles split; if some range would need more than `cap` entries
+    // (a heavy-tailed profile: the ranges without a long tile hold too many short ones), EVEN ranges with long tiles split — the
+    // splits are what such a profile needs most; if that does not fit either, even ranges of whole tiles (always fits).
+    bool bad = false;
+    uint32_t my_s = 0, my_e = 0, my_n = 0;
+    int split = allow_split;
+    const uint32_t even = (T + 7u) / 8u;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        const bool balanced = attempt == 0;
+        if (attempt == 2) split = 0;
+        if (tid < 9) { cut_t[tid] = T; cut_e[tid] = 0u; }
+        uint32_t esum = 0, xl = 0, run = cpre;
+        uint32_t xr[PER], ne[PER];
 #pragma unroll
         for (uint32_t i = 0; i < PER; i++) {
             const uint32_t t = tid * PER + i;
-            if (t < T) {
-                for (uint32_t k = prev + 1u; k <= xr[i]; k++) { cut_t[k] = t; cut_e[k] = er; }     // ranges (prev, xr] start at this tile
-                prev = xr[i];
-            }
-            er += ne[i];
+            uint32_t ce;
+            const uint32_t code = sched_code(c[i], bound, split, ce);
+            ne[i] = t < T ? (code == 0u ? 1u : (code == 1u ? 2u : 4u)) : 0u;
+            esum += ne[i];
+            xr[i] = balanced ? min(7u, (uint32_t)((float)(run + c[i] / 2u) * range_scale)) : min(7u, t / even);
+            run += c[i];
+            if (t < T) xl = xr[i];
         }
-        if (tid == 0) { cut_t[0] = 0u; cut_e[0] = 0u; cut_e[8] = Etot; }
-    }
-    __syncthreads();
-    // (a range nobody starts keeps cut_t = T: empty — and every later one as well, since the ranges are monotone; its cut_e must
-    //  then be the total)
-    bool bad = false;
-    uint32_t my_s, my_e, my_n;
-    {
-        uint32_t ct[9], cee[9];
+        uint32_t einc = esum;
 #pragma unroll
-        for (int k = 0; k < 9; k++) { ct[k] = cut_t[k]; cee[k] = cut_t[k] >= T ? Etot : cut_e[k]; }
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)einc, off, 64); if ((int)lane >= off) einc += u; }
+        if (lane == 63) wave_e[wv] = einc;
+        last_x[tid + 1] = xl;               // (threads behind the last tile repeat the last range)
+        if (tid == 0) last_x[0] = 0u;
+        __syncthreads();
+        uint32_t epre = einc - esum, Etot = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) bad = bad || (cee[k + 1] - cee[k]) > cap;
-        my_s = ct[0]; my_e = ct[1]; my_n = cee[1] - cee[0];
+        for (uint32_t k = 0; k < 16; k++) { const uint32_t v = wave_e[k]; epre += k < wv ? v : 0u; Etot += v; }
+        {
+            uint32_t prev = last_x[tid], er = epre;
 #pragma unroll
-        for (int k = 1; k < 8; k++) if (x == (uint32_t)k) { my_s = ct[k]; my_e = ct[k + 1]; my_n = cee[k + 1] - cee[k]; }
-    }
-    int split = allow_split;
-    if (bad) {                      // (the same decision in all eight workgroups) -> even ranges, whole tiles
-        const uint32_t even = (T + 7u) / 8u;
-        my_s = min(T, x * even); my_e = min(T, my_s + even); my_n = my_e - my_s;
-        split = 0;
+            for (uint32_t i = 0; i < PER; i++) {
+                const uint32_t t = tid * PER + i;
+                if (t < T) {
+                    for (uint32_t k = prev + 1u; k <= xr[i]; k++) { cut_t[k] = t; cut_e[k] = er; }     // ranges (prev, xr] start at this tile
+                    prev = xr[i];
+                }
+                er += ne[i];
+            }
+            if (tid == 0) { cut_t[0] = 0u; cut_e[0] = 0u; cut_e[8] = Etot; }
+        }
+        __syncthreads();
+        // (a range nobody starts keeps cut_t = T: empty — and every later one as well, since the ranges are monotone; its cut_e must
+        //  then be the total)
+        bad = false;
+        {
+            uint32_t ct[9], cee[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) { ct[k] = cut_t[k]; cee[k] = cut_t[k] >= T ? Etot : cut_e[k]; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) bad = bad || (cee[k + 1] - cee[k]) > cap;
+            my_s = ct[0]; my_e = ct[1]; my_n = cee[1] - cee[0];
+#pragma unroll
+            for (int k = 1; k < 8; k++) if (x == (uint32_t)k) { my_s = ct[k]; my_e = ct[k + 1]; my_n = cee[k + 1] - cee[k]; }
+        }
+        __syncthreads();               // (the cuts are rewritten by the next attempt)
+        if (!bad) break;               // (uniform: the same data in all threads of all eight workgroups)
+        if (!split) attempt = 1;       // (nothing to split: the next attempt is the last one)
     }
     // ---- pass 3: this range's entries, longest first
     if (tid < 64) cnt[tid] = 0u;

@@ -521,6 +521,21 @@ def debug_tile_rects(saved):
     return out
 
 
+def debug_tile_schedule(saved):
+    """(8, cap) int64 numpy array of the block -> (tile, part) entries the last blend kernel on this state ran
+    (include/w3d.h w3d_debug_tile_schedule)."""
+    import numpy as np
+    v = saved["view"].c
+    lib.w3d_debug_tile_schedule.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_void_p] * 3
+    lib.w3d_debug_tile_schedule.restype = ctypes.c_int
+    cap = ctypes.c_uint32()
+    check(lib.w3d_debug_tile_schedule(v.image_height, v.image_width, saved["P"], None, None, ctypes.byref(cap)))
+    out = np.empty(8 * cap.value, np.uint32)
+    torch.cuda.synchronize(saved["state"].device)
+    check(lib.w3d_debug_tile_schedule(v.image_height, v.image_width, saved["P"], ptr(saved["state"]), out.ctypes.data, ctypes.byref(cap)))
+    return out.astype(np.int64).reshape(8, cap.value)
+
+
 def debug_gaussian_records(saved):
     """(P,16) float32: the 64-B per-Gaussian records of a forward (include/w3d.h w3d_debug_gaussian_records); rows of culled
     Gaussians (radii == 0) are not written by the forward."""
