@@ -905,8 +905,9 @@ tile_order_kernel(const uint32_t *__restrict__ tile_walk, uint32_t T, uint32_t p
 //     the order: such a tile is cut into two waves (upper / lower pair of 8x8 quadrants, each ~0.6 of the cost: the staging is paid
 //     twice) or, beyond 2.2x, four (one quadrant each, ~0.35).  Part-waves add into the same Gaussian records (atomic backward
 //     only: allow_split = 0 for the deterministic one) and write disjoint pixels.
-// Inside a range: longest entry first (counting sort by a 6-bit quantised cost).  If a range would need more than `cap` entries
-// (a pathological cost profile) the even ranges without splitting are used.
+// Inside a range: longest entry first (counting sort by a 6-bit quantised cost).  If a cost-balanced range would need more than `cap`
+// entries (a heavy-tailed profile) even ranges are used with the long tiles still split, and if that does not fit either, even ranges
+// of whole tiles.  Frames of up to 1024 tiles have cap = 4x the even share: every tile may run as four quadrant waves.
 #define W3D_SCHED_C0 16u
 #ifndef W3D_SPLIT_X10
 #define W3D_SPLIT_X10 15u      // a tile is cut in two when its cost exceeds this / 10 x (total cost / wave slots), in four beyond 2.2x that
