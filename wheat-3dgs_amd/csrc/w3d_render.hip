@@ -909,6 +909,9 @@ tile_order_kernel(const uint32_t *__restrict__ tile_walk, uint32_t T, uint32_t p
 // entries (a heavy-tailed profile) even ranges are used with the long tiles still split, and if that does not fit either, even ranges
 // of whole tiles.  Frames of up to 1024 tiles have cap = 4x the even share: every tile may run as four quadrant waves.
 #define W3D_SCHED_C0 16u
+#ifndef W3D_QUARTER_X10
+#define W3D_QUARTER_X10 22u    // ... and in four beyond this / 10 x the halving threshold
+#endif
 #ifndef W3D_SPLIT_X10
 #define W3D_SPLIT_X10 15u      // a tile is cut in two when its cost exceeds this / 10 x (total cost / wave slots), in four beyond 2.2x that
 #endif
@@ -917,7 +920,7 @@ __device__ __forceinline__ uint32_t sched_cost(uint32_t walk) { return walk ? wa
 __device__ __forceinline__ uint32_t sched_code(uint32_t c, uint32_t bound, int allow_split, uint32_t &ce) {
     ce = c;
     if (!allow_split || 10u * c <= W3D_SPLIT_X10 * bound) return 0u;
-    if (100u * c > 22u * W3D_SPLIT_X10 * bound) { ce = (35u * c) / 100u; return 3u; }
+    if (100u * c > W3D_QUARTER_X10 * W3D_SPLIT_X10 * bound) { ce = (35u * c) / 100u; return 3u; }
     ce = (6u * c) / 10u;
     return 1u;
 }
