@@ -1,6 +1,6 @@
 """Launch-to-launch repeatability of ONE view's backward (round 4): the forward + loss + gradient-writing backward of the two-rank
 test's scene (5 000 Gaussians) repeated `reps` times per camera, every gradient bucket diffed against the first — an element
-that moves by more than 1e-4 of its block's maximum is printed with its Gaussian.  This is what found the idle-lane race of the
+that moves by more than 3e-4 of its block's maximum is printed with its Gaussian.  This is what found the idle-lane race of the
 per-Gaussian backward (DESIGN.md section 2.3 lessons): Gaussian P - 1 lost its gradient in 3-9 of 120 launches.
   usage: python3 profiles/repeat_view_probe.py [none|zeros|ff|nan|small|rand|unit] [reps]      (fill modes: tests/_poison.py)"""
 import os, sys
@@ -41,9 +41,13 @@ with torch.no_grad():
             for name, (a, b) in sl.items():
                 d = (g[a:b] - ref[0][a:b]).abs()
                 rel = float(d.max() / (ref[0][a:b].abs().max() + 1e-30))
-                if rel > 1e-4 or dimg_ > 1e-5:
+                # (3e-4 of the block's maximum since round 6: the tiles of a small frame run as four quadrant waves, DESIGN.md section 2.2,
+                #  so a Gaussian receives four atomic partial sums per tile instead of one and the order of the float additions —
+                #  free in the atomic mode, as in the reference's per-pixel atomics — moves a strongly cancelling sum by up to 1.8e-4
+                #  (one Gaussian of 5 000, a recurring handful of values); a lost update, what this probe is for, is of order 1)
+                if rel > 3e-4 or dimg_ > 1e-5:
                     bad += 1
-                    idx = (d > 1e-4 * ref[0][a:b].abs().max()).nonzero().flatten()
+                    idx = (d > 3e-4 * ref[0][a:b].abs().max()).nonzero().flatten()
                     dim = (b - a) // m.num_points
                     print(f"cam {ci} it {it} sync {sync} block {name}: rel {rel:.3e} img diff {dimg_:.2e}; {idx.numel()} elems; gaussians {sorted(set((idx // max(dim,1)).tolist()))[:12]}")
 print(f"mode={mode} reps={reps} anomalies={bad}")

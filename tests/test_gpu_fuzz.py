@@ -51,8 +51,9 @@ def test_forward_repeats_bit_for_bit():
 
 @pytest.mark.parametrize("fill", ["none", "small"])
 def test_one_views_backward_repeats(fill):
-    """60 launches per camera of the same view's backward: no gradient element moves by more than 1e-4 of its block's maximum
-    (with and without patterned torch.empty, tests/_poison.py)."""
+    """60 launches per camera of the same view's backward: no gradient element moves by more than 3e-4 of its block's maximum
+    (with and without patterned torch.empty, tests/_poison.py; the bar covers the float-addition order of the atomic mode — up to
+    1.8e-4 for one strongly cancelling sum since small frames run their tiles as four quadrant waves — a lost update is of order 1)."""
     out = _run("repeat_view_probe.py", fill, 60)
     assert f"mode={fill} reps=60 anomalies=0" in out, out[-3000:]
 
