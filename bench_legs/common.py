@@ -94,7 +94,7 @@ def _newest(pattern):
 # kernels of every stage of the step (names as rocprofv3 prints them, template arguments included where they matter)
 STAGE_KERNELS = {
     "preprocess_fwd": ("preprocess_fwd_kernel",),
-    "depth_sort": ("depth_bucket_",),
+    "depth_sort": ("depth_bucket_", "depth_grid_"),
     "tile_count_scan": ("chunk_walk_kernel<0", "seg_sum_kernel", "tile_scan_kernel", "chunk_off_kernel", "tile_count_", "band_"),
     "fill_lists": ("chunk_walk_kernel<1", "fill_"),
     "render_fwd": ("render_fwd_kernel",),

@@ -102,6 +102,8 @@ def main():
         import json
         from w3d_amd.fused_step import render_raw
         from w3d_amd.rasterizer import debug_gaussian_records
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        from depth_grid_model import grid_buckets, summary
         out = []
         for ci in (0, 7, 14, 21, 28, 35):
             cam = cams[ci % len(cams)]
@@ -109,12 +111,10 @@ def main():
                 pkg = render_raw(cam, model, bg, sync=True)
             rec = debug_gaussian_records(pkg["handle"])
             vis = pkg["radii"] > 0
-            keys = rec[vis][:, 11].contiguous().view(torch.int32).to(torch.int64)
-            kmin, kmax = int(keys.min()), int(keys.max())
-            M = (1 << 42) // (kmax - kmin + 1)
-            b = torch.bincount(((keys - kmin) * M) >> 32, minlength=1024)
-            out.append({"camera": ci, "visible": int(vis.sum()), "max": int(b.max()), "p99": int(b.float().quantile(0.99)), "mean": round(float(b.float().mean()), 1),
-                        "over_4096": int((b > 4096).sum()), "over_2048": int((b > 2048).sum()), "empty": int((b == 0).sum())})
+            keys = rec[:, 11].contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+            keys[~vis] = 0xFFFFFFFF
+            pop, widths, nbk = grid_buckets(keys.cpu().numpy())
+            out.append({"camera": ci, "visible": int(vis.sum()), "buckets": nbk, **summary(pop, widths)})
         print(json.dumps({"scene": a.scene, "gaussians": model.num_points, "depth_buckets": out}))
         return
     if a.walk_stats:

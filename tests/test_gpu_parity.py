@@ -347,29 +347,35 @@ def test_culls_are_exact_on_needles(seed):
 
 
 @pytest.mark.parametrize("depth_span,P", [("narrow", 150_000), ("wide", 150_000), ("wide", 9_000), ("clustered", 120_000),
-                                          ("two_depths", 30_000), ("piled", 200_000)])
+                                          ("two_depths", 30_000), ("piled", 200_000), ("missed_pile", 199_936)])
 def test_depth_sort_paths_and_tie_order_at_size(depth_span, P):
-    """The depth sort (w3d_binning.hip: 1024 buckets over the view's depth interval, every bucket sorted in LDS by its low bits) on
-    enough Gaussians that every wave of the split holds keys: `narrow` — the benchmark's overhead cameras, depths within one octave
-    (bucket shift 12-13: two in-bucket passes); `wide` — the slab stretched 30 units away from the cameras, depths 2 ... 33 (four
-    octaves: shift 16, the bucket populations follow the depth distribution); `clustered` — all Gaussians at 24 positions, 5 000
-    EQUAL keys each: buckets beyond the LDS arrays, sorted through their slice of the global buffers, nothing but ties;
-    `two_depths` — two positions (a span below 1024 key values would need no in-bucket pass at all: shift 0); `piled` — 99 % of
-    the Gaussians in a sheet 0.1 thick and 1 % strewn 30 units behind it: the sheet falls into a few dozen of the 1024 buckets, 5-10 k
-    DIFFERENT keys each — beyond the LDS arrays: the in-bucket passes through global memory on real digits (the densified benchmark
-    scene does this on some cameras: 140-230 buckets of 4 100-9 700 keys).  A quarter of the
-    Gaussians are exact duplicates of earlier ones (densify_and_clone's output), so equal keys must keep ascending index order.
-    Per-tile ranges and lists: bit-identical to the oracle's (stable order by (depth bits, index))."""
+    """The depth sort (w3d_binning.hip: 1024 buckets over the view's depth interval — a piecewise-linear grid, even in population as
+    far as a sample of two keys per preprocess workgroup tells — every bucket sorted in LDS by its low bits) on enough Gaussians
+    that every wave of the split holds keys: `narrow` — the benchmark's overhead cameras, depths within one octave (two in-bucket
+    passes); `wide` — the slab stretched 30 units away from the cameras, depths 2 ... 33 (four octaves); `clustered` — all
+    Gaussians at 24 positions, 5 000 EQUAL keys each: buckets beyond the LDS arrays, nothing but ties; `two_depths` — two positions
+    (a span below 1024 key values needs no in-bucket pass at all); `piled` — 99 % of the Gaussians in a sheet 0.1 thick and 1 %
+    strewn 30 units behind it: equal-WIDTH buckets would put the sheet into a few dozen of them, 5-10 k keys each (round 6's first
+    grid did, and the densified benchmark scene showed 140-230 such buckets on some cameras) — the grid must spread it: no bucket
+    beyond the LDS capacity; `missed_pile` — the same sheet, but the strewn Gaussians sit exactly at the storage positions the
+    sample is taken from (lanes 64 and 192 of every 256), so the grid sees an even view and the sheet DOES land in a few buckets
+    of 5-20 k DIFFERENT keys: the one-LDS-array path (4 097-8 192 keys) and the in-bucket passes through global memory on real
+    digits.  A quarter of the Gaussians are exact duplicates of earlier ones (densify_and_clone's output), so equal keys must keep
+    ascending index order.  Per-tile ranges and lists: bit-identical to the oracle's (stable order by (depth bits, index))."""
+    from depth_grid_model import grid_buckets, summary
     from w3d_amd.synth import make_scene, make_cameras
     W, H = 320, 240
     sc = make_scene(P, seed=23, scale_mean=0.004)
     g5 = torch.Generator().manual_seed(5)
     if depth_span == "wide":
         sc.xyz[:, 2] = 0.6 - 30.0 * torch.rand(P, generator=g5)
-    elif depth_span == "piled":
+    elif depth_span in ("piled", "missed_pile"):
         sc.xyz[:, 2] = 0.1 * torch.rand(P, generator=g5)
         sc.xyz[:, :2] *= 0.25                       # (seen obliquely, the sheet's lateral extent spreads its depths more than its thickness)
         far = torch.rand(P, generator=g5) < 0.01
+        if depth_span == "missed_pile":
+            assert P % 128 == 0                     # (the duplicates appended below keep their lane)
+            far = torch.arange(P) % 128 == 64
         sc.xyz[far, 2] = 0.6 - 30.0 * torch.rand(int(far.sum()), generator=g5)
         sc.opacity[:] = -3.0
     elif depth_span in ("clustered", "two_depths"):
@@ -386,10 +392,17 @@ def test_depth_sort_paths_and_tie_order_at_size(depth_span, P):
     octaves = float(np.log2(depth.max() / depth.min()))
     if depth_span in ("wide", "narrow"):
         assert (octaves > 2.5) if depth_span == "wide" else (octaves < 1.0), octaves
-    elif depth_span == "piled":
+    elif depth_span in ("piled", "missed_pile"):
         kk = depth.view(np.uint32).astype(np.int64)
         pop = np.bincount(((kk - kk.min()) * ((1 << 42) // (kk.max() - kk.min() + 1))) >> 32, minlength=1024)
-        assert (pop > 4096).sum() >= 5, pop.max()         # (buckets beyond the LDS capacity exist)
+        assert (pop > 4096).sum() >= 5, pop.max()         # (equal-width buckets beyond the LDS capacity would exist)
+        keys = np.where(ref["radii"] > 0, o.geom()["depth"].view(np.uint32).astype(np.int64), 0xFFFFFFFF)
+        gpop, gwidths, _ = grid_buckets(keys)
+        if depth_span == "piled":
+            assert gpop.max() <= 4096, summary(gpop, gwidths)
+        else:
+            mid = (gpop > 4096) & (gpop <= 8192)
+            assert mid.sum() >= 1 and (gpop > 8192).sum() >= 1, summary(gpop, gwidths)     # (both paths beyond the LDS ping-pong)
     else:
         assert len(np.unique(depth)) <= 24 and (ref["radii"] > 0).sum() > 0.5 * P
     out, _ = run_hip(d, cam, bg, tile_cull=False)

@@ -6,7 +6,7 @@
 // (tile|depth) keys and radix-sorting all of them through HBM, the order contract
 // "within a tile ascending depth bits, ties by ascending Gaussian index" is met in two steps:
 //   1. ONE stable sort of the (depth bits, index) pairs — P << R, 16 B per Gaussian — as a 1024-way bucket split over the view's
-//      depth interval + an in-LDS sort of every bucket (four launches, "depth sort" below); the split drops the culled
+//      depth interval + an in-LDS sort of every bucket (five launches, "depth sort" below); the split drops the culled
 //      Gaussians and publishes V;
 //   2. a single-pass stable counting sort of the tile instances by tile id: the depth order is cut into C chunks and the
 //      image into bands of tile rows; one wave per (chunk, band) keeps the band's per-tile counters (count pass) or
@@ -25,17 +25,16 @@ namespace {
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
 // ------------------------------------------------------------------------------ depth sort
-// Stable sort of the visible Gaussians by (depth bits, index) in FOUR launches (rounds 1-5: an LSD radix sort, 3-4 passes x
+// Stable sort of the visible Gaussians by (depth bits, index) in FIVE launches (rounds 1-5: an LSD radix sort, 3-4 passes x
 // {histogram, row scan, scatter} = 12 launches, 0.162 ms for 1.2 M keys — a chain of short latency-bound kernels, at the level of
 // rocPRIM's one-sweep sort, 139 us, on this part).
 //
 // The keys are the bit patterns of positive floats (view depths > 0.2), monotone in the depth, and ONE view's depths are a narrow
-// interval of them.  Every workgroup of the preprocess kernel leaves {min, max} of its visible keys (a block reduction and one 8-B
-// store, nothing to initialise); the histogram kernel reduces them to the view's interval [kmin, kmax].  Then
-//   1. depth_bucket_hist      the interval is cut into W3D_DB_BINS = 1024 equal buckets, bucket(key) = ((key - kmin) * M) >> 32 with
-//                             M = floor(2^42 / (kmax - kmin + 1)) — monotone in the key, below 1024, and (unlike a power-of-two
-//                             shift, which left 25-45 % of the buckets empty and the others twice as full) using all of them;
-//                             one histogram per run (= the slice of the Gaussian order one wave owns);
+// interval of them.  Every workgroup of the preprocess kernel leaves {min, max} of its visible keys and two of its keys (a block reduction and one 16-B
+// store, nothing to initialise).  Then
+//   0. depth_grid             one workgroup: the view's interval [kmin, kmax] from those entries and the bucket grid over it (below:
+//                             W3D_DB_BINS = 1024 buckets, piecewise linear in the key, even in POPULATION as far as a sample tells);
+//   1. depth_bucket_hist      one histogram of bucket(key) per run (= the slice of the Gaussian order one wave owns);
 //   2. depth_bucket_scan      per bucket: exclusive scan of the run counts + bucket total;
 //   3. depth_bucket_scatter   stable multi-split of the (key, index) pairs into the buckets (culled Gaussians dropped, V published);
 //   4. depth_bucket_sort      one workgroup per bucket: the bucket (1 200 pairs on the benchmark view) is sorted IN LDS by the key's
@@ -47,78 +46,56 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x
 //                             the same passes through its own slice of the two global (key, id) buffers — slower, same result
 //                             (depth sort 0.141 ms on that scene against 0.099; a second launch with 128 KB of LDS for those
 //                             buckets was measured and is slower still: its 1024 one-per-CU workgroups cost 12 us when idle).
-// Bucket b holds exactly the keys of [kmin + lower(b), kmin + lower(b + 1)), lower(b) = ceil(b * 2^32 / M); the scatter keeps index order inside a
+// Bucket b holds exactly the keys of [kmin + lo(b), kmin + lo(b) + width(b)) (depth_bucket_range); the scatter keeps index order inside a
 // bucket and the in-bucket passes are stable, so the result is THE stable order by (depth bits, index), whatever the depth
 // distribution (tests/test_gpu_parity.py::test_depth_sort_paths_and_tie_order_at_size: lists bit-identical to the oracle's).
 #define W3D_CTL_KMIN 4          // counters[4] = smallest visible depth key
-#define W3D_CTL_MUL 5           // counters[5] = M: bucket(key) = ((key - kmin) * M) >> 32 (0: the interval has fewer than 1024 keys, bucket = key - kmin)
-#define W3D_CTL_RBITS 7         // counters[7] = bits of a key's offset inside its bucket
+#define W3D_CTL_MUL 5           // counters[5] = the grid's segment multiplier (0: the interval has fewer than 1024 key values, bucket = key - kmin)
 #define W3D_DB_CAP 4096         // items a bucket may hold to be sorted in LDS (one 32-bit word each, 2 x 16 KB of ping-pong arrays: 4 workgroups per CU)
 
-// the bucket grid of this view from the per-workgroup intervals the preprocess left (nb = ceil(P / W3D_PRE_BLOCK) pairs {min, max};
-// every workgroup of the histogram kernel reduces all of them: 62 KB of L2 hits at 2 M Gaussians)
-struct DepthGrid { uint32_t kmin, mul, rbits; };
-__device__ __forceinline__ uint32_t depth_bucket(uint32_t key, uint32_t kmin, uint32_t mul) {
-    const uint32_t x = key - kmin;
-    return mul ? __umulhi(x, mul) : x;
+// ---- the bucket grid of a view.  Equal-WIDTH buckets over [kmin, kmax] are only balanced when the depths are spread evenly: one
+// Gaussian in a thousand far behind the scene (a background 30-60 units away) stretches the interval to five octaves, the scene keeps
+// 14 % of the buckets, 50-90 of them hold 8-20 k keys and fall out of the LDS paths — depth sort 0.094 -> 0.235 ms
+// (profiles/skewed_depth_probe.py).  So the grid is piecewise linear: the interval is cut into W3D_DB_SEGS = 64 equal segments, a
+// fixed SAMPLE of the keys (two per preprocess workgroup, at most 16384, spread over the Gaussian order: ~150 visible samples per
+// segment on an even view — with 256 segments and ~10 the sampling noise alone doubled some buckets) estimates each segment's
+// population, every segment gets one bucket plus its proportional share of the other 960, and inside a segment the buckets are
+// equal-width again:  seg = ((key - kmin) * mseg) >> 32,  bucket = first[seg] + min(count[seg] - 1, ((key - kmin - start[seg]) *
+// slope[seg]) >> 32).  Monotone in the key whatever the sample says, so the sort stays exact; the sample only decides how even the
+// buckets come out.  The table (one uint4 per segment: start, slope, first | count << 16, end) is built by depth_grid_kernel.
+#define W3D_DB_SEGS 64
+#define W3D_DB_SEG_BITS 6
+struct DepthGridHead { uint32_t kmin, mseg, nbuckets, pad; };       // mseg == 0: fewer than 1024 key values, bucket = key - kmin
+// LDS image of the grid: tab[seg] = {start, slope (0: one key value per bucket), first | count << 16, end}
+__device__ __forceinline__ uint32_t depth_bucket(uint32_t key, const DepthGridHead &h, const uint4 *tab) {
+    const uint32_t x = key - h.kmin;
+    if (h.mseg == 0u) return x;
+    const uint4 t = tab[__umulhi(x, h.mseg)];
+    const uint32_t loc = t.y ? __umulhi(x - t.x, t.y) : x - t.x;
+    return (t.z & 0xFFFFu) + min(loc, (t.z >> 16) - 1u);
 }
-// smallest x with depth_bucket(x) == b
-__device__ __forceinline__ uint32_t depth_bucket_lower(uint32_t b, uint32_t mul) {
-    return mul ? (uint32_t)((((uint64_t)b << 32) + mul - 1u) / mul) : b;
+// [lo, hi) of the key offsets (key - kmin) bucket b holds; false: the bucket is past the grid's last one
+__device__ __forceinline__ bool depth_bucket_range(uint32_t b, const DepthGridHead &h, const uint4 *tab, uint32_t &lo, uint32_t &hi) {
+    if (h.mseg == 0u) { lo = b; hi = b + 1u; return b < h.nbuckets; }
+    if (b >= h.nbuckets) return false;
+    uint32_t s0 = 0, s1 = W3D_DB_SEGS;                       // last segment whose first bucket is <= b
+    while (s1 - s0 > 1u) { const uint32_t mid = (s0 + s1) >> 1; if ((tab[mid].z & 0xFFFFu) <= b) s0 = mid; else s1 = mid; }
+    const uint4 t = tab[s0];
+    const uint32_t loc = b - (t.z & 0xFFFFu), cnt = t.z >> 16;
+    // smallest offset x in the segment with ((x - start) * slope) >> 32 >= l: ceil(l * 2^32 / slope) — a double-precision
+    // estimate, then made exact against the very expression depth_bucket() evaluates
+    auto lower = [&](uint32_t l) -> uint32_t {
+        if (t.y == 0u) return t.x + l;
+        if (l == 0u) return t.x;
+        uint32_t x = (uint32_t)fmin(4294967295.0, (double)l * 4294967296.0 / (double)t.y);
+        while (__umulhi(x, t.y) < l) x++;
+        while (x > 0u && __umulhi(x - 1u, t.y) >= l) x--;
+        return t.x + x;
+    };
+    lo = lower(loc);
+    hi = loc + 1u >= cnt ? t.w : lower(loc + 1u);
+    return true;
 }
-__device__ __forceinline__ DepthGrid depth_grid(const uint2 *__restrict__ minmax, uint32_t nb, uint32_t *red /* LDS [8] */) {
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-    for (uint32_t i = threadIdx.x; i < nb; i += 256) { const uint2 m = minmax[i]; kmin = min(kmin, m.x); kmax = max(kmax, m.y); }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
-        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
-    }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = kmin; red[4 + (threadIdx.x >> 6)] = kmax; }
-    __syncthreads();
-    kmin = min(min(red[0], red[1]), min(red[2], red[3]));
-    kmax = max(max(red[4], red[5]), max(red[6], red[7]));
-    DepthGrid g;
-    g.kmin = kmin; g.mul = 0u; g.rbits = 0u;
-    if (kmin > kmax) { g.kmin = 0u; return g; }                        // nothing visible
-    const uint32_t span = kmax - kmin;
-    if (span < W3D_DB_BINS) return g;                                  // one key value per bucket: nothing to sort inside
-    g.mul = (uint32_t)((1ull << (32 + W3D_DB_BITS)) / ((uint64_t)span + 1ull));      // < 2^32 since span + 1 > 1024; (span * mul) >> 32 < 1024
-    const uint32_t wmax = (uint32_t)(((1ull << 32) + g.mul - 1u) / g.mul) + 1u;      // lower(b + 1) - lower(b) <= ceil(2^32 / mul) + 1
-    g.rbits = 32u - (uint32_t)__builtin_clz(wmax);
-    return g;
-}
-
-// one run per wave, four runs per workgroup; hist[bucket][run] (row pitch = runs rounded up to 4: the four counts of a workgroup
-// leave as one 16-B store per bucket)
-__global__ void __launch_bounds__(256)
-depth_bucket_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items, uint32_t n_runs, uint32_t pitch,
-                         uint32_t *__restrict__ hist, uint32_t *__restrict__ counters, const uint2 *__restrict__ minmax, uint32_t nb) {
-    __shared__ __align__(16) uint32_t h_all[4][W3D_DB_BINS];
-    __shared__ uint32_t red[8];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t run = blockIdx.x * 4 + wv;
-    const DepthGrid dg = depth_grid(minmax, nb, red);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { counters[W3D_CTL_KMIN] = dg.kmin; counters[W3D_CTL_MUL] = dg.mul; counters[W3D_CTL_RBITS] = dg.rbits; }
-    uint4 *hz = reinterpret_cast<uint4 *>(h_all[wv]);
-#pragma unroll
-    for (int i = 0; i < W3D_DB_BINS / 256; i++) hz[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
-    __builtin_amdgcn_wave_barrier();
-    if (run < n_runs) {
-        // (per-lane LDS atomics: finding the lanes of one bucket by ballots first — in Morton storage order a batch falls into a
-        //  handful of buckets — was measured and is slower, 25 -> 32 us)
-        const uint32_t beg = min(n, run * items), end = min(n, beg + items);
-#pragma unroll 8
-        for (uint32_t i = beg + lane; i < end; i += 64) {
-            const uint32_t key = keys[i];
-            if (key != W3D_INVALID_KEY) atomicAdd(&h_all[wv][depth_bucket(key, dg.kmin, dg.mul)], 1u);
-        }
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < W3D_DB_BINS; b += 256)
-        *reinterpret_cast<uint4 *>(&hist[(size_t)b * pitch + 4u * blockIdx.x]) = make_uint4(h_all[0][b], h_all[1][b], h_all[2][b], h_all[3][b]);
-}
-
 // inclusive scan across the 64 lanes of a wave
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     const int lane = threadIdx.x & 63;
@@ -149,6 +126,146 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
     return res;
 }
 
+// The view's grid: ONE workgroup of 1024 threads (built inside the histogram kernel by each of its 256 one-per-CU workgroups the
+// interval reduction + sample + scans sat on every workgroup's critical path: 25 -> 39 us).  Publishes head + table (grid_out) and
+// every bucket's interval of key offsets {lo, width} (brange).  A single workgroup lives on latency, so: every thread keeps its
+// entries in registers (one round of loads up to 2 M Gaussians), the 64-bit integer divisions (a software routine of ~200
+// instructions) are left to the one wave that owns the segments, and the sample is counted into 16 interleaved copies of the
+// segment histogram (neighbours in the Gaussian order lie at about the same depth: 64 lanes adding to one LDS word serialize).
+#define W3D_DG_THREADS 1024
+#define W3D_DG_HOLD 8            // entries a thread keeps in registers: one round of loads up to 8192 preprocess workgroups = 2 M Gaussians
+#define W3D_DG_COPIES 16
+__global__ void __launch_bounds__(W3D_DG_THREADS)
+depth_grid_kernel(const uint4 *__restrict__ entries, uint32_t nb,
+                  uint4 *__restrict__ grid_out /* [1 + W3D_DB_SEGS] */, uint2 *__restrict__ brange /* [W3D_DB_BINS] */,
+                  uint32_t *__restrict__ counters) {
+    __shared__ __align__(16) uint4 tab[W3D_DB_SEGS];
+    __shared__ uint32_t red[32], chist[W3D_DG_COPIES][W3D_DB_SEGS + 1], s_head[4];
+    static_assert(W3D_DB_SEGS == 64, "one wave owns the segments");
+    static_assert(W3D_DB_BINS == W3D_DG_THREADS, "one thread per bucket");
+    const uint32_t tid = threadIdx.x;
+    // the per-workgroup entries the preprocess left: nb = ceil(P / W3D_PRE_BLOCK) x {min, max, two of the workgroup's keys} — 125 KB of
+    // coalesced reads at 2 M Gaussians.  The two keys are the grid's population sample: one Gaussian in 128, spread evenly over the
+    // Gaussian order (in Morton order: over space); gathering a sample from the key array here cost 20 us — 8192 scattered lines
+    // through ONE CU.  Beyond W3D_DG_HOLD x 1024 entries the sample is every stride-th entry and the rest only feed the interval.
+    const uint32_t stride = (nb + W3D_DG_HOLD * W3D_DG_THREADS - 1) / (W3D_DG_HOLD * W3D_DG_THREADS);
+    const uint32_t ns = stride ? (nb + stride - 1) / stride : 0u;
+    uint4 m[W3D_DG_HOLD];
+#pragma unroll
+    for (int u = 0; u < W3D_DG_HOLD; u++) {
+        const uint32_t i = tid + (uint32_t)W3D_DG_THREADS * u;
+        m[u] = i < ns ? entries[(size_t)i * stride] : make_uint4(0xFFFFFFFFu, 0u, W3D_INVALID_KEY, W3D_INVALID_KEY);
+    }
+    for (uint32_t i = tid; i < W3D_DG_COPIES * (W3D_DB_SEGS + 1); i += W3D_DG_THREADS) (&chist[0][0])[i] = 0u;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int u = 0; u < W3D_DG_HOLD; u++) { kmin = min(kmin, m[u].x); kmax = max(kmax, m[u].y); }
+    if (stride > 1u)
+        for (uint32_t i = tid; i < nb; i += W3D_DG_THREADS) { const uint4 e = entries[i]; kmin = min(kmin, e.x); kmax = max(kmax, e.y); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+    }
+    if ((tid & 63) == 0) { red[tid >> 6] = kmin; red[16 + (tid >> 6)] = kmax; }
+    __syncthreads();
+    if (tid < 64) {
+        kmin = red[tid & 15]; kmax = red[16 + (tid & 15)];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+        }
+        if (tid == 0) {
+            uint32_t mseg = 0u, nbk = 0u;
+            const bool any = kmin <= kmax;
+            const uint32_t span = any ? kmax - kmin : 0u;
+            if (!any) kmin = 0u;                                                // nothing visible: no buckets
+            else if (span < W3D_DB_BINS) nbk = span + 1u;                       // one key value per bucket: nothing to sort inside
+            else mseg = (uint32_t)((1ull << (32 + W3D_DB_SEG_BITS)) / ((uint64_t)span + 1ull));   // (span * mseg) >> 32 < W3D_DB_SEGS; every segment >= 16 key values wide
+            s_head[0] = kmin; s_head[1] = mseg; s_head[2] = nbk; s_head[3] = span;
+        }
+    }
+    __syncthreads();
+    DepthGridHead h;
+    h.kmin = s_head[0]; h.mseg = s_head[1]; h.nbuckets = s_head[2]; h.pad = 0u;
+    if (h.mseg) {
+        const uint32_t span = s_head[3];
+        uint32_t *mine = chist[tid & (W3D_DG_COPIES - 1)];
+#pragma unroll
+        for (int u = 0; u < 2 * W3D_DG_HOLD; u++) {
+            const uint32_t key = (u & 1) ? m[u >> 1].w : m[u >> 1].z;
+            if (key != W3D_INVALID_KEY) atomicAdd(&mine[__umulhi(key - h.kmin, h.mseg)], 1u);
+        }
+        __syncthreads();
+        if (tid < W3D_DB_SEGS) {
+            // lane <-> segment: key-offset interval [start, end), share of the buckets, first bucket
+            const uint32_t start = (uint32_t)((((uint64_t)tid << 32) + h.mseg - 1u) / h.mseg);          // smallest x with (x * mseg) >> 32 == tid
+            const uint32_t nxt = (uint32_t)__shfl_down((int)start, 1, 64);
+            const uint32_t end = tid + 1u == W3D_DB_SEGS ? span + 1u : nxt;
+            uint32_t c = 0u;
+#pragma unroll
+            for (int k = 0; k < W3D_DG_COPIES; k++) c += chist[k][tid];
+            const uint32_t nsamp = (uint32_t)__shfl((int)wave_inclusive_scan(c), 63, 64);
+            const uint32_t width = end - start;
+            // (c <= 16384, the share is below 2^24: 32-bit arithmetic)
+            uint32_t cnt = 1u + ((uint32_t)(W3D_DB_BINS - W3D_DB_SEGS) * c) / max(nsamp, 1u);
+            cnt = min(cnt, width);                                             // never more buckets than key values
+            const uint32_t inc = wave_inclusive_scan(cnt);
+            // slope: ((x - start) * slope) >> 32 in [0, cnt) for x - start < width; cnt == width: one key value per bucket (slope 0)
+            const uint32_t slope = cnt == width ? 0u : (uint32_t)(((uint64_t)cnt << 32) / width);
+            const uint4 t = make_uint4(start, slope, (inc - cnt) | (cnt << 16), end);
+            tab[tid] = t; grid_out[1 + tid] = t;
+            if (tid == W3D_DB_SEGS - 1) s_head[2] = inc;
+        }
+        __syncthreads();
+        h.nbuckets = s_head[2];
+    }
+    if (tid == 0) { grid_out[0] = make_uint4(h.kmin, h.mseg, h.nbuckets, 0u); counters[W3D_CTL_KMIN] = h.kmin; counters[W3D_CTL_MUL] = h.mseg; }
+    // thread <-> bucket: its interval of key offsets (the in-bucket sort reads these 8 bytes instead of the table)
+    uint32_t lo = 0u, hi = 0u;
+    const bool ok = depth_bucket_range(tid, h, tab, lo, hi);
+    brange[tid] = ok ? make_uint2(lo, hi - lo) : make_uint2(0u, 0u);
+}
+
+// the published grid -> LDS (256 threads; includes the barrier)
+__device__ __forceinline__ DepthGridHead depth_grid_load(const uint4 *__restrict__ grid, uint4 *tab) {
+    const uint4 h4 = grid[0];
+    DepthGridHead h;
+    h.kmin = h4.x; h.mseg = h4.y; h.nbuckets = h4.z; h.pad = 0u;
+    if (h.mseg && threadIdx.x < W3D_DB_SEGS) tab[threadIdx.x] = grid[1 + threadIdx.x];
+    __syncthreads();
+    return h;
+}
+
+// one run per wave, four runs per workgroup; hist[bucket][run] (row pitch = runs rounded up to 4: the four counts of a workgroup
+// leave as one 16-B store per bucket)
+__global__ void __launch_bounds__(256)
+depth_bucket_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t items, uint32_t n_runs, uint32_t pitch,
+                         uint32_t *__restrict__ hist, const uint4 *__restrict__ grid) {
+    __shared__ __align__(16) uint32_t h_all[4][W3D_DB_BINS];
+    __shared__ __align__(16) uint4 tab[W3D_DB_SEGS];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t run = blockIdx.x * 4 + wv;
+    uint4 *hz = reinterpret_cast<uint4 *>(h_all[wv]);
+#pragma unroll
+    for (int i = 0; i < W3D_DB_BINS / 256; i++) hz[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
+    const DepthGridHead dg = depth_grid_load(grid, tab);
+    if (run < n_runs) {
+        // (per-lane LDS atomics: finding the lanes of one bucket by ballots first — in Morton storage order a batch falls into a
+        //  handful of buckets — was measured and is slower, 25 -> 32 us)
+        const uint32_t beg = min(n, run * items), end = min(n, beg + items);
+#pragma unroll 8
+        for (uint32_t i = beg + lane; i < end; i += 64) {
+            const uint32_t key = keys[i];
+            if (key != W3D_INVALID_KEY) atomicAdd(&h_all[wv][depth_bucket(key, dg, tab)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < W3D_DB_BINS; b += 256)
+        *reinterpret_cast<uint4 *>(&hist[(size_t)b * pitch + 4u * blockIdx.x]) = make_uint4(h_all[0][b], h_all[1][b], h_all[2][b], h_all[3][b]);
+}
+
 // one workgroup per bucket: exclusive scan of its row of run counts (in place, four runs per thread) + the bucket's total
 __global__ void __launch_bounds__(256)
 depth_bucket_scan_kernel(uint32_t *__restrict__ hist, uint32_t pitch, uint32_t *__restrict__ rowtot) {
@@ -171,12 +288,14 @@ depth_bucket_scan_kernel(uint32_t *__restrict__ hist, uint32_t pitch, uint32_t *
 __global__ void __launch_bounds__(256)
 depth_bucket_scatter_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                             uint32_t n, uint32_t items, uint32_t n_runs, uint32_t pitch, const uint32_t *__restrict__ offs,
-                            const uint32_t *__restrict__ rowtot, uint32_t *__restrict__ counters, uint32_t *__restrict__ bstart) {
+                            const uint32_t *__restrict__ rowtot, uint32_t *__restrict__ counters, uint32_t *__restrict__ bstart,
+                            const uint4 *__restrict__ grid) {
     __shared__ uint32_t cur_all[4][W3D_DB_BINS];
+    __shared__ __align__(16) uint4 tab[W3D_DB_SEGS];
     __shared__ uint32_t wave_tot[17];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t run = blockIdx.x * 4 + wv;
-    const uint32_t kmin = counters[W3D_CTL_KMIN], mul = counters[W3D_CTL_MUL];
+    const DepthGridHead dg = depth_grid_load(grid, tab);
     {
         // bucket bases = exclusive scan of the bucket totals (four consecutive buckets per thread); cursor of run r in bucket b =
         // base[b] + (counts of the runs before r in b)
@@ -208,7 +327,7 @@ depth_bucket_scatter_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__re
         const bool valid = key != W3D_INVALID_KEY;
         k1 = k2;
         k2 = (i + 128 < end) ? keys_in[i + 128] : W3D_INVALID_KEY;
-        const uint32_t d = valid ? depth_bucket(key, kmin, mul) : 0u;
+        const uint32_t d = valid ? depth_bucket(key, dg, tab) : 0u;
         // lanes holding the same bucket (stable rank = number of such lanes below me)
         uint64_t peers = w3d_ballot(valid);
 #pragma unroll
@@ -293,7 +412,8 @@ __device__ __forceinline__ void bucket_pass(const uint32_t *ksrc, const uint32_t
 // one workgroup per bucket: sort by the offset from the bucket's lower bound, write the depth-ordered packed records
 __global__ void __launch_bounds__(256)
 depth_bucket_sort_kernel(uint32_t *__restrict__ keys_a, uint32_t *__restrict__ vals_a, uint32_t *__restrict__ keys_b,
-                         uint32_t *__restrict__ vals_b, const uint32_t *__restrict__ counters, const uint32_t *__restrict__ bstart,
+                         uint32_t *__restrict__ vals_b, const uint4 *__restrict__ grid, const uint2 *__restrict__ brange,
+                         const uint32_t *__restrict__ bstart,
                          const uint2 *__restrict__ rect, const uint4 *__restrict__ rect_mask, uint4 *__restrict__ rec,
                          uint2 *__restrict__ rec_mask, int cull) {
     __shared__ uint32_t lc[2][W3D_DB_CAP];
@@ -301,8 +421,12 @@ depth_bucket_sort_kernel(uint32_t *__restrict__ keys_a, uint32_t *__restrict__ v
     __shared__ uint32_t wave_tot[17];
     const uint32_t beg = bstart[blockIdx.x], n = bstart[blockIdx.x + 1] - beg;
     if (n == 0) return;
-    const uint32_t rbits = counters[W3D_CTL_RBITS];
-    const uint32_t klo = counters[W3D_CTL_KMIN] + depth_bucket_lower(blockIdx.x, counters[W3D_CTL_MUL]);      // smallest key of this bucket
+    // this bucket's interval of key offsets: its width decides how many 8-bit passes the bucket needs (a bucket of a densely
+    // populated segment is narrow whatever the view's whole interval is)
+    const uint2 rng = brange[blockIdx.x];
+    const uint32_t klo = grid[0].x + rng.x;                                        // smallest key this bucket can hold
+    const uint32_t width = rng.y;
+    const uint32_t rbits = width > 1u ? 32u - (uint32_t)__builtin_clz(width - 1u) : 0u;
     const uint32_t npass = (rbits + 7u) / 8u;
     auto gather = [&](uint32_t g) -> uint4 {
         if (cull) return rect_mask[g];                   // one 16-B record per Gaussian: a single random line
@@ -735,7 +859,7 @@ W3DBands w3d_pick_bands(const W3DLayout &L, int mode) {
 }
 }  // namespace
 
-// stable depth sort of the visible Gaussians + depth-ordered packed records: four launches (see "depth sort" above)
+// stable depth sort of the visible Gaussians + depth-ordered packed records: five launches (see "depth sort" above)
 int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, char *scratch, hipStream_t stream) {
     uint32_t *counters = reinterpret_cast<uint32_t *>(state + L.o_counters);
     uint32_t *keys[2] = {reinterpret_cast<uint32_t *>(scratch + L.s_keys0), reinterpret_cast<uint32_t *>(scratch + L.s_keys1)};
@@ -746,17 +870,20 @@ int w3d_launch_depth_sort(const W3DLayout &L, const w3d_view &v, char *state, ch
     if (L.P == 0) return W3D_OK;
     const uint32_t n = (uint32_t)L.P, runs = L.sort_waves, blocks = (runs + 3) / 4, pitch = blocks * 4;
     W3D_PROF("depth_sort", stream);
-    hipLaunchKernelGGL(depth_bucket_hist_kernel, dim3(blocks), dim3(256), 0, stream, keys[0], n, L.sort_items, runs, pitch, hist, counters,
-                       reinterpret_cast<const uint2 *>(scratch + L.s_minmax), (n + W3D_PRE_BLOCK - 1) / W3D_PRE_BLOCK);
+    uint4 *grid = reinterpret_cast<uint4 *>(scratch + L.s_grid);
+    uint2 *brange = reinterpret_cast<uint2 *>(scratch + L.s_grid + 257 * 16);        // (the table region is sized for 256 segments)
+    hipLaunchKernelGGL(depth_grid_kernel, dim3(1), dim3(W3D_DG_THREADS), 0, stream, reinterpret_cast<const uint4 *>(scratch + L.s_minmax),
+                       (n + W3D_PRE_BLOCK - 1) / W3D_PRE_BLOCK, grid, brange, counters);
+    hipLaunchKernelGGL(depth_bucket_hist_kernel, dim3(blocks), dim3(256), 0, stream, keys[0], n, L.sort_items, runs, pitch, hist, (const uint4 *)grid);
     W3D_LAUNCH_CHECK(v.debug, stream);
     hipLaunchKernelGGL(depth_bucket_scan_kernel, dim3(W3D_DB_BINS), dim3(256), 0, stream, hist, pitch, rowtot);
     W3D_LAUNCH_CHECK(v.debug, stream);
     hipLaunchKernelGGL(depth_bucket_scatter_kernel, dim3(blocks), dim3(256), 0, stream, keys[0], keys[1], vals[1], n, L.sort_items, runs,
-                       pitch, hist, rowtot, counters, bstart);
+                       pitch, hist, rowtot, counters, bstart, (const uint4 *)grid);
     W3D_LAUNCH_CHECK(v.debug, stream);
     // (keys[0] / vals[0] — the unsorted keys are not needed any more — serve as the second buffer of a bucket that is too large for LDS)
-    hipLaunchKernelGGL(depth_bucket_sort_kernel, dim3(W3D_DB_BINS), dim3(256), 0, stream, keys[1], vals[1], keys[0], vals[0], counters,
-                       bstart, reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint4 *>(state + L.o_tile_mask),
+    hipLaunchKernelGGL(depth_bucket_sort_kernel, dim3(W3D_DB_BINS), dim3(256), 0, stream, keys[1], vals[1], keys[0], vals[0],
+                       (const uint4 *)grid, (const uint2 *)brange, bstart, reinterpret_cast<const uint2 *>(state + L.o_rect), reinterpret_cast<const uint4 *>(state + L.o_tile_mask),
                        reinterpret_cast<uint4 *>(scratch + L.s_rec), reinterpret_cast<uint2 *>(scratch + L.s_rec_mask), (int)v.tile_cull);
     W3D_LAUNCH_CHECK(v.debug, stream);
     return W3D_OK;

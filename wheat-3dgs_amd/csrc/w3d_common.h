@@ -68,7 +68,9 @@ struct W3DLayout {
     uint64_t s_hist;       // u32[W3D_DB_BINS * pitch] per-run bucket histograms of the depth sort (pitch = sort_waves rounded up to 4)
     uint64_t s_rowtot;     // u32[W3D_DB_BINS] bucket totals
     uint64_t s_bstart;     // u32[W3D_DB_BINS + 1] bucket boundaries in the depth order
-    uint64_t s_minmax;     // uint2[ceil(P / W3D_PRE_BLOCK)] {min, max} of the visible depth keys of every preprocess workgroup
+    uint64_t s_minmax;     // uint4[ceil(P / W3D_PRE_BLOCK)] {min, max} of the visible depth keys of every preprocess workgroup + two sample keys
+    uint64_t s_grid;       // uint4[1 + 256]: the depth sort's bucket grid of this view (w3d_binning.hip DepthGridHead + segment table),
+                           // followed by uint2[W3D_DB_BINS]: every bucket's {first key offset, width}
     uint64_t s_cnt;        // u16[C*T] per-chunk per-tile counts
     uint64_t s_off;        // u32[C*T] per-chunk per-tile list offsets
     uint64_t s_part;       // u32[SEGS*T]
@@ -121,10 +123,18 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->o_tile_order = o; o += w3d_align_up((uint64_t)8 * L->order_cap * 4);
     L->state_bytes = o;
     // depth sort geometry: one wave per contiguous run of sort_items keys
-    const uint64_t max_runs = 1024;              // one wave per SIMD (measured at P = 2 M: 512 runs 0.216 ms, 1024 0.161, 2048 0.177, 4096 0.214)
+    // (rounds 1-5, the 12-launch radix sort, at P = 2 M: 512 runs 0.216 ms, 1024 0.161, 2048 0.177, 4096 0.214; the bucket sort's
+    //  histogram + scatter: 1024 runs 52 us, 2048 runs 44 us, 4096 runs of 512 keys 47 us)
+#ifndef W3D_SORT_RUNS
+#define W3D_SORT_RUNS 2048
+#endif
+    const uint64_t max_runs = W3D_SORT_RUNS;
     uint64_t items = (Pp + max_runs - 1) / max_runs;
     items = (items + 63) / 64 * 64;
-    if (items < 1024) items = 1024;
+#ifndef W3D_SORT_ITEMS_MIN
+#define W3D_SORT_ITEMS_MIN 1024
+#endif
+    if (items < W3D_SORT_ITEMS_MIN) items = W3D_SORT_ITEMS_MIN;
     L->sort_items = (uint32_t)items;
     L->sort_waves = (uint32_t)((Pp + items - 1) / items);
     o = 0;
@@ -135,7 +145,8 @@ static inline int w3d_make_layout(int32_t P, int32_t H, int32_t W, W3DLayout *L)
     L->s_hist = o;  o += w3d_align_up((uint64_t)W3D_DB_BINS * ((L->sort_waves + 3) / 4 * 4) * 4);
     L->s_rowtot = o; o += w3d_align_up(W3D_DB_BINS * 4);
     L->s_bstart = o; o += w3d_align_up((W3D_DB_BINS + 1) * 4);
-    L->s_minmax = o; o += w3d_align_up((Pp + W3D_PRE_BLOCK - 1) / W3D_PRE_BLOCK * 8);
+    L->s_minmax = o; o += w3d_align_up((Pp + W3D_PRE_BLOCK - 1) / W3D_PRE_BLOCK * 16);
+    L->s_grid = o;  o += w3d_align_up(257 * 16 + W3D_DB_BINS * 8);
     L->s_cnt = o;   o += w3d_align_up((uint64_t)L->C * T * 2);
     L->s_off = o;   o += w3d_align_up((uint64_t)L->C * T * 4);
     L->s_part = o;  o += w3d_align_up((uint64_t)W3D_SCAN_SEGS * T * 4);

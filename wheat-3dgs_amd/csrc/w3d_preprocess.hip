@@ -293,7 +293,7 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, int lsx, int lsy, const
                       int32_t *__restrict__ radii, float4 *__restrict__ grec, ushort4 *__restrict__ rect,
                       uint8_t *__restrict__ clamped_out,
                       uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ counters,
-                      uint4 *__restrict__ tile_mask, const uint8_t *__restrict__ used_mask, uint2 *__restrict__ minmax) {
+                      uint4 *__restrict__ tile_mask, const uint8_t *__restrict__ used_mask, uint4 *__restrict__ minmax) {
 #pragma clang fp contract(off)
     // f_rest rows of one wave's 64 Gaussians (64 x 180 B, contiguous in memory) on their way to the lanes
     __shared__ float4 s_sh[RAW ? 4 : 1][RAW ? W3D_SH_CHUNKS / W3D_SH_ROUNDS : 1];
@@ -535,19 +535,20 @@ preprocess_fwd_kernel(w3d_view v, int P, int gx, int gy, int lsx, int lsy, const
     }
     {
         // the interval of this workgroup's visible depth keys, for the depth sort's bucket grid (w3d_binning.hip depth_grid): a culled
-        // Gaussian's key, 0xFFFFFFFF, is neutral for the minimum
-        __shared__ uint32_t s_mm[2][4];
+        // Gaussian's key, 0xFFFFFFFF, is neutral for the minimum.  Two of the keys (the first lanes of waves 1 and 3, culled or
+        // not) go along as the grid's population SAMPLE: one 16-B store per workgroup, nothing to initialise
+        __shared__ uint32_t s_mm[3][4];
         uint32_t kmn = key, kmx = vis ? key : 0u;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             kmn = min(kmn, (uint32_t)__shfl_xor((int)kmn, off, 64));
             kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, off, 64));
         }
-        if ((threadIdx.x & 63) == 0) { s_mm[0][threadIdx.x >> 6] = kmn; s_mm[1][threadIdx.x >> 6] = kmx; }
+        if ((threadIdx.x & 63) == 0) { s_mm[0][threadIdx.x >> 6] = kmn; s_mm[1][threadIdx.x >> 6] = kmx; s_mm[2][threadIdx.x >> 6] = key; }
         __syncthreads();
         if (threadIdx.x == 0)
-            minmax[blockIdx.x] = make_uint2(min(min(s_mm[0][0], s_mm[0][1]), min(s_mm[0][2], s_mm[0][3])),
-                                            max(max(s_mm[1][0], s_mm[1][1]), max(s_mm[1][2], s_mm[1][3])));
+            minmax[blockIdx.x] = make_uint4(min(min(s_mm[0][0], s_mm[0][1]), min(s_mm[0][2], s_mm[0][3])),
+                                            max(max(s_mm[1][0], s_mm[1][1]), max(s_mm[1][2], s_mm[1][3])), s_mm[2][1], s_mm[2][3]);
     }
     if (!valid) return;
     radii[g] = radius;
@@ -1230,7 +1231,7 @@ int w3d_launch_preprocess(const W3DLayout &L, const w3d_view &v, const float *me
         reinterpret_cast<float4 *>(state + L.o_grec), reinterpret_cast<ushort4 *>(state + L.o_rect),                 \
         reinterpret_cast<uint8_t *>(state + L.o_clamped), reinterpret_cast<uint32_t *>(scratch + L.s_keys0),         \
         reinterpret_cast<uint32_t *>(scratch + L.s_vals0), reinterpret_cast<uint32_t *>(state + L.o_counters),       \
-        reinterpret_cast<uint4 *>(state + L.o_tile_mask), used_mask, reinterpret_cast<uint2 *>(scratch + L.s_minmax)
+        reinterpret_cast<uint4 *>(state + L.o_tile_mask), used_mask, reinterpret_cast<uint4 *>(scratch + L.s_minmax)
     if (f_rest_raw) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(grid), dim3(block), 0, stream, ARGS);
     else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(grid), dim3(block), 0, stream, ARGS);
 #undef ARGS
