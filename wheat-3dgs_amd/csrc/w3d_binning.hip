@@ -255,10 +255,13 @@ depth_bucket_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t
         // (per-lane LDS atomics: finding the lanes of one bucket by ballots first — in Morton storage order a batch falls into a
         //  handful of buckets — was measured and is slower, 25 -> 32 us)
         const uint32_t beg = min(n, run * items), end = min(n, beg + items);
-#pragma unroll 8
-        for (uint32_t i = beg + lane; i < end; i += 64) {
-            const uint32_t key = keys[i];
-            if (key != W3D_INVALID_KEY) atomicAdd(&h_all[wv][depth_bucket(key, dg, tab)], 1u);
+        for (uint32_t i0 = beg + lane; i0 < end; i0 += 64u * 16u) {        // (sixteen loads in flight: the scatter kernel explains)
+            uint32_t kk[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) kk[u] = i0 + 64u * u < end ? keys[i0 + 64u * u] : W3D_INVALID_KEY;
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                if (kk[u] != W3D_INVALID_KEY) atomicAdd(&h_all[wv][depth_bucket(kk[u], dg, tab)], 1u);
         }
     }
     __syncthreads();
@@ -318,30 +321,38 @@ depth_bucket_scatter_kernel(const uint32_t *__restrict__ keys_in, uint32_t *__re
     uint32_t *cur = cur_all[wv];
     const uint32_t beg = min(n, run * items), end = min(n, beg + items);
     const uint64_t lt = lanemask_lt();
-    // software pipeline: the keys of the next two batches are in flight while the current batch is ranked
-    uint32_t k1 = (beg + lane < end) ? keys_in[beg + lane] : W3D_INVALID_KEY;
-    uint32_t k2 = (beg + 64 + lane < end) ? keys_in[beg + 64 + lane] : W3D_INVALID_KEY;
-    for (uint32_t base = beg; base < end; base += 64) {
-        const uint32_t i = base + lane;
-        const uint32_t key = k1;
-        const bool valid = key != W3D_INVALID_KEY;
-        k1 = k2;
-        k2 = (i + 128 < end) ? keys_in[i + 128] : W3D_INVALID_KEY;
-        const uint32_t d = valid ? depth_bucket(key, dg, tab) : 0u;
-        // lanes holding the same bucket (stable rank = number of such lanes below me)
-        uint64_t peers = w3d_ballot(valid);
+    // sixteen batches of keys (1024: a whole run at P <= 2 M) are requested at once, then ranked one after the other: with two
+    // waves per SIMD nothing else hides the latency of the loads (two batches in flight: 27 us, sixteen: see DESIGN.md section 2b)
+    constexpr int NBATCH = 16;
+    for (uint32_t base0 = beg; base0 < end; base0 += 64u * NBATCH) {
+        uint32_t kk[NBATCH];
 #pragma unroll
-        for (int b = 0; b < W3D_DB_BITS; b++) {
-            const uint64_t m = w3d_ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
+        for (int u = 0; u < NBATCH; u++) {
+            const uint32_t i = base0 + 64u * u + lane;
+            kk[u] = i < end ? keys_in[i] : W3D_INVALID_KEY;
         }
-        const uint32_t rank = __popcll(peers & lt);
-        uint32_t pos = 0;
-        if (valid) pos = cur[d] + rank;
-        __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) cur[d] = pos + (uint32_t)__popcll(peers);   // group leader advances the cursor
-        __builtin_amdgcn_wave_barrier();
-        if (valid) { keys_out[pos] = key; vals_out[pos] = i; }
+#pragma unroll
+        for (int u = 0; u < NBATCH; u++) {
+            const uint32_t i = base0 + 64u * u + lane;
+            if (base0 + 64u * u >= end) break;                              // (wave-uniform)
+            const uint32_t key = kk[u];
+            const bool valid = key != W3D_INVALID_KEY;
+            const uint32_t d = valid ? depth_bucket(key, dg, tab) : 0u;
+            // lanes holding the same bucket (stable rank = number of such lanes below me)
+            uint64_t peers = w3d_ballot(valid);
+#pragma unroll
+            for (int b = 0; b < W3D_DB_BITS; b++) {
+                const uint64_t m = w3d_ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? m : ~m;
+            }
+            const uint32_t rank = __popcll(peers & lt);
+            uint32_t pos = 0;
+            if (valid) pos = cur[d] + rank;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0) cur[d] = pos + (uint32_t)__popcll(peers);   // group leader advances the cursor
+            __builtin_amdgcn_wave_barrier();
+            if (valid) { keys_out[pos] = key; vals_out[pos] = i; }
+        }
     }
 }
 
@@ -809,7 +820,14 @@ chunk_off_kernel(const uint16_t *__restrict__ cnt, const uint32_t *__restrict__ 
     uint32_t run = tile_start[t];
     for (uint32_t s = 0; s < sg; s++) run += part[(size_t)s * T + t];
     uint32_t c = c0;
-    for (; c + 8 <= c1; c += 8) {         // 8 count loads in flight per step of the running sum
+    for (; c + 32 <= c1; c += 32) {       // 32 count loads in flight per step of the running sum
+        uint32_t v[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) v[i] = cnt[(size_t)(c + i) * T + t];
+#pragma unroll
+        for (int i = 0; i < 32; i++) { off[(size_t)(c + i) * T + t] = run; run += v[i]; }
+    }
+    for (; c + 8 <= c1; c += 8) {
         uint32_t v[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) v[i] = cnt[(size_t)(c + i) * T + t];
