@@ -411,6 +411,47 @@ def test_depth_sort_paths_and_tie_order_at_size(depth_span, P):
     o.free()
 
 
+@pytest.mark.parametrize("dist", ["lognormal", "bimodal", "power_tail", "one_outlier", "quantized", "thin_slab"])
+def test_depth_grid_on_skewed_depth_distributions(dist):
+    """The depth sort's bucket grid adapts to the view's depth distribution (w3d_binning.hip depth_grid_kernel): whatever it decides,
+    the result must be THE stable order by (depth bits, index).  Depth distributions that stress the grid — log-normal over five
+    octaves, two slabs 40 units apart, a power-law tail, ONE Gaussian far behind everything (the interval is almost empty), a few
+    hundred distinct depth values (ties across bucket bounds), a slab a few thousand key values thick (segments barely wider than
+    their bucket count: the one-key-per-bucket slope) — with a third of the Gaussians duplicated: per-tile ranges and lists
+    bit-identical to the oracle's."""
+    from w3d_amd.synth import make_scene, make_cameras
+    W, H, P = 320, 240, 60_000
+    sc = make_scene(P, seed=31, scale_mean=0.004)
+    g = torch.Generator().manual_seed(17)
+    z0 = sc.xyz[:, 2].clone()
+    if dist == "lognormal":
+        sc.xyz[:, 2] = 0.5 - torch.exp(1.2 * torch.randn(P, generator=g))
+    elif dist == "bimodal":
+        far = torch.rand(P, generator=g) < 0.5
+        sc.xyz[far, 2] = z0[far] - 40.0
+    elif dist == "power_tail":
+        sc.xyz[:, 2] = 0.5 - (torch.rand(P, generator=g).clamp_min(1e-4) ** -0.7 - 1.0)
+    elif dist == "one_outlier":
+        sc.xyz[P // 2, 2] = -500.0
+        sc.xyz[P // 2, :2] = 0.0
+    elif dist == "quantized":
+        sc.xyz[:, 2] = torch.round(z0 * 300.0) / 300.0
+        sc.xyz[:, :2] = torch.round(sc.xyz[:, :2] * 40.0) / 40.0
+    else:
+        sc.xyz[:, 2] = 0.3 + 2e-4 * torch.rand(P, generator=g)
+        sc.xyz[:, :2] *= 0.002
+        sc.opacity[:] = -4.0
+    cam, bg = make_cameras(6, W, H)[1], (0.0, 0.0, 0.0)
+    d = view_inputs(sc, cam)
+    d = {k: (None if v is None else torch.cat([v, v[: P // 3]], 0).contiguous()) for k, v in d.items()}
+    o = make_oracle(cam, bg, nthreads=8)
+    ref = o.forward(**np_inputs(d))
+    assert (ref["radii"] > 0).sum() > 0.2 * P, dist
+    out, _ = run_hip(d, cam, bg, tile_cull=False)
+    check_integers(out, o, ref)
+    o.free()
+
+
 @pytest.mark.parametrize("num_obj", [1, 5])
 def test_flashsplat_parity(num_obj):
     from flashsplat_rasterization import GaussianRasterizer
