@@ -6,19 +6,22 @@ SEGS, BINS, PRE_BLOCK, HOLD = 64, 1024, 256, 8 * 1024
 INVALID = 0xFFFFFFFF
 
 
-def grid_buckets(keys):
-    """keys: (P,) uint32 depth keys in storage order, 0xFFFFFFFF = culled.  Returns (populations[1024], widths[1024], nbuckets)."""
+def grid_buckets(keys, return_buckets=False):
+    """keys: (P,) uint32 depth keys in storage order, 0xFFFFFFFF = culled.  Returns (populations[1024], widths[1024], nbuckets)
+    and, with return_buckets, the bucket of every visible key (in storage order) as a fourth item."""
     keys = np.asarray(keys, dtype=np.int64)
     P = keys.shape[0]
     nb = (P + PRE_BLOCK - 1) // PRE_BLOCK
     vis = keys != INVALID
     kv = keys[vis]
     if kv.size == 0:
-        return np.zeros(BINS, np.int64), np.zeros(BINS, np.int64), 0
+        out = (np.zeros(BINS, np.int64), np.zeros(BINS, np.int64), 0)
+        return out + (np.zeros(0, np.int64),) if return_buckets else out
     kmin, kmax = int(kv.min()), int(kv.max())
     span = kmax - kmin
     if span < BINS:
-        return np.bincount(kv - kmin, minlength=BINS), (np.arange(BINS) <= span).astype(np.int64), span + 1
+        out = (np.bincount(kv - kmin, minlength=BINS), (np.arange(BINS) <= span).astype(np.int64), span + 1)
+        return out + (kv - kmin,) if return_buckets else out
     mseg = (1 << (32 + 6)) // (span + 1)
     stride = (nb + HOLD - 1) // HOLD
     ent = np.arange(0, nb, stride) * PRE_BLOCK
@@ -46,7 +49,8 @@ def grid_buckets(keys):
         lo = np.array(lo, dtype=np.int64)
         lo[-1] = width[s]
         widths[first[s]:first[s] + cnt[s]] = np.diff(lo)
-    return pop, widths, int(cnt.sum())
+    out = (pop, widths, int(cnt.sum()))
+    return out + (b,) if return_buckets else out
 
 
 def summary(pop, widths):
