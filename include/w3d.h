@@ -121,7 +121,7 @@ typedef struct w3d_view {
 
 /* Version of this ABI: major * 100 + minor.  The major number changes whenever a struct of this header changes its layout or
  * an entry point its signature; a binding must refuse a library whose major number differs from the header it mirrors. */
-#define W3D_ABI_VERSION 305
+#define W3D_ABI_VERSION 306
 int w3d_version(void);
 const char *w3d_last_error(void);
 
@@ -410,6 +410,11 @@ int w3d_debug_tile_schedule(int32_t H, int32_t W, int32_t P, const void *state, 
  * conic.x, conic.y, conic.z, opacity | r, g, b, depth | the conic scaled into the log2 domain, opacity}.  Records of culled
  * Gaussians (radii == 0) are NOT written: they hold whatever the buffer held before — gate on radii. */
 int w3d_debug_gaussian_records(int32_t H, int32_t W, int32_t P, const void *state, float *records_out, w3d_stream_t stream);
+/* Debug/inspection: the depth sort's bucket grid of the forward that last used this SCRATCH buffer (the caller must have kept it
+ * alive and the stream must be idle: synchronous copies).  bstart_out: HOST memory, 1025 u32 — bucket b holds the positions
+ * [bstart[b], bstart[b + 1]) of the depth order, bstart[1024] = visible Gaussians; brange_out: HOST memory, 2 x 1024 u32 —
+ * {lo, width} of the key offsets (key - smallest visible key) bucket b covers, {0, 0} past the grid's last bucket. */
+int w3d_debug_depth_buckets(int32_t H, int32_t W, int32_t P, const void *scratch, uint32_t *bstart_out, uint32_t *brange_out);
 /* Debug/inspection of the per-pixel state kept for backward: final_T (H,W) f32, n_contrib (H,W) u32. */
 int w3d_debug_pixel_state(int32_t H, int32_t W, int32_t P, const void *state, float *final_T_out,
                           uint32_t *n_contrib_out, w3d_stream_t stream);

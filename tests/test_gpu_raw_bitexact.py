@@ -86,3 +86,41 @@ def test_activations_bit_for_bit_on_adversarial_values():
     a, b = raw["rec"][vis].view(torch.int32), act["rec"][vis].view(torch.int32)
     assert torch.equal(a, b), f"{int((a != b).any(1).sum())} records differ; columns {(a != b).any(0).nonzero().flatten().tolist()}"
     assert torch.equal(raw["color"].view(torch.int32), act["color"].view(torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("far", [0.0, 0.002])
+def test_depth_grid_restatement_equals_the_kernels_grid(far):
+    """tests/depth_grid_model.py — which the sort tests use to assert that a scene reaches the large-bucket paths — against the grid
+    the library really built (w3d_debug_depth_buckets): bucket populations, bucket intervals and the bucket count agree exactly, on
+    an even view and on one whose depth interval a far background stretches."""
+    import numpy as np
+    from depth_grid_model import grid_buckets
+    from w3d_amd.fused_step import render_raw
+    from w3d_amd.gaussian_model import GaussianModel
+    from w3d_amd.rasterizer import debug_depth_buckets, debug_gaussian_records
+    from w3d_amd.synth import make_scene, make_cameras
+    dev = torch.device("cuda:0")
+    sc = make_scene(300_000, seed=3)
+    if far:
+        g = torch.Generator().manual_seed(2)
+        sel = torch.rand(sc.P, generator=g) < far
+        sc.xyz[sel, 2] = -30.0 - 30.0 * torch.rand(int(sel.sum()), generator=g)
+    m = GaussianModel(3, device=dev)
+    m.create_from_tensors(sc.xyz, sc.features_dc, sc.features_rest, sc.scaling, sc.rotation, sc.opacity)
+    m.active_sh_degree = 3
+    m.sort_spatially()
+    m.debug_keep_scratch = True
+    cam = make_cameras(6, 640, 480)[1].to(dev)
+    with torch.no_grad():
+        pkg = render_raw(cam, m, torch.zeros(3, device=dev), sync=True)
+    h = pkg["handle"]
+    bstart, brange = debug_depth_buckets(h)
+    vis = (pkg["radii"] > 0).cpu().numpy()
+    keys = debug_gaussian_records(h)[:, 11].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    keys[~vis] = 0xFFFFFFFF
+    pop, widths, nbk = grid_buckets(keys)
+    assert bstart[1024] == vis.sum() and vis.sum() > 100_000
+    assert np.array_equal(np.diff(bstart), pop)
+    assert np.array_equal(brange[:, 1], widths) and (brange[nbk:] == 0).all()
+    assert np.array_equal(brange[:nbk, 0], np.concatenate([[0], np.cumsum(widths[:nbk])[:-1]]))

@@ -544,6 +544,16 @@ int w3d_debug_gaussian_records(int32_t H, int32_t W, int32_t P, const void *stat
     return W3D_OK;
 }
 
+int w3d_debug_depth_buckets(int32_t H, int32_t W, int32_t P, const void *scratch, uint32_t *bstart_out, uint32_t *brange_out) {
+    W3DLayout L;
+    int rc = w3d_make_layout(P, H, W, &L);
+    if (rc || !scratch || !bstart_out || !brange_out) { w3d_set_error("bad arguments"); return W3D_ERR_INVALID; }
+    const char *s = static_cast<const char *>(scratch);
+    W3D_HIP_CHECK(hipMemcpy(bstart_out, s + L.s_bstart, (size_t)(W3D_DB_BINS + 1) * 4, hipMemcpyDeviceToHost));
+    W3D_HIP_CHECK(hipMemcpy(brange_out, s + L.s_grid + 257 * 16, (size_t)W3D_DB_BINS * 8, hipMemcpyDeviceToHost));
+    return W3D_OK;
+}
+
 int w3d_debug_pixel_state(int32_t H, int32_t W, int32_t P, const void *state, float *final_T_out,
                           uint32_t *n_contrib_out, w3d_stream_t stream_) {
     W3DLayout L;

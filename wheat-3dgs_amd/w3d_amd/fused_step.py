@@ -193,6 +193,8 @@ def render_raw(cam, model, bg_color, scaling_modifier=1.0, sync=True, flash=None
                                      ptr(contrib_num), ptr(proj_xy), ptr(gs_depth), stream))
     handle = dict(view=view, P=P, state=state, point_list=plist, radii=radii, num_rendered=R, num_visible=V,
                   capacity=R, pending=pending, cap=cap)
+    if getattr(model, "debug_keep_scratch", False):       # (rasterizer.debug_depth_buckets reads the sort's grid from it)
+        handle["scratch"] = scratch
     out = {"render": color, "radii": radii, "depth": depth, "alpha": alpha, "handle": handle}
     if flash is not None:
         out.update(contrib_num=contrib_num, used_count=used_count, proj_xy=proj_xy, gs_depth=gs_depth)

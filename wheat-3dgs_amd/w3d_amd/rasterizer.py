@@ -536,6 +536,21 @@ def debug_tile_schedule(saved):
     return out.astype(np.int64).reshape(8, cap.value)
 
 
+def debug_depth_buckets(saved):
+    """(bstart[1025], brange[1024, 2]) int64 numpy arrays: the depth sort's bucket grid of this forward (include/w3d.h
+    w3d_debug_depth_buckets).  The forward must have kept its scratch buffer (model.debug_keep_scratch = True for render_raw)."""
+    import numpy as np
+    if saved.get("scratch") is None:
+        raise RuntimeError("this forward did not keep its scratch buffer (set model.debug_keep_scratch = True)")
+    v = saved["view"].c
+    lib.w3d_debug_depth_buckets.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_void_p] * 3
+    lib.w3d_debug_depth_buckets.restype = ctypes.c_int
+    bstart, brange = np.empty(1025, np.uint32), np.empty((1024, 2), np.uint32)
+    torch.cuda.synchronize(saved["scratch"].device)
+    check(lib.w3d_debug_depth_buckets(v.image_height, v.image_width, saved["P"], ptr(saved["scratch"]), bstart.ctypes.data, brange.ctypes.data))
+    return bstart.astype(np.int64), brange.astype(np.int64)
+
+
 def debug_gaussian_records(saved):
     """(P,16) float32: the 64-B per-Gaussian records of a forward (include/w3d.h w3d_debug_gaussian_records); rows of culled
     Gaussians (radii == 0) are not written by the forward."""
