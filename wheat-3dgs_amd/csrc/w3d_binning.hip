@@ -51,6 +51,7 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x
 // distribution (tests/test_gpu_parity.py::test_depth_sort_paths_and_tie_order_at_size: lists bit-identical to the oracle's).
 #define W3D_CTL_KMIN 4          // counters[4] = smallest visible depth key
 #define W3D_CTL_MUL 5           // counters[5] = the grid's segment multiplier (0: the interval has fewer than 1024 key values, bucket = key - kmin)
+#define W3D_DB_FAST 2048        // ... and up to this many take the path that keeps the pairs in registers (depth_bucket_sort_kernel)
 #define W3D_DB_CAP 4096         // items a bucket may hold to be sorted in LDS (one 32-bit word each, 2 x 16 KB of ping-pong arrays: 4 workgroups per CU)
 
 // ---- the bucket grid of a view.  Equal-WIDTH buckets over [kmin, kmax] are only balanced when the depths are spread evenly: one
@@ -469,6 +470,45 @@ depth_bucket_sort_kernel(uint32_t *__restrict__ keys_a, uint32_t *__restrict__ v
     };
     if (npass == 0) {
         emit_all(keys_a + beg, vals_a + beg, [](uint32_t i) { return i; });
+    } else if (n <= W3D_DB_FAST && rbits <= 20u) {
+        // The usual bucket (the grid aims at ~1 200 keys): every thread keeps its up to 8 (key, id) pairs in registers and asks
+        // for their rect / mask lines BEFORE the sort — which lines are needed does not depend on the order, only where their
+        // records go — so the random gathers are in flight during the LDS passes; the sorted order is then inverted in LDS
+        // (source position -> rank) and every thread writes its own items' records to their ranks.  Two dependent memory
+        // round trips (pairs, gathers) instead of four (keys; sorted positions -> pairs; gathers).
+        constexpr int IT = W3D_DB_FAST / 256;
+        uint32_t *a0 = &lc[0][0], *a1 = &lc[0][W3D_DB_FAST], *inv = &lc[1][0];
+        uint32_t kk[IT], vv[IT];
+        uint4 gg[IT];
+#pragma unroll
+        for (int u = 0; u < IT; u++) {
+            const uint32_t i = threadIdx.x + 256u * u;
+            kk[u] = i < n ? keys_a[beg + i] : 0u;
+            vv[u] = i < n ? vals_a[beg + i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < IT; u++) {
+            const uint32_t i = threadIdx.x + 256u * u;
+            if (i < n) a0[i] = ((kk[u] - klo) << 12) | i;
+        }
+#pragma unroll
+        for (int u = 0; u < IT; u++) if (threadIdx.x + 256u * u < n) gg[u] = gather(vv[u]);
+        __syncthreads();                                       // (waits for LDS traffic only: the gathers stay in flight)
+        for (uint32_t p = 0; p < npass; p++) {
+            bucket_pass<0>(a0, nullptr, a1, nullptr, n, 0u, 12u + 8u * p, hw, wave_tot);
+            uint32_t *t = a0; a0 = a1; a1 = t;
+        }
+        for (uint32_t i = threadIdx.x; i < n; i += 256) inv[a0[i] & 4095u] = i;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < IT; u++) {
+            const uint32_t i = threadIdx.x + 256u * u;
+            if (i < n) {
+                const uint32_t d = beg + inv[i];
+                rec[d] = make_uint4(vv[u], gg[u].x, gg[u].y, kk[u]);          // (the sort key IS the view depth)
+                rec_mask[d] = make_uint2(gg[u].z, gg[u].w);
+            }
+        }
     } else if (n <= W3D_DB_CAP && rbits <= 20u) {
         // in LDS, one word per item: (offset of the key in the bucket) << 12 | position after the split
         for (uint32_t i = threadIdx.x; i < n; i += 256) lc[0][i] = ((keys_a[beg + i] - klo) << 12) | i;
