@@ -60,3 +60,18 @@ def summary(pop, widths):
     return {"max": int(pop.max()), "over_4096": int((pop > 4096).sum()), "over_8192": int((pop > 8192).sum()), "empty": int((pop == 0).sum()),
             "keys_by_passes": {str(p): int(pop[npass == p].sum()) for p in sorted(set(npass.tolist()))},
             "key_passes_per_key": round(float((pop * npass).sum()) / V, 3)}
+
+
+def bucket_paths(pop, widths):
+    """How many non-empty buckets take which branch of depth_bucket_sort_kernel: `direct` (one key value per bucket: no pass),
+    `fast` (<= 2048 keys: pairs in registers), `lds4096` (<= 4096: records emitted from the sorted positions), `mid` (<= 8192 keys,
+    two passes: one LDS array + one trip through the second global buffer), `global` (everything else)."""
+    rbits = np.where(widths > 1, np.ceil(np.log2(np.maximum(widths, 2))).astype(np.int64), 0)
+    npass = (rbits + 7) // 8
+    nz = pop > 0
+    direct = nz & (npass == 0)
+    fast = nz & ~direct & (pop <= 2048) & (rbits <= 20)
+    lds = nz & ~direct & ~fast & (pop <= 4096) & (rbits <= 20)
+    mid = nz & ~direct & ~fast & ~lds & (pop <= 8192) & (npass == 2) & (rbits <= 19)
+    glob = nz & ~direct & ~fast & ~lds & ~mid
+    return {"direct": int(direct.sum()), "fast": int(fast.sum()), "lds4096": int(lds.sum()), "mid": int(mid.sum()), "global": int(glob.sum())}

@@ -347,7 +347,7 @@ def test_culls_are_exact_on_needles(seed):
 
 
 @pytest.mark.parametrize("depth_span,P", [("narrow", 150_000), ("wide", 150_000), ("wide", 9_000), ("clustered", 120_000),
-                                          ("two_depths", 30_000), ("piled", 200_000), ("missed_pile", 199_936)])
+                                          ("two_depths", 30_000), ("piled", 200_000), ("missed_pile", 199_936), ("missed_pile_near", 199_936)])
 def test_depth_sort_paths_and_tie_order_at_size(depth_span, P):
     """The depth sort (w3d_binning.hip: 1024 buckets over the view's depth interval — a piecewise-linear grid, even in population as
     far as a sample of two keys per preprocess workgroup tells — every bucket sorted in LDS by its low bits) on enough Gaussians
@@ -359,24 +359,25 @@ def test_depth_sort_paths_and_tie_order_at_size(depth_span, P):
     grid did, and the densified benchmark scene showed 140-230 such buckets on some cameras) — the grid must spread it: no bucket
     beyond the LDS capacity; `missed_pile` — the same sheet, but the strewn Gaussians sit exactly at the storage positions the
     sample is taken from (lanes 64 and 192 of every 256), so the grid sees an even view and the sheet DOES land in a few buckets
-    of 5-20 k DIFFERENT keys: the one-LDS-array path (4 097-8 192 keys) and the in-bucket passes through global memory on real
-    digits.  A quarter of the Gaussians are exact duplicates of earlier ones (densify_and_clone's output), so equal keys must keep
+    of 5-60 k DIFFERENT keys: the in-bucket passes through global memory on real digits; `missed_pile_near` — the same with the
+    strewn Gaussians only 3 units deep, so the sheet spreads over ~60 buckets of 2-6 k keys: the 4 096-key LDS path and the
+    one-LDS-array path (4 097-8 192 keys).  A quarter of the Gaussians are exact duplicates of earlier ones (densify_and_clone's output), so equal keys must keep
     ascending index order.  Per-tile ranges and lists: bit-identical to the oracle's (stable order by (depth bits, index))."""
-    from depth_grid_model import grid_buckets, summary
+    from depth_grid_model import bucket_paths, grid_buckets, summary
     from w3d_amd.synth import make_scene, make_cameras
     W, H = 320, 240
     sc = make_scene(P, seed=23, scale_mean=0.004)
     g5 = torch.Generator().manual_seed(5)
     if depth_span == "wide":
         sc.xyz[:, 2] = 0.6 - 30.0 * torch.rand(P, generator=g5)
-    elif depth_span in ("piled", "missed_pile"):
+    elif depth_span in ("piled", "missed_pile", "missed_pile_near"):
         sc.xyz[:, 2] = 0.1 * torch.rand(P, generator=g5)
         sc.xyz[:, :2] *= 0.25                       # (seen obliquely, the sheet's lateral extent spreads its depths more than its thickness)
         far = torch.rand(P, generator=g5) < 0.01
-        if depth_span == "missed_pile":
+        if depth_span != "piled":
             assert P % 128 == 0                     # (the duplicates appended below keep their lane)
             far = torch.arange(P) % 128 == 64
-        sc.xyz[far, 2] = 0.6 - 30.0 * torch.rand(int(far.sum()), generator=g5)
+        sc.xyz[far, 2] = 0.6 - (3.0 if depth_span == "missed_pile_near" else 30.0) * torch.rand(int(far.sum()), generator=g5)
         sc.opacity[:] = -3.0
     elif depth_span in ("clustered", "two_depths"):
         k = 24 if depth_span == "clustered" else 2
@@ -392,17 +393,19 @@ def test_depth_sort_paths_and_tie_order_at_size(depth_span, P):
     octaves = float(np.log2(depth.max() / depth.min()))
     if depth_span in ("wide", "narrow"):
         assert (octaves > 2.5) if depth_span == "wide" else (octaves < 1.0), octaves
-    elif depth_span in ("piled", "missed_pile"):
+    elif depth_span in ("piled", "missed_pile", "missed_pile_near"):
         kk = depth.view(np.uint32).astype(np.int64)
         pop = np.bincount(((kk - kk.min()) * ((1 << 42) // (kk.max() - kk.min() + 1))) >> 32, minlength=1024)
-        assert (pop > 4096).sum() >= 5, pop.max()         # (equal-width buckets beyond the LDS capacity would exist)
+        assert (pop > 4096).sum() >= 5 or depth_span == "missed_pile_near", pop.max()    # (equal-width buckets beyond the LDS capacity would exist)
         keys = np.where(ref["radii"] > 0, o.geom()["depth"].view(np.uint32).astype(np.int64), 0xFFFFFFFF)
         gpop, gwidths, _ = grid_buckets(keys)
+        taken = bucket_paths(gpop, gwidths)
         if depth_span == "piled":
-            assert gpop.max() <= 4096, summary(gpop, gwidths)
+            assert gpop.max() <= 4096 and taken["fast"] > 500, (summary(gpop, gwidths), taken)
+        elif depth_span == "missed_pile":
+            assert taken["global"] >= 1 and gpop.max() > 8192, (summary(gpop, gwidths), taken)
         else:
-            mid = (gpop > 4096) & (gpop <= 8192)
-            assert mid.sum() >= 1 and (gpop > 8192).sum() >= 1, summary(gpop, gwidths)     # (both paths beyond the LDS ping-pong)
+            assert taken["lds4096"] >= 5 and taken["mid"] >= 5, (summary(gpop, gwidths), taken)
     else:
         assert len(np.unique(depth)) <= 24 and (ref["radii"] > 0).sum() > 0.5 * P
     out, _ = run_hip(d, cam, bg, tile_cull=False)
@@ -411,14 +414,16 @@ def test_depth_sort_paths_and_tie_order_at_size(depth_span, P):
     o.free()
 
 
-@pytest.mark.parametrize("dist", ["lognormal", "bimodal", "power_tail", "one_outlier", "quantized", "thin_slab"])
+@pytest.mark.parametrize("dist", ["lognormal", "bimodal", "power_tail", "one_outlier", "quantized", "thin_slab", "flat"])
 def test_depth_grid_on_skewed_depth_distributions(dist):
     """The depth sort's bucket grid adapts to the view's depth distribution (w3d_binning.hip depth_grid_kernel): whatever it decides,
     the result must be THE stable order by (depth bits, index).  Depth distributions that stress the grid — log-normal over five
     octaves, two slabs 40 units apart, a power-law tail, ONE Gaussian far behind everything (the interval is almost empty), a few
     hundred distinct depth values (ties across bucket bounds), a slab a few thousand key values thick (segments barely wider than
-    their bucket count: the one-key-per-bucket slope) — with a third of the Gaussians duplicated: per-tile ranges and lists
-    bit-identical to the oracle's."""
+    their bucket count: the one-key-per-bucket slope), a sheet facing the camera whose depths span fewer than 1024 key values (one
+    key value per bucket: no in-bucket pass, the records are emitted straight from the split) — with a third of the Gaussians
+    duplicated: per-tile ranges and lists bit-identical to the oracle's."""
+    from depth_grid_model import bucket_paths, grid_buckets
     from w3d_amd.synth import make_scene, make_cameras
     W, H, P = 320, 240, 60_000
     sc = make_scene(P, seed=31, scale_mean=0.004)
@@ -437,16 +442,24 @@ def test_depth_grid_on_skewed_depth_distributions(dist):
     elif dist == "quantized":
         sc.xyz[:, 2] = torch.round(z0 * 300.0) / 300.0
         sc.xyz[:, :2] = torch.round(sc.xyz[:, :2] * 40.0) / 40.0
-    else:
+    elif dist == "thin_slab":
         sc.xyz[:, 2] = 0.3 + 2e-4 * torch.rand(P, generator=g)
         sc.xyz[:, :2] *= 0.002
         sc.opacity[:] = -4.0
+    else:
+        sc.xyz[:, 2] = 0.3 + 2e-6 * torch.rand(P, generator=g)
+        sc.xyz[:, :2] *= 1e-4
+        sc.opacity[:] = -5.0
     cam, bg = make_cameras(6, W, H)[1], (0.0, 0.0, 0.0)
     d = view_inputs(sc, cam)
     d = {k: (None if v is None else torch.cat([v, v[: P // 3]], 0).contiguous()) for k, v in d.items()}
     o = make_oracle(cam, bg, nthreads=8)
     ref = o.forward(**np_inputs(d))
     assert (ref["radii"] > 0).sum() > 0.2 * P, dist
+    if dist == "flat":
+        keys = np.where(ref["radii"] > 0, o.geom()["depth"].view(np.uint32).astype(np.int64), 0xFFFFFFFF)
+        gpop, gwidths, nbk = grid_buckets(keys)
+        assert nbk < 1024 and bucket_paths(gpop, gwidths)["direct"] == (gpop > 0).sum(), (nbk, bucket_paths(gpop, gwidths))
     out, _ = run_hip(d, cam, bg, tile_cull=False)
     check_integers(out, o, ref)
     o.free()
