@@ -353,8 +353,8 @@ def test_depth_sort_paths_and_tie_order_at_size(depth_span, P):
     far as a sample of two keys per preprocess workgroup tells — every bucket sorted in LDS by its low bits) on enough Gaussians
     that every wave of the split holds keys: `narrow` — the benchmark's overhead cameras, depths within one octave (two in-bucket
     passes); `wide` — the slab stretched 30 units away from the cameras, depths 2 ... 33 (four octaves); `clustered` — all
-    Gaussians at 24 positions, 5 000 EQUAL keys each: buckets beyond the LDS arrays, nothing but ties; `two_depths` — two positions
-    (a span below 1024 key values needs no in-bucket pass at all); `piled` — 99 % of the Gaussians in a sheet 0.1 thick and 1 %
+    Gaussians at 24 positions, 5 000 EQUAL keys each: buckets beyond the LDS arrays, nothing but ties; `two_depths` — two positions:
+    two buckets of 20 000 equal keys each, far apart (the passes through global memory on nothing but ties); `piled` — 99 % of the Gaussians in a sheet 0.1 thick and 1 %
     strewn 30 units behind it: equal-WIDTH buckets would put the sheet into a few dozen of them, 5-10 k keys each (round 6's first
     grid did, and the densified benchmark scene showed 140-230 such buckets on some cameras) — the grid must spread it: no bucket
     beyond the LDS capacity; `missed_pile` — the same sheet, but the strewn Gaussians sit exactly at the storage positions the
