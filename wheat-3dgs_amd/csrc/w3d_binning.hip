@@ -594,7 +594,10 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
     const uint32_t s_beg = min(V, c * chunk), s_end = min(V, s_beg + chunk);
     // the first records are requested before the LDS set-up below, which hides their latency; NB 64-record
     // batches are kept in flight (rotating registers, so the loop body — and process() — exists once)
-    constexpr int NB = 4;
+#ifndef W3D_WALK_NB
+#define W3D_WALK_NB 2     // (measured, untrained / densified scene, count + fill in us: 1 -> 28.0 + 72.2 / 71.5 + 138.1, 2 -> 27.7 + 72.8 / 72.0 + 138.9,
+#endif                   //  3 -> 31.4 + 73.5 / 74.0 + 165.4, 4 -> 32.1 + 73.7 / 74.7 + 156.3, 8 -> 36.7 + 81.3 / 83.3 + 183.6)
+    constexpr int NB = W3D_WALK_NB;
     uint4 nx_rec[NB];
     uint2 nx_mask[NB];
     auto fetch_one = [&](uint32_t from, uint4 &r, uint2 &mk) {
