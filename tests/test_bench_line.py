@@ -72,3 +72,32 @@ def test_compact_line_with_an_exchange_object_and_without_a_cpu_baseline():
     full["exchange"]["rows"]["rows_per_view_last_step"] = list(range(100000, 100000 + 600))
     out = json.loads(bench.compact_line(full))
     assert out["value"] == full["value"] and out["roofline"]["frac"] > 0 and out["exchange"]["selfcheck_ok"] is True
+
+
+def test_committed_lines_of_this_round_are_what_the_contract_asks():
+    """The lines bench.py really printed on the GPU box this round (profiles/r06/bench_n1*.json: the default run of each
+    collection) — one line each, under 4 KB, with the contract's fields, the roofline and cpu_baseline objects, and the parity
+    statement with zero unattributed outliers; and the detail file written next to the newest one is the record it was cut from."""
+    import glob
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06", "bench_n1*.json")))
+    assert files
+    for f in files:
+        text = open(f).read().strip()
+        assert len(text.splitlines()) == 1 and len(text) < 4096, f
+        d = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in d, (f, k)
+        assert d["unit"] == "iters/s" and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["value"] > 100.0      # north star: >= 100
+        assert abs(d["value"] * d["ms_per_step"] - 1000.0) < 1.0
+        r = d["roofline"]
+        assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] < 1.0
+        assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["value"] > 0
+        if "parity" in d:
+            assert d["parity"]["statement"] == bench.PARITY_STATEMENT
+            assert d["parity"].get("unattributed_outliers", 0) == 0
+    newest = json.load(open(os.path.join(ROOT, "profiles", "r06", "bench_n1.json")))
+    detail = json.load(open(os.path.join(ROOT, "profiles", "r06", "bench_detail.json")))
+    assert detail["value"] == newest["value"] and detail["roofline"]["frac"] == newest["roofline"]["frac"]
+    assert json.loads(bench.compact_line(detail))["value"] == newest["value"]
