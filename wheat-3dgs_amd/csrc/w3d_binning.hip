@@ -555,13 +555,16 @@ depth_bucket_sort_kernel(uint32_t *__restrict__ keys_a, uint32_t *__restrict__ v
 #ifndef W3D_WALK_SMALL
 #define W3D_WALK_SMALL 16
 #endif
+#ifndef W3D_WALK_SMALL_SHARED
+#define W3D_WALK_SMALL_SHARED 8
+#endif
 #define W3D_WALK_QUEUE 128
 
 #ifndef W3D_WW
 #define W3D_WW 4          // (chunk, band) waves per workgroup of the walk: the 4 band-waves of a chunk share its records in L1
                           // (measured fill: 1 wave 0.255 ms, 2 -> 0.198, 4 -> 0.172, 8 -> 0.202, 16 -> 0.234)
 #endif
-template <int MODE, bool CULL>
+template <int MODE, bool CULL, int SMALL>
 __global__ void __launch_bounds__(64 * W3D_WW)
 chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_mask,
                   const uint32_t *__restrict__ counters,
@@ -643,7 +646,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
                 const uint32_t k_lo = (max(miny, y0) - miny) * w, k_hi = (min(maxy, y1) - miny) * w;
                 rm = (k_hi >= 64u ? ~0ull : ((1ull << k_hi) - 1ull)) & ~((1ull << k_lo) - 1ull);
                 if (CULL) rm &= (uint64_t)em.x | ((uint64_t)em.y << 32);
-                kind = __popcll(rm) > W3D_WALK_SMALL ? 1u : 0u;
+                kind = __popcll(rm) > SMALL ? 1u : 0u;
             } else {
                 kind = 2u;
             }
@@ -653,19 +656,19 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         const uint32_t magic = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)max(w, 1u)) + 0.004f) + 1u;
         const uint4 eb = make_uint4((uint32_t)rm, (uint32_t)(rm >> 32), er.w, er.z);     // (layout the whole-wave part reads)
         const uint64_t coop = w3d_ballot(lane < nq && kind != 0u);
-        // lane-parallel part: the (at most W3D_WALK_SMALL) tiles of this lane's record, derived once and kept in registers
+        // lane-parallel part: the (at most SMALL) tiles of this lane's record, derived once and kept in registers
         constexpr uint32_t NONE = 0xFFFFFFFFu;
-        uint32_t tls[W3D_WALK_SMALL];
+        uint32_t tls[SMALL];
         uint32_t kmax = 0;                                         // wave-uniform: slots [0, kmax) hold a tile for some lane
 #pragma unroll
-        for (int i = 0; i < W3D_WALK_SMALL; i++) tls[i] = NONE;
+        for (int i = 0; i < SMALL; i++) tls[i] = NONE;
         {
             uint64_t m = (lane < nq && kind == 0u) ? rm : 0ull;
             // tile of rect slot k (row ty = k / w): (miny + ty - y0) * gx + minx + k - ty * w = base + k + ty * (gx - w);
             // base may wrap below zero for a rect that starts above the band — the sum is taken modulo 2^32
             const uint32_t base = (miny - y0) * gx + minx, rowskip = gx - w;
 #pragma unroll
-            for (int i = 0; i < W3D_WALK_SMALL; i++) {
+            for (int i = 0; i < SMALL; i++) {
                 const bool v = m != 0ull;
                 if (w3d_ballot(v) == 0ull) break;                  // every lane has run out of tiles
                 kmax = (uint32_t)i + 1u;
@@ -703,7 +706,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         };
         if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < W3D_WALK_SMALL; i++) {
+            for (int i = 0; i < SMALL; i++) {
                 if ((uint32_t)i >= kmax) break;
                 if (tls[i] != NONE) atomicAdd(&h32[tls[i] >> 1], 1u << ((tls[i] & 1u) * 16u));
             }
@@ -711,7 +714,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         } else {
             const unsigned long long mybit = 1ull << lane;
 #pragma unroll
-            for (int i = 0; i < W3D_WALK_SMALL; i++) {
+            for (int i = 0; i < SMALL; i++) {
                 if ((uint32_t)i >= kmax) break;
                 if (tls[i] != NONE) atomicOr(&bm[tls[i]], mybit);
             }
@@ -719,7 +722,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
             __builtin_amdgcn_wave_barrier();
             // all cursor / bitmap reads of the batch are issued back to back, then the list entries are written
 #pragma unroll
-            for (int i0 = 0; i0 < W3D_WALK_SMALL; i0 += 8) {
+            for (int i0 = 0; i0 < SMALL; i0 += 8) {
                 if ((uint32_t)i0 >= kmax) break;
                 uint32_t hh[8];
                 unsigned long long bb[8];
@@ -962,12 +965,16 @@ static void launch_walk(const W3DLayout &L, const w3d_view &v, char *state, char
     const uint32_t *counters = reinterpret_cast<const uint32_t *>(state + L.o_counters);
     uint16_t *cnt = reinterpret_cast<uint16_t *>(scratch + L.s_cnt);
     const uint32_t *off = reinterpret_cast<const uint32_t *>(scratch + L.s_off);
-    if (v.tile_cull)
-        hipLaunchKernelGGL((chunk_walk_kernel<MODE, true>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C,
-                           (uint32_t)L.LT, (uint32_t)L.lgx, (uint32_t)L.lgy, bands.rows, cnt, off, point_list, capacity, wave_bytes);
-    else
-        hipLaunchKernelGGL((chunk_walk_kernel<MODE, false>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C,
-                           (uint32_t)L.LT, (uint32_t)L.lgx, (uint32_t)L.lgy, bands.rows, cnt, off, point_list, capacity, wave_bytes);
+    // records binned one per lane may touch at most SMALL cells of the band (larger ones go through the whole-wave part): 16 on
+    // the tile grid, 8 on a shared list grid, whose cells are 2-4 tiles (measured on the untrained scene's 32x32 cells: count
+    // 27.8 -> 25.6 us, fill 72.7 -> 70.9; on the densified scene's one list per tile 8 costs +14 us)
+    const bool shared = (L.lsx | L.lsy) != 0;
+#define W3D_WALK_LAUNCH(CULL_, SMALL_)                                                                                              \
+    hipLaunchKernelGGL((chunk_walk_kernel<MODE, CULL_, SMALL_>), grid, dim3(64 * W3D_WW), lds, stream, rec, rmask, counters, L.chunk, L.C, \
+                       (uint32_t)L.LT, (uint32_t)L.lgx, (uint32_t)L.lgy, bands.rows, cnt, off, point_list, capacity, wave_bytes)
+    if (v.tile_cull) { if (shared) W3D_WALK_LAUNCH(true, W3D_WALK_SMALL_SHARED); else W3D_WALK_LAUNCH(true, W3D_WALK_SMALL); }
+    else             { if (shared) W3D_WALK_LAUNCH(false, W3D_WALK_SMALL_SHARED); else W3D_WALK_LAUNCH(false, W3D_WALK_SMALL); }
+#undef W3D_WALK_LAUNCH
 }
 
 // per-chunk per-tile counts and the list offsets
