@@ -658,6 +658,7 @@ chunk_walk_kernel(const uint4 *__restrict__ rec, const uint2 *__restrict__ rec_m
         const uint64_t coop = w3d_ballot(lane < nq && kind != 0u);
         // lane-parallel part: the (at most SMALL) tiles of this lane's record, derived once and kept in registers
         constexpr uint32_t NONE = 0xFFFFFFFFu;
+        static_assert(SMALL % 8 == 0, "the fill pass reads the slots eight at a time");
         uint32_t tls[SMALL];
         uint32_t kmax = 0;                                         // wave-uniform: slots [0, kmax) hold a tile for some lane
 #pragma unroll
