@@ -41,18 +41,19 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << (threadIdx.x
 //                             offset from the bucket's lower bound (`rbits` bits: the width of a bucket) — ceil(rbits / 8) stable
 //                             8-bit passes, 2 for the benchmark cameras — and written out as
 //                             the depth-ordered packed records {id, rect lo, rect hi, depth} + tile mask the (chunk, band) walkers
-//                             stream.  A bucket that does not fit the LDS arrays (everything at one depth, 40 M Gaussians, the piled
-//                             depths of some cameras of the densified benchmark scene: 140-230 buckets of 4 100-9 700 keys) takes
-//                             the same passes through its own slice of the two global (key, id) buffers — slower, same result
-//                             (depth sort 0.141 ms on that scene against 0.099; a second launch with 128 KB of LDS for those
-//                             buckets was measured and is slower still: its 1024 one-per-CU workgroups cost 12 us when idle).
+//                             stream.  A bucket that does not fit the LDS arrays (everything at one depth, 40 M Gaussians, a pile
+//                             the grid's sample did not see) takes the same passes through its own slice of the two global
+//                             (key, id) buffers — slower, same result (with round 6's first, equal-width grid the densified
+//                             benchmark scene had 140-230 such buckets on some cameras: 0.141 ms against 0.099; a second launch
+//                             with 128 KB of LDS for those buckets was measured and is slower still: its 1024 one-per-CU
+//                             workgroups cost 12 us when idle).
 // Bucket b holds exactly the keys of [kmin + lo(b), kmin + lo(b) + width(b)) (depth_bucket_range); the scatter keeps index order inside a
 // bucket and the in-bucket passes are stable, so the result is THE stable order by (depth bits, index), whatever the depth
 // distribution (tests/test_gpu_parity.py::test_depth_sort_paths_and_tie_order_at_size: lists bit-identical to the oracle's).
 #define W3D_CTL_KMIN 4          // counters[4] = smallest visible depth key
 #define W3D_CTL_MUL 5           // counters[5] = the grid's segment multiplier (0: the interval has fewer than 1024 key values, bucket = key - kmin)
-#define W3D_DB_FAST 2048        // ... and up to this many take the path that keeps the pairs in registers (depth_bucket_sort_kernel)
 #define W3D_DB_CAP 4096         // items a bucket may hold to be sorted in LDS (one 32-bit word each, 2 x 16 KB of ping-pong arrays: 4 workgroups per CU)
+#define W3D_DB_FAST 2048        // ... and up to this many take the path that keeps the pairs in registers (depth_bucket_sort_kernel)
 
 // ---- the bucket grid of a view.  Equal-WIDTH buckets over [kmin, kmax] are only balanced when the depths are spread evenly: one
 // Gaussian in a thousand far behind the scene (a background 30-60 units away) stretches the interval to five octaves, the scene keeps
